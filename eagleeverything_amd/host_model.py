@@ -1,0 +1,87 @@
+"""Host-side dense n x n model algebra that feeds the marker scan (stays on the host by design).
+
+north_star keeps calculateH / calculateP / the eigendecomposition of MM^T on host LAPACK; in the R
+package these are base-R calls.  This numpy restatement exists so that the scan can be driven with
+realistic operands (S = MMt^-1/2, V = Var(a_hat), a_hat) on a box without R.  It is *not* part of
+the GPU hot path and is not a fallback for it.
+
+Reference lines (E/ = MyPackage/Eagle/):
+  calculateH ........................ E/R/calculateH.R:36
+  calculateP ........................ E/R/calculateP.R:27-28
+  calculateMMt_sqrt_and_sqrtinv ..... E/R/calculateMMt_sqrt_and_sqrtinv.R:15-47
+  calculate_reduced_a ............... E/R/calculate_reduced_a.R:31
+  calculate_reduced_vara ............ E/R/calculate_reduced_vara.R:21-35
+No recorded outputs exist in the reference for any of these: parity unpinned.
+"""
+import numpy as np
+import scipy.linalg as sla
+
+
+def calculateH(MMt, varE, varG):
+    if varE < 0 or varG < 0:
+        raise ValueError("variance components cannot be negative")  # calculateH.R:19-30
+    n = MMt.shape[0]
+    return varE * np.eye(n) + varG * MMt
+
+
+def _chol2inv(A):
+    c, low = sla.cho_factor(A, lower=False, check_finite=False)
+    return sla.cho_solve((c, low), np.eye(A.shape[0]), check_finite=False)
+
+
+def calculateP(H, X):
+    if H.shape[0] != X.shape[0]:
+        raise ValueError("The number of rows in H and X are not the same.")  # calculateP.R:22-25
+    Hinv = _chol2inv(H)
+    HX = Hinv @ X
+    return Hinv - HX @ np.linalg.solve(X.T @ HX, HX.T)
+
+
+def calculateMMt_sqrt_and_sqrtinv(MMt, checkres=True):
+    """eigen(MMt, symmetric=TRUE); sqrt = U diag(sqrt(l)) U^T ; invsqrt = chol2inv(chol(sqrt))."""
+    evals, U = np.linalg.eigh(MMt)
+    if evals.min() <= 0:
+        raise ValueError("M %*% t(M) is not positive definite")  # :15-23
+    sq = (U * np.sqrt(evals)) @ U.T
+    sq = 0.5 * (sq + sq.T)
+    inv = _chol2inv(sq)
+    if checkres:  # :35-46
+        tr = np.trace(sq @ inv)
+        if int(np.trunc(tr)) != MMt.shape[0]:
+            import warnings
+            warnings.warn("sqrt(MMt) %*% invsqrt(MMt) trace = %r, expected %d" % (tr, MMt.shape[0]))
+    return {"sqrt_MMt": sq, "inverse_sqrt_MMt": inv}
+
+
+def calculate_reduced_a(varG, P, MMtsqrt, y):
+    if P.shape[0] != np.size(y):
+        raise ValueError("dimension mismatch between P and y")
+    return varG * (MMtsqrt @ (P @ np.ravel(y)))
+
+
+def calculate_reduced_vara(X, varE, varG, invMMt, MMtsqrt):
+    """vars = varG*I - (D1 + D1 C (A - B D1 C)^-1 B D1)   (calculate_reduced_vara.R:21-35)."""
+    n = invMMt.shape[0]
+    Ze = MMtsqrt
+    r1 = 1.0 / varE
+    g1 = 1.0 / varG
+    A = r1 * (X.T @ X)
+    B = r1 * (X.T @ Ze)
+    Cm = r1 * (Ze.T @ X)
+    D = r1 * (Ze.T @ Ze) + g1 * np.eye(n)
+    D1 = np.linalg.inv(D)
+    D1C = D1 @ Cm
+    BD1 = B @ D1
+    mid = np.linalg.solve(A - B @ D1C, BD1)
+    return varG * np.eye(n) - (D1 + D1C @ mid)
+
+
+def scan_operands(MMt_norm, X, y, varE, varG):
+    """Everything .find_qtl (E/R/find_qtl.R:5-49) builds before calling calculate_a_and_vara."""
+    H = calculateH(MMt_norm, varE, varG)
+    P = calculateP(H, X)
+    sq = calculateMMt_sqrt_and_sqrtinv(MMt_norm, checkres=False)
+    hat_a = calculate_reduced_a(varG, P, sq["sqrt_MMt"], y)
+    invMMt = _chol2inv(MMt_norm)  # AM.R:422
+    var_hat_a = calculate_reduced_vara(X, varE, varG, invMMt, sq["sqrt_MMt"])
+    return {"S": sq["inverse_sqrt_MMt"], "Shalf": sq["sqrt_MMt"], "V": var_hat_a, "ahat": hat_a, "P": P}

@@ -1,0 +1,32 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+    return load
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle_c
+    oracle_c.build()
+    return oracle_c
+
+
+GOLDEN_CASES = ["geno_150x100", "genoDemo_150x4998", "synth_203x1531"]
