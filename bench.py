@@ -1,0 +1,274 @@
+#!/usr/bin/env python3
+"""bench.py -- markers/sec through the calculate_a_and_vara genome scan (+ MM^T build wall-clock) on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json configs[1]): synthetic 5,000 individuals x 500,000 biallelic SNPs per GPU, single trait,
+genotypes resident in HBM as int8 before the timed region.  A "step" is one full pass of the reference's
+calculate_a_and_vara_rcpp (v = S a_hat, a = Mt v, W = S V S, T = Mt W, vara_i = T_i . m_i;
+E/src/calculate_a_and_vara_rcpp.cpp:90-112) followed by find_qtl's tsq / arg-max (E/R/find_qtl.R:71-83) over all
+markers of the rank's shard; for N > 1 the shards' (max tsq, first index) pairs are all-gathered inside the step.
+Weak scaling: every rank holds L markers, value = N*L / max-over-ranks time.  The MM^T build
+(calculateMMt_rcpp.cpp:95; partial int32 SYRK per rank + one RCCL all-reduce) is timed separately and reported
+as mmt_build_s.  The CPU baseline is the C oracle (a port of the reference's in-memory branch) on a bounded
+marker sample on rank 0's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix, AMD datasheet (the microarch guide lists no fp64 row)
+I8_MFMA_PEAK_TOPS = 5000.0     # dense int8 = 2x the 2.5 PF bf16 dense peak (MI355X_MICROARCH.md, Matrix cores)
+HBM_PEAK_GBS = 8000.0
+
+
+def host_operands_torch(torch, MMt_norm, X, y, varE, varG):
+    """E/R/find_qtl.R:5-49 (calculateH, calculateP, MMt^{+-1/2}, a_hat, Var a_hat) in fp64 on the device --
+    input manufacturing for the scan, not part of the timed path (same formulas as eagleeverything_amd.host_model)."""
+    n = MMt_norm.shape[0]
+    I = torch.eye(n, dtype=torch.float64, device=MMt_norm.device)
+    H = varE * I + varG * MMt_norm
+    Hinv = torch.cholesky_inverse(torch.linalg.cholesky(H))
+    HX = Hinv @ X
+    P = Hinv - HX @ torch.linalg.solve(X.T @ HX, HX.T)
+    ev, U = torch.linalg.eigh(MMt_norm)
+    sq = (U * ev.sqrt()) @ U.T
+    sq = 0.5 * (sq + sq.T)
+    S = torch.cholesky_inverse(torch.linalg.cholesky(sq))
+    ahat = varG * (sq @ (P @ y))
+    r1, g1 = 1.0 / varE, 1.0 / varG
+    A = r1 * (X.T @ X)
+    B = r1 * (X.T @ sq)
+    D1 = torch.cholesky_inverse(torch.linalg.cholesky(r1 * (sq.T @ sq) + g1 * I))  # D is SPD
+    D1C = D1 @ B.T
+    V = varG * I - (D1 + D1C @ torch.linalg.solve(A - B @ D1C, B @ D1))
+    return S, V, ahat
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=5000, help="individuals")
+    ap.add_argument("--markers", type=int, default=500000, help="markers per GPU")
+    ap.add_argument("--mode", choices=["f64", "i8"], default=os.environ.get("EAGLE_SCAN_MODE", "f64"))
+    ap.add_argument("--mmt-reps", type=int, default=2)
+    ap.add_argument("--cpu-sample", type=int, default=32768, help="markers in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--simple-operands", action="store_true", help="seeded random SPD S / V instead of the model algebra")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from eagleeverything_amd import rcpp_api
+    from eagleeverything_amd.sharded import Collectives, DeviceShard
+
+    coll = Collectives(dist if world > 1 else None)
+    info = rcpp_api.device_info(local_rank)
+    n, Lloc = args.n, args.markers
+    Ltot = Lloc * world
+    dev = torch.device("cuda", local_rank)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- resident inputs (untimed) ---------------------------------------------------------------
+    t0 = time.time()
+    sh = DeviceShard(n, Lloc, first_marker=rank * Lloc, device=local_rank)
+    sh.mode = 0 if args.mode == "f64" else 1
+    sh.fill_synthetic()
+    sh.individual_major()
+    torch.cuda.synchronize(dev)
+    t_gen = time.time() - t0
+
+    # ---- MM^T build: partial SYRK per shard + one all-reduce + finish (timed separately) ----------
+    c32 = torch.empty((sh.np_, sh.np_), dtype=torch.int32, device=dev)
+    mmt_times = []
+    ev_k0, ev_k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    syrk_ms = []
+    MMt = None
+    for rep in range(args.mmt_reps + 1):
+        barrier()
+        t1 = time.perf_counter()
+        c32.zero_()
+        ev_k0.record()
+        sh.mmt_partial(out=c32)
+        ev_k1.record()
+        coll.sum_partial_mmt(c32)
+        MMt, mx = sh.mmt_finish(c32, normalise=True)
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t1)
+        if rep > 0:
+            mmt_times.append(dt)
+            syrk_ms.append(ev_k0.elapsed_time(ev_k1))
+    mmt_build_s = float(np.mean(mmt_times))
+    syrk_s = float(np.mean(syrk_ms)) / 1e3
+
+    # ---- scan operands from the model algebra on the actual MM^T (untimed input manufacturing) ----
+    t2 = time.time()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    if rank == 0:
+        qtl = torch.linspace(0, Lloc - 1, 12, device=dev).long()[1:-1]
+        y = 0.5 * sh.Mt8[qtl, :n].double().sum(0) + torch.randn(n, generator=gen, device=dev, dtype=torch.float64)
+        X = torch.ones((n, 1), dtype=torch.float64, device=dev)
+        if args.simple_operands:
+            A = torch.randn((n, 64), generator=gen, device=dev, dtype=torch.float64) / 8.0
+            S = torch.eye(n, dtype=torch.float64, device=dev) + A @ A.T
+            V = 0.5 * torch.eye(n, dtype=torch.float64, device=dev) - 0.01 * (A[:, :8] @ A[:, :8].T)
+            ahat = torch.randn(n, generator=gen, device=dev, dtype=torch.float64)
+        else:
+            S, V, ahat = host_operands_torch(torch, MMt, X, y, 1.0, 0.5)
+    else:
+        S = torch.empty((n, n), dtype=torch.float64, device=dev)
+        V = torch.empty((n, n), dtype=torch.float64, device=dev)
+        ahat = torch.empty(n, dtype=torch.float64, device=dev)
+    S, V, ahat = S.contiguous(), V.contiguous(), ahat.contiguous()
+    coll.broadcast_(S); coll.broadcast_(V); coll.broadcast_(ahat)
+    sh.set_operands(S, V, ahat)
+    torch.cuda.synchronize(dev)
+    t_ops = time.time() - t2
+    del MMt, c32
+
+    # ---- timed scan steps -------------------------------------------------------------------------
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev_gemv = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        sh.scan_operands()
+        if i is not None:
+            ev_gemv[i][0].record()
+        sh.gemv_a()
+        if i is not None:
+            ev_gemv[i][1].record()
+            ev[i][0].record()
+        sh.vara_kernel()
+        if i is not None:
+            ev[i][1].record()
+        sh.argmax()
+        tsqmax, gidx, near = sh.best()
+        return coll.best_marker(tsqmax, gidx, device=dev)
+
+    for _ in range(args.warmup):
+        sel = step()
+    barrier()
+    t3 = time.perf_counter()
+    for i in range(args.steps):
+        sel = step(i)
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t3)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = Ltot * args.steps / elapsed
+    kern_s = float(np.mean([a.elapsed_time(b) for a, b in ev])) / 1e3
+    gemv_s = float(np.mean([a.elapsed_time(b) for a, b in ev_gemv])) / 1e3
+
+    # ---- roofline of the dominant kernel (vara) ---------------------------------------------------
+    np_, Lp = sh.np_, sh.Lp
+    nct = np_ // 128
+    if sh.mode == 0:
+        # executed = algorithmic for the triangular fp64 kernel: column tile ct needs k < (ct+1)*128
+        flops = sum(2.0 * Lp * 128 * min((ct + 1) * 128, np_) for ct in range(nct))
+        roof = {"bound": "mfma", "kernel": "k_gemm_f64<int8 A, row-dot> (v_mfma_f64_16x16x4_f64)", "dtype": "f64",
+                "achieved": flops / kern_s / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
+    else:
+        ops = sum(2.0 * Lp * 128 * min((ct + 1) * 128, np_) for ct in range(nct)) * sh.nslices
+        roof = {"bound": "mfma", "kernel": "k_vara_i8 (v_mfma_i32_32x32x32_i8, %d slices)" % sh.nslices, "dtype": "i8",
+                "achieved": ops / kern_s / 1e12, "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s"}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    roof["traffic"] = None  # HBM bytes per launch from the PMC pass: see profiles/ and DESIGN.md
+    roof["kernel_ms"] = kern_s * 1e3
+    roof["reference_flops_per_launch"] = 2.0 * Lloc * n * n + 2.0 * Lloc * n
+    roof["fp64_equiv_tflops"] = roof["reference_flops_per_launch"] / kern_s / 1e12
+    secondary = {
+        "gemv_a": {"bound": "hbm", "achieved": Lp * np_ / gemv_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": Lp * np_ / gemv_s / 1e9 / HBM_PEAK_GBS, "kernel_ms": gemv_s * 1e3},
+        "syrk_i8": {"bound": "mfma", "achieved": (np_ * (np_ + 128.0)) * Lp / syrk_s / 1e12, "peak": I8_MFMA_PEAK_TOPS,
+                    "unit": "TFLOP/s", "frac": (np_ * (np_ + 128.0)) * Lp / syrk_s / 1e12 / I8_MFMA_PEAK_TOPS,
+                    "kernel_ms": syrk_s * 1e3},
+    }
+
+    # ---- CPU baseline + parity gate on a bounded sample (rank 0, N = 1 only) ----------------------
+    cpu = None
+    parity = None
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        # the box gives one GPU a 16-core share of the host: keep the baseline inside it
+        from oracle import oracle_c  # checker / baseline only
+        oracle_c.build()
+        oracle_c.set_num_threads(int(os.environ.get("OMP_NUM_THREADS", min(16, os.cpu_count() or 1))))
+        ns = min(args.cpu_sample, Lloc)
+        Mt_s = sh.Mt8[:ns, :n].cpu().numpy()
+        Sh, Vh, ah = S.cpu().numpy(), V.cpu().numpy(), ahat.cpu().numpy()
+        v_h, W_h = oracle_c.scan_operands(Sh, Vh, ah)          # n^3 part, done once per call in the reference too
+        tc = time.perf_counter()
+        a_ref, vara_ref = oracle_c.scan_from_i8_with_W(Mt_s, v_h, W_h)
+        cpu_s = time.perf_counter() - tc
+        cores = oracle_c.num_threads()
+        cpu = {"value": ns / cpu_s, "unit": "markers/s", "cores": cores, "kind": "port",
+               "sample": "first %d markers of the %dx%d shard, reference in-memory branch order (GEMV, T=Mt*W, row-dot; "
+                         "calculate_a_and_vara_rcpp.cpp:91-112), W=S*V*S precomputed and excluded" % (ns, n, Lloc),
+               "seconds": cpu_s}
+        a_g = sh.a[:ns].cpu().numpy()
+        v_g = sh.vara[:ns].cpu().numpy()
+        rel = lambda x, r: float(np.max(np.abs(x - r)) / np.max(np.abs(r)))
+        parity = {"a_max_rel": rel(a_g, a_ref), "vara_max_rel": float(np.max(np.abs(v_g - vara_ref) / np.abs(vara_ref))),
+                  "sample_argmax_equal": bool(np.argmax(a_g ** 2 / v_g) == np.argmax(a_ref ** 2 / vara_ref))}
+        # MM^T baseline on a marker subsample, scaled linearly in L
+        nm = min(4096, Lloc)
+        M_s = np.ascontiguousarray(sh.Mt8[:nm, :n].cpu().numpy().T)
+        tc = time.perf_counter()
+        mm_ref = oracle_c.mmt_from_i8(M_s)
+        mm_s = time.perf_counter() - tc
+        cpu["mmt_build_s_est"] = mm_s * Lloc / nm
+        cpu["mmt_sample"] = "%d markers, scaled linearly to %d" % (nm, Lloc)
+
+    if rank == 0:
+        out = {
+            "metric": "markers/sec in calculate_a_and_vara scan", "value": value, "unit": "markers/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64" if sh.mode == 0 else "i8+f64", "data": "synthetic",
+            "config": {"workload": "synthetic %d individuals x %d SNPs per GPU (HWE genotypes, int8 resident in HBM), "
+                                   "single trait, full calculate_a_and_vara pass + tsq arg-max" % (n, Lloc),
+                       "n": n, "markers_per_gpu": Lloc, "markers_total": Ltot, "parallelism": "marker-shard x%d" % world,
+                       "scan_mode": args.mode, "operands": "simple" if args.simple_operands else "model algebra on MM^T"},
+            "mmt_build_s": mmt_build_s, "selected_marker": int(sel[0]), "tsqmax": sel[1],
+            "roofline": roof, "roofline_secondary": secondary, "cpu_baseline": cpu, "parity": parity,
+            "device": info, "setup_s": {"genotypes": t_gen, "operands": t_ops},
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,685 @@
+// eagle_api.cpp -- host side of libeaglehip.so: context, genotype tile streamer, and the
+// reference-shaped entry points of section 1 of include/eagle_hip.h.
+//
+// What is replaced (E/ = MyPackage/Eagle/ of the reference):
+//   eagle_read_block ............. E/src/ReadBlock.cpp:16-68
+//   eagle_calculateMMt ........... E/src/calculateMMt_rcpp.cpp:19-185
+//   eagle_calculate_a_and_vara ... E/src/calculate_a_and_vara_rcpp.cpp:22-241
+//   eagle_calculate_reduced_a .... E/src/calculate_reduced_a_rcpp.cpp:20-171
+//   eagle_last_scan_argmax ....... E/R/find_qtl.R:71-83
+//   eagle_last_mmt_normalised .... E/R/calcMMt.R:13
+//
+// Design: the reference re-parses the text file into an n x L (or L x n) matrix of doubles on every call and,
+// when that does not fit `availmemGb`, re-scans the file from line 0 once per block.  Here a text tile is
+// pread() into pinned memory by `num_cores` threads, copied to HBM, decoded on the device to int8 {-1,0,1} and
+// kept resident (one byte per genotype: 10k x 1M = 10 GB of the 288 GB) for every later call on the same file.
+// All arithmetic happens in the HIP kernels of eagle_kernels.hip; there is no host compute path.
+#include <fcntl.h>
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/eagle_hip.h"
+#include "eagle_internal.h"
+
+struct GenoEntry {
+    std::string path;
+    off_t size = 0;
+    long mtime_ns = 0;
+    long rows = 0, cols = 0;          // logical tile held: all `rows` lines, first `cols` characters
+    long rows_pad = 0, ld = 0;
+    int8_t* dev = nullptr;
+};
+
+struct eagle_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    char err[1024] = {0};
+    eagle_message_fn msg_fn = nullptr;
+    void* msg_user = nullptr;
+    int scan_mode = 0;
+    std::vector<GenoEntry> cache;
+    // results of the last calls, kept in HBM
+    double* d_mmt = nullptr; long mmt_n = 0; double* d_mmt_max = nullptr;
+    double* d_a = nullptr; double* d_vara = nullptr; long scan_L = 0; long scan_cap = 0;
+    char arch[64] = {0};
+    int cu_count = 0;
+    int64_t hbm_bytes = 0;
+};
+
+static thread_local char g_open_err[512];
+static int host_threads() { unsigned h = std::thread::hardware_concurrency(); return h == 0 ? 1 : (h > 16 ? 16 : (int)h); }
+
+extern "C" int eagle_fail(eagle_ctx* ctx, int code, const char* msg) {
+    if (ctx) snprintf(ctx->err, sizeof ctx->err, "%s", msg);
+    return code;
+}
+extern "C" int eagle_fail_hip(eagle_ctx* ctx, hipError_t e, const char* where) {
+    if (ctx) snprintf(ctx->err, sizeof ctx->err, "HIP error in %s: %s", where, hipGetErrorString(e));
+    return EAGLE_ERR_HIP;
+}
+static int failf(eagle_ctx* ctx, int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    if (ctx) vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+static void say(eagle_ctx* ctx, const char* fmt, ...) {
+    if (!ctx->msg_fn) return;
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    ctx->msg_fn(buf, ctx->msg_user);
+}
+
+#define HIPCHK(ctx, call)                                              \
+    do {                                                               \
+        hipError_t e__ = (call);                                       \
+        if (e__ != hipSuccess) return eagle_fail_hip(ctx, e__, #call); \
+    } while (0)
+
+// RAII device / pinned buffers so every error path frees what it took
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    template <class T> T* as() { return (T*)p; }
+};
+struct PinBuf {
+    void* p = nullptr;
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+    hipError_t alloc(size_t bytes) { return hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault); }
+};
+
+// ------------------------------------------------------------------------------------------------
+extern "C" const char* eagle_open_error(void) { return g_open_err; }
+
+extern "C" eagle_ctx* eagle_open(int device) {
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        snprintf(g_open_err, sizeof g_open_err, "no HIP device available (%s); libeaglehip has no CPU fallback",
+                 e != hipSuccess ? hipGetErrorString(e) : "0 devices");
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) {
+        snprintf(g_open_err, sizeof g_open_err, "device %d out of range (0..%d)", device, ndev - 1);
+        return nullptr;
+    }
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) {
+        snprintf(g_open_err, sizeof g_open_err, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+        return nullptr;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        snprintf(g_open_err, sizeof g_open_err, "device %d is %s; this library is built for gfx950 (MI355X) only", device,
+                 prop.gcnArchName);
+        return nullptr;
+    }
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        snprintf(g_open_err, sizeof g_open_err, "hipSetDevice: %s", hipGetErrorString(e));
+        return nullptr;
+    }
+    eagle_ctx* ctx = new eagle_ctx();
+    ctx->device = device;
+    snprintf(ctx->arch, sizeof ctx->arch, "%s", prop.gcnArchName);
+    ctx->cu_count = prop.multiProcessorCount;
+    ctx->hbm_bytes = (int64_t)prop.totalGlobalMem;
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+        snprintf(g_open_err, sizeof g_open_err, "hipStreamCreate: %s", hipGetErrorString(e));
+        delete ctx;
+        return nullptr;
+    }
+    return ctx;
+}
+
+extern "C" void eagle_drop_cache(eagle_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    for (auto& g : ctx->cache) if (g.dev) (void)hipFree(g.dev);
+    ctx->cache.clear();
+}
+
+extern "C" void eagle_close(eagle_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    eagle_drop_cache(ctx);
+    if (ctx->d_mmt) (void)hipFree(ctx->d_mmt);
+    if (ctx->d_mmt_max) (void)hipFree(ctx->d_mmt_max);
+    if (ctx->d_a) (void)hipFree(ctx->d_a);
+    if (ctx->d_vara) (void)hipFree(ctx->d_vara);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" const char* eagle_last_error(eagle_ctx* ctx) { return ctx ? ctx->err : g_open_err; }
+extern "C" void eagle_set_message_callback(eagle_ctx* ctx, eagle_message_fn fn, void* user) {
+    if (ctx) { ctx->msg_fn = fn; ctx->msg_user = user; }
+}
+extern "C" int eagle_device_info(eagle_ctx* ctx, char* arch_out, int arch_len, int* cu_count, int64_t* hbm_bytes) {
+    if (!ctx) return EAGLE_ERR_ARG;
+    if (arch_out && arch_len > 0) snprintf(arch_out, arch_len, "%s", ctx->arch);
+    if (cu_count) *cu_count = ctx->cu_count;
+    if (hbm_bytes) *hbm_bytes = ctx->hbm_bytes;
+    return EAGLE_OK;
+}
+extern "C" int eagle_set_scan_mode(eagle_ctx* ctx, int mode) {
+    if (!ctx || mode < 0 || mode > 1) return EAGLE_ERR_ARG;
+    ctx->scan_mode = mode;
+    return EAGLE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// selected_loci rule (calculateMMt_rcpp.cpp:88; calculate_a_and_vara_rcpp.cpp:79; calculate_reduced_a_rcpp.cpp:74):
+// masking fires iff element 0 is not NA.  NA arrives as NaN.
+// ------------------------------------------------------------------------------------------------
+static int parse_selected(eagle_ctx* ctx, const double* sel, long nsel, long bound, std::vector<long>& out) {
+    out.clear();
+    if (nsel <= 0 || !sel || isnan(sel[0])) return EAGLE_OK;
+    for (long i = 0; i < nsel; i++) {
+        if (isnan(sel[i])) return eagle_fail(ctx, EAGLE_ERR_ARG, "NA in selected_loci after element 0");
+        long v = (long)sel[i];
+        if (v < 0 || v >= bound) return eagle_fail(ctx, EAGLE_ERR_ARG, "selected_loci index out of range");
+        out.push_back(v);
+    }
+    return EAGLE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tile streamer: lines [row0, row0+nrows), characters [col0, col0+ncols) of a no-space ASCII genotype file
+// -> int8 {-1,0,1} at dst[r*ld + c] in HBM (padding untouched; callers zero it).
+// Fast path: fixed-width file (every line `width` characters + '\n'), pread() straight into pinned memory by
+// `threads` workers, double-buffered against the H2D copy + decode kernel.  The decode kernel verifies the
+// end-of-line byte of every row, so a file that is not fixed-width is detected, and the general path (scan
+// for newlines on the host, copy the first `width` characters of each line) is used instead.
+// ------------------------------------------------------------------------------------------------
+struct FileInfo {
+    int fd = -1;
+    off_t size = 0;
+    long mtime_ns = 0;
+    long width = -1;   // characters per line if fixed-width, else -1
+    long nlines = -1;
+    ~FileInfo() { if (fd >= 0) close(fd); }
+};
+
+static int open_file(eagle_ctx* ctx, const char* path, FileInfo& fi) {
+    fi.fd = open(path, O_RDONLY);
+    if (fi.fd < 0) return failf(ctx, EAGLE_ERR_OPEN, "ERROR: Could not open  %s", path);  // ReadBlock.cpp:42-45
+    struct stat st;
+    if (fstat(fi.fd, &st) != 0) return failf(ctx, EAGLE_ERR_OPEN, "ERROR: Could not stat  %s", path);
+    fi.size = st.st_size;
+    fi.mtime_ns = (long)st.st_mtim.tv_sec * 1000000000L + st.st_mtim.tv_nsec;
+    // probe the first line
+    char buf[1 << 16];
+    long pos = 0, width = -1;
+    while (pos < fi.size && width < 0) {
+        ssize_t got = pread(fi.fd, buf, sizeof buf, pos);
+        if (got <= 0) break;
+        void* nl = memchr(buf, '\n', (size_t)got);
+        if (nl) width = pos + ((char*)nl - buf);
+        pos += got;
+    }
+    if (width >= 0 && fi.size % (width + 1) == 0) {
+        fi.width = width;
+        fi.nlines = fi.size / (width + 1);
+    } else if (width >= 0 && (fi.size + 1) % (width + 1) == 0) {  // last line without '\n'
+        fi.width = width;
+        fi.nlines = (fi.size + 1) / (width + 1);
+    }
+    return EAGLE_OK;
+}
+
+static void parallel_pread(int fd, uint8_t* dst, long dst_stride, long nrows, long nbytes, off_t off0, long src_stride,
+                           int threads, volatile int* io_err) {
+    auto work = [&](long r0, long r1) {
+        if (src_stride == dst_stride && nbytes == src_stride) {  // contiguous range
+            long total = (r1 - r0) * src_stride, done = 0;
+            while (done < total) {
+                ssize_t got = pread(fd, dst + r0 * dst_stride + done, (size_t)(total - done), off0 + r0 * src_stride + done);
+                if (got <= 0) {  // reading past EOF by the missing final '\n' is fine
+                    if (got == 0 && total - done <= 1) { dst[r0 * dst_stride + done] = '\n'; break; }
+                    *io_err = 1;
+                    return;
+                }
+                done += got;
+            }
+            return;
+        }
+        for (long r = r0; r < r1; r++) {
+            long done = 0;
+            while (done < nbytes) {
+                ssize_t got = pread(fd, dst + r * dst_stride + done, (size_t)(nbytes - done), off0 + r * src_stride + done);
+                if (got <= 0) {
+                    if (got == 0 && nbytes - done <= 1) { dst[r * dst_stride + done] = '\n'; break; }
+                    *io_err = 1;
+                    return;
+                }
+                done += got;
+            }
+        }
+    };
+    if (threads <= 1 || nrows < 2 * threads) { work(0, nrows); return; }
+    std::vector<std::thread> pool;
+    long per = (nrows + threads - 1) / threads;
+    for (int t = 0; t < threads; t++) {
+        long r0 = t * per, r1 = std::min(nrows, r0 + per);
+        if (r0 >= r1) break;
+        pool.emplace_back(work, r0, r1);
+    }
+    for (auto& th : pool) th.join();
+}
+
+static int load_tile_fixed(eagle_ctx* ctx, FileInfo& fi, long row0, long nrows, long col0, long ncols, int8_t* dst,
+                           long ld, double max_mem_gb, int threads) {
+    const long line = fi.width + 1;
+    // take the end-of-line byte along when the window reaches the end of the line: the decode kernel then
+    // verifies it, which is what detects a file that is not fixed-width after all
+    const bool at_end = (col0 + ncols == fi.width);
+    const long src_bytes = at_end ? ncols + 1 : ncols;
+    const long stride = src_bytes;
+    // staging budget: a quarter of availmemGb per buffer, within [one row, 256 MiB]
+    double budget = max_mem_gb > 0 ? max_mem_gb * 1e9 / 4.0 : 64e6;
+    long chunk_rows = (long)std::max(1.0, std::min(budget, 268435456.0) / (double)stride);
+    chunk_rows = std::min(chunk_rows, nrows);
+    PinBuf pin[2];
+    DevBuf raw[2], bad;
+    hipEvent_t done[2] = {nullptr, nullptr};
+    HIPCHK(ctx, bad.alloc(sizeof(int)));
+    HIPCHK(ctx, hipMemsetAsync(bad.p, 0, sizeof(int), ctx->stream));
+    for (int b = 0; b < 2; b++) {
+        HIPCHK(ctx, pin[b].alloc((size_t)chunk_rows * stride));
+        HIPCHK(ctx, raw[b].alloc((size_t)chunk_rows * stride));
+        HIPCHK(ctx, hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
+    }
+    int rc = EAGLE_OK;
+    volatile int io_err = 0;
+    long k = 0;
+    for (long r = 0; r < nrows && rc == EAGLE_OK; r += chunk_rows, k++) {
+        const int b = (int)(k & 1);
+        const long nr = std::min(chunk_rows, nrows - r);
+        if (k >= 2) {
+            hipError_t e = hipEventSynchronize(done[b]);  // the copy out of pin[b] two chunks ago has finished
+            if (e != hipSuccess) { rc = eagle_fail_hip(ctx, e, "hipEventSynchronize"); break; }
+        }
+        parallel_pread(fi.fd, (uint8_t*)pin[b].p, stride, nr, src_bytes, (off_t)(row0 + r) * line + col0, line, threads,
+                       &io_err);
+        if (io_err) { rc = eagle_fail(ctx, EAGLE_ERR_FORMAT, "short read: file has fewer lines than requested"); break; }
+        hipError_t e = hipMemcpyAsync(raw[b].p, pin[b].p, (size_t)nr * stride, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) { rc = eagle_fail_hip(ctx, e, "hipMemcpyAsync H2D"); break; }
+        e = hipEventRecord(done[b], ctx->stream);
+        if (e != hipSuccess) { rc = eagle_fail_hip(ctx, e, "hipEventRecord"); break; }
+        rc = eagle_dev_decode_ascii(ctx, raw[b].as<uint8_t>(), nr, ncols, stride, dst + r * ld, ld, bad.as<int>(), ctx->stream);
+    }
+    int nbad = 0;
+    if (rc == EAGLE_OK) {
+        hipError_t e = hipMemcpyAsync(&nbad, bad.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = eagle_fail_hip(ctx, e, "decode sync");
+    } else {
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    for (int b = 0; b < 2; b++) if (done[b]) (void)hipEventDestroy(done[b]);
+    if (rc == EAGLE_OK && nbad)
+        rc = failf(ctx, EAGLE_ERR_FORMAT, "%d characters outside '0'..'2' (or misplaced line ends) in the requested tile", nbad);
+    return rc;
+}
+
+// General path: arbitrary line lengths.  Lines are located on the host; the first `col0+ncols` characters of
+// each wanted line are required to exist (the reference indexes past the end of a short line: undefined).
+static int load_tile_general(eagle_ctx* ctx, FileInfo& fi, long row0, long nrows, long col0, long ncols, int8_t* dst,
+                             long ld) {
+    FILE* f = fdopen(dup(fi.fd), "r");
+    if (!f) return eagle_fail(ctx, EAGLE_ERR_OPEN, "fdopen failed");
+    rewind(f);
+    const long chunk_rows = std::max(1L, std::min(nrows, (long)(67108864 / std::max(1L, ncols))));
+    PinBuf pin;
+    DevBuf raw, bad;
+    int rc = EAGLE_OK;
+    hipError_t e;
+    if ((e = pin.alloc((size_t)chunk_rows * ncols)) != hipSuccess || (e = raw.alloc((size_t)chunk_rows * ncols)) != hipSuccess ||
+        (e = bad.alloc(sizeof(int))) != hipSuccess) {
+        fclose(f);
+        return eagle_fail_hip(ctx, e, "alloc");
+    }
+    (void)hipMemsetAsync(bad.p, 0, sizeof(int), ctx->stream);
+    char* line = nullptr;
+    size_t cap = 0;
+    long filled = 0, out_row = 0;
+    for (long rr = 0; rr < row0 + nrows && rc == EAGLE_OK; rr++) {
+        ssize_t len = getline(&line, &cap, f);
+        if (len < 0) { rc = eagle_fail(ctx, EAGLE_ERR_FORMAT, "file has fewer lines than requested"); break; }
+        if (rr < row0) continue;
+        while (len > 0 && (line[len - 1] == '\n' || line[len - 1] == '\r')) len--;
+        if (len < col0 + ncols) { rc = eagle_fail(ctx, EAGLE_ERR_FORMAT, "line shorter than the requested columns"); break; }
+        memcpy((char*)pin.p + filled * ncols, line + col0, (size_t)ncols);
+        filled++;
+        if (filled == chunk_rows || rr == row0 + nrows - 1) {
+            e = hipMemcpyAsync(raw.p, pin.p, (size_t)filled * ncols, hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) { rc = eagle_fail_hip(ctx, e, "H2D"); break; }
+            rc = eagle_dev_decode_ascii(ctx, raw.as<uint8_t>(), filled, ncols, ncols, dst + out_row * ld, ld, bad.as<int>(),
+                                        ctx->stream);
+            e = hipStreamSynchronize(ctx->stream);  // single staging buffer
+            if (e != hipSuccess) { rc = eagle_fail_hip(ctx, e, "sync"); break; }
+            out_row += filled;
+            filled = 0;
+        }
+    }
+    free(line);
+    fclose(f);
+    int nbad = 0;
+    if (rc == EAGLE_OK) {
+        e = hipMemcpy(&nbad, bad.p, sizeof(int), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = eagle_fail_hip(ctx, e, "D2H");
+        else if (nbad) rc = failf(ctx, EAGLE_ERR_FORMAT, "%d characters outside '0'..'2' in the requested tile", nbad);
+    }
+    return rc;
+}
+
+// public: load a window of a genotype text file into a caller-owned HBM int8 buffer
+extern "C" int eagle_dev_load_ascii(eagle_ctx* ctx, const char* path, long row0, long nrows, long col0, long ncols,
+                                    int8_t* dst, long ld, double max_mem_gb, int threads) {
+    if (!ctx) return EAGLE_ERR_ARG;
+    if (row0 < 0 || nrows < 0 || col0 < 0 || ncols < 0 || ld % 4 || ncols > ld) return eagle_fail(ctx, EAGLE_ERR_ARG, "load_ascii: bad window");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    FileInfo fi;
+    int rc = open_file(ctx, path, fi);
+    if (rc) return rc;
+    if (nrows == 0 || ncols == 0) return EAGLE_OK;
+    if (fi.width >= 0) {
+        if (row0 + nrows > fi.nlines) return eagle_fail(ctx, EAGLE_ERR_FORMAT, "file has fewer lines than requested");
+        if (col0 + ncols > fi.width) return eagle_fail(ctx, EAGLE_ERR_FORMAT, "line shorter than the requested columns");
+        rc = load_tile_fixed(ctx, fi, row0, nrows, col0, ncols, dst, ld, max_mem_gb, threads);
+        if (rc != EAGLE_ERR_FORMAT) return rc;
+        // a misplaced line end means the file is not fixed-width after all: fall through to the line scanner
+    }
+    return load_tile_general(ctx, fi, row0, nrows, col0, ncols, dst, ld);
+}
+
+// Resident genotype tile of a whole file: `rows` lines x first `cols` characters, zero padded to
+// [pad128(rows)][pad128(cols)].
+static int get_resident(eagle_ctx* ctx, const char* path, long rows, long cols, double max_mem_gb, int threads,
+                        GenoEntry** out) {
+    struct stat st;
+    if (stat(path, &st) != 0) return failf(ctx, EAGLE_ERR_OPEN, "ERROR: Could not open  %s", path);
+    long mt = (long)st.st_mtim.tv_sec * 1000000000L + st.st_mtim.tv_nsec;
+    for (auto& g : ctx->cache)
+        if (g.path == path && g.size == st.st_size && g.mtime_ns == mt && g.rows == rows && g.cols == cols) { *out = &g; return EAGLE_OK; }
+    // stale entries of the same path are dropped
+    for (size_t i = 0; i < ctx->cache.size();)
+        if (ctx->cache[i].path == path) { (void)hipFree(ctx->cache[i].dev); ctx->cache.erase(ctx->cache.begin() + i); } else i++;
+    GenoEntry g;
+    g.path = path; g.size = st.st_size; g.mtime_ns = mt; g.rows = rows; g.cols = cols;
+    g.rows_pad = eagle_pad128(rows); g.ld = eagle_pad128(cols);
+    size_t bytes = (size_t)g.rows_pad * (size_t)g.ld;
+    size_t freeb = 0, totalb = 0;
+    HIPCHK(ctx, hipMemGetInfo(&freeb, &totalb));
+    if (bytes + ((size_t)1 << 30) > freeb) {
+        eagle_drop_cache(ctx);
+        HIPCHK(ctx, hipMemGetInfo(&freeb, &totalb));
+        if (bytes + ((size_t)1 << 30) > freeb)
+            return failf(ctx, EAGLE_ERR_NOMEM, "genotype tile of %zu bytes does not fit in HBM (%zu free): shard the markers", bytes, freeb);
+    }
+    HIPCHK(ctx, hipMalloc((void**)&g.dev, bytes));
+    hipError_t e = hipMemsetAsync(g.dev, 0, bytes, ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(g.dev); return eagle_fail_hip(ctx, e, "memset"); }
+    int rc = eagle_dev_load_ascii(ctx, path, 0, rows, 0, cols, g.dev, g.ld, max_mem_gb, threads);
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(g.dev); return rc; }
+    ctx->cache.push_back(g);
+    *out = &ctx->cache.back();
+    return EAGLE_OK;
+}
+
+// column-major n x n host matrix -> zero padded np x np device image (row-major image of the transpose)
+static int upload_square(eagle_ctx* ctx, const double* host, long n, long np, double* dev) {
+    HIPCHK(ctx, hipMemsetAsync(dev, 0, sizeof(double) * np * np, ctx->stream));
+    HIPCHK(ctx, hipMemcpy2DAsync(dev, sizeof(double) * np, host, sizeof(double) * n, sizeof(double) * n, n,
+                                 hipMemcpyHostToDevice, ctx->stream));
+    return EAGLE_OK;
+}
+static int upload_vec(eagle_ctx* ctx, const double* host, long n, long np, double* dev) {
+    HIPCHK(ctx, hipMemsetAsync(dev, 0, sizeof(double) * np, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dev, host, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    return EAGLE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int eagle_read_block(eagle_ctx* ctx, const char* asciifname, long start_row, long numcols, long numrows,
+                                double* out) {
+    if (!ctx) return EAGLE_ERR_ARG;
+    if (start_row < 0 || numcols < 0 || numrows < 0) return eagle_fail(ctx, EAGLE_ERR_ARG, "negative dimension");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (numcols == 0 || numrows == 0) {
+        FileInfo fi;
+        return open_file(ctx, asciifname, fi);
+    }
+    const long ld = eagle_pad128(numcols);
+    DevBuf tile, dbl;
+    HIPCHK(ctx, tile.alloc((size_t)numrows * ld));
+    HIPCHK(ctx, dbl.alloc(sizeof(double) * (size_t)numrows * numcols));
+    int rc = eagle_dev_load_ascii(ctx, asciifname, start_row, numrows, 0, numcols, tile.as<int8_t>(), ld, 1.0, 4);
+    if (rc) return rc;
+    rc = eagle_dev_i8_to_f64_colmajor(ctx, tile.as<int8_t>(), numrows, numcols, ld, dbl.as<double>(), ctx->stream);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(out, dbl.p, sizeof(double) * (size_t)numrows * numcols, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return EAGLE_OK;
+}
+
+extern "C" int eagle_calculateMMt(eagle_ctx* ctx, const char* f_name_ascii, double max_memory_in_Gbytes, int num_cores,
+                                  const double* selected_loci, long n_selected, const long dims[2], int quiet,
+                                  double* MMt_out) {
+    if (!ctx) return EAGLE_ERR_ARG;
+    const long n = dims[0], L = dims[1];
+    if (n <= 0 || L <= 0) return eagle_fail(ctx, EAGLE_ERR_ARG, "bad dims");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<long> sel;
+    int rc = parse_selected(ctx, selected_loci, n_selected, L, sel);
+    if (rc) return rc;
+    say(ctx, " Number of cores being used for calculation is .. %d", num_cores);  // calculateMMt_rcpp.cpp:36
+    // calculateMMt_rcpp.cpp:75-76,84,103-106: the reference chooses between one DGEMM and row blocks; a block
+    // size of zero rows makes it divide by zero.  The device path needs no such split, but the failure is kept.
+    double need = (double)((unsigned long)n * n * sizeof(double) + 2 * ((unsigned long)n * L * sizeof(double))) / 1e9;
+    if (!(max_memory_in_Gbytes > need)) {
+        double p2 = sqrt(4.0 * (double)L * (double)L + 4.0 * max_memory_in_Gbytes * 1e9 / sizeof(double));
+        long rows_in_block = (long)((-2.0 * (double)L + p2) / 2.2);
+        if (rows_in_block <= 0) return eagle_fail(ctx, EAGLE_ERR_ARG, "availmemGb too small: zero rows per block");
+        if (!quiet) say(ctx, "number of rows in block is %ld", rows_in_block);  // :107
+    }
+    GenoEntry* g = nullptr;
+    rc = get_resident(ctx, f_name_ascii, n, L, max_memory_in_Gbytes, num_cores > 0 ? num_cores : 1, &g);
+    if (rc) return rc;
+    const long np = g->rows_pad;
+    DevBuf c32, dsel;
+    HIPCHK(ctx, c32.alloc(sizeof(int32_t) * (size_t)np * np));
+    HIPCHK(ctx, hipMemsetAsync(c32.p, 0, sizeof(int32_t) * (size_t)np * np, ctx->stream));
+    rc = eagle_dev_mmt_accumulate(ctx, g->dev, np, g->ld, g->ld, c32.as<int32_t>(), ctx->stream);
+    if (rc) return rc;
+    if (!sel.empty()) {  // :88-92 as an exact rank-k downdate
+        HIPCHK(ctx, dsel.alloc(sizeof(long) * sel.size()));
+        HIPCHK(ctx, hipMemcpyAsync(dsel.p, sel.data(), sizeof(long) * sel.size(), hipMemcpyHostToDevice, ctx->stream));
+        rc = eagle_dev_mmt_downdate(ctx, g->dev, np, g->ld, dsel.as<long>(), (long)sel.size(), c32.as<int32_t>(), ctx->stream);
+        if (rc) return rc;
+    }
+    if (ctx->mmt_n != n) {
+        if (ctx->d_mmt) { (void)hipFree(ctx->d_mmt); ctx->d_mmt = nullptr; }
+        ctx->mmt_n = 0;
+        HIPCHK(ctx, hipMalloc((void**)&ctx->d_mmt, sizeof(double) * (size_t)n * n));
+        ctx->mmt_n = n;
+    }
+    if (!ctx->d_mmt_max) HIPCHK(ctx, hipMalloc((void**)&ctx->d_mmt_max, sizeof(double)));
+    rc = eagle_dev_mmt_finish(ctx, c32.as<int32_t>(), n, np, ctx->d_mmt, n, ctx->d_mmt_max, ctx->stream);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(MMt_out, ctx->d_mmt, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return EAGLE_OK;
+}
+
+extern "C" int eagle_last_mmt_normalised(eagle_ctx* ctx, double* MMt_norm_out, double* max_out) {
+    if (!ctx || !ctx->d_mmt || ctx->mmt_n <= 0) return eagle_fail(ctx, EAGLE_ERR_ARG, "no MMt result held");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const long n = ctx->mmt_n;
+    DevBuf tmp;
+    HIPCHK(ctx, tmp.alloc(sizeof(double) * (size_t)n * n));
+    HIPCHK(ctx, hipMemcpyAsync(tmp.p, ctx->d_mmt, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, ctx->stream));
+    int rc = eagle_dev_mmt_normalise(ctx, tmp.as<double>(), n, n, ctx->d_mmt_max, ctx->stream);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(MMt_norm_out, tmp.p, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost, ctx->stream));
+    if (max_out) HIPCHK(ctx, hipMemcpyAsync(max_out, ctx->d_mmt_max, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return EAGLE_OK;
+}
+
+static int ensure_scan_out(eagle_ctx* ctx, long L_pad) {
+    if (ctx->scan_cap >= L_pad) return EAGLE_OK;
+    if (ctx->d_a) { (void)hipFree(ctx->d_a); ctx->d_a = nullptr; }
+    if (ctx->d_vara) { (void)hipFree(ctx->d_vara); ctx->d_vara = nullptr; }
+    ctx->scan_cap = 0;
+    HIPCHK(ctx, hipMalloc((void**)&ctx->d_a, sizeof(double) * (size_t)L_pad));
+    HIPCHK(ctx, hipMalloc((void**)&ctx->d_vara, sizeof(double) * (size_t)L_pad));
+    ctx->scan_cap = L_pad;
+    return EAGLE_OK;
+}
+
+extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_ascii, const double* selected_loci,
+                                          long n_selected, const double* inv_MMt_sqrt, const double* dim_reduced_vara,
+                                          double max_memory_in_Gbytes, const long dims[2], const double* a, int quiet,
+                                          double* a_out, double* vara_out) {
+    if (!ctx) return EAGLE_ERR_ARG;
+    const long L = dims[0], n = dims[1];
+    if (n <= 0 || L <= 0) return eagle_fail(ctx, EAGLE_ERR_ARG, "bad dims");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<long> sel;
+    int rc = parse_selected(ctx, selected_loci, n_selected, L, sel);
+    if (rc) return rc;
+    // calculate_a_and_vara_rcpp.cpp:65 (integer division), :74, :129-144
+    double mem_needed = (double)((4UL * (unsigned long)n * (unsigned long)L * sizeof(double)) / 1000000000UL);
+    if (!quiet) say(ctx, "Inside internal function calculate_a_and_vara_rcpp: Need memory (gigabytes)  %g", mem_needed);
+    if (!(mem_needed < max_memory_in_Gbytes)) {
+        say(ctx, " Increasing maxmemGb would improve performance... \n");
+        long rows_in_block = (long)(max_memory_in_Gbytes * 1e9 / (double)(4UL * (unsigned long)n * sizeof(double)));
+        if (rows_in_block < 0) {
+            say(ctx, "Error:  availmemGb is set to %g", max_memory_in_Gbytes);
+            say(ctx, "        Cannot even read in a single row of data into memory.");
+            a_out[0] = 0.0;
+            vara_out[0] = 0.0;
+            eagle_fail(ctx, EAGLE_SOFT_SENTINEL, "availmemGb: cannot even read in a single row of data into memory");
+            return EAGLE_SOFT_SENTINEL;
+        }
+        if (rows_in_block == 0) return eagle_fail(ctx, EAGLE_ERR_ARG, "availmemGb too small: zero rows per block");
+    }
+    GenoEntry* g = nullptr;
+    rc = get_resident(ctx, f_name_ascii, L, n, max_memory_in_Gbytes, host_threads(), &g);
+    if (rc) return rc;
+    const long np = g->ld, Lp = g->rows_pad;
+    DevBuf Sa, Va, tmp, Wu, ah, v, dsel, ws;
+    const size_t sq = sizeof(double) * (size_t)np * np;
+    HIPCHK(ctx, Sa.alloc(sq)); HIPCHK(ctx, Va.alloc(sq)); HIPCHK(ctx, tmp.alloc(sq)); HIPCHK(ctx, Wu.alloc(sq));
+    HIPCHK(ctx, ah.alloc(sizeof(double) * np)); HIPCHK(ctx, v.alloc(sizeof(double) * np));
+    if ((rc = upload_square(ctx, inv_MMt_sqrt, n, np, Sa.as<double>()))) return rc;
+    if ((rc = upload_square(ctx, dim_reduced_vara, n, np, Va.as<double>()))) return rc;
+    if ((rc = upload_vec(ctx, a, n, np, ah.as<double>()))) return rc;
+    if ((rc = ensure_scan_out(ctx, Lp))) return rc;
+    rc = eagle_dev_scan_operands(ctx, Sa.as<double>(), Va.as<double>(), ah.as<double>(), n, np, v.as<double>(), Wu.as<double>(),
+                                 tmp.as<double>(), ctx->stream);
+    if (rc) return rc;
+    rc = eagle_dev_gemv_i8(ctx, g->dev, Lp, np, g->ld, v.as<double>(), 1.0, ctx->d_a, ctx->stream);
+    if (rc) return rc;
+    if (ctx->scan_mode == 1) {
+        const int nslices = 8;
+        HIPCHK(ctx, ws.alloc((size_t)eagle_vara_i8_workspace_bytes(np, Lp, nslices)));
+        rc = eagle_dev_vara_i8(ctx, g->dev, Lp, np, g->ld, Wu.as<double>(), nslices, ws.p, ctx->d_vara, nullptr, ctx->stream);
+    } else {
+        rc = eagle_dev_vara_f64(ctx, g->dev, Lp, np, g->ld, Wu.as<double>(), ctx->d_vara, ctx->stream);
+    }
+    if (rc) return rc;
+    if (!sel.empty()) {  // :79-84: a zeroed marker row gives a = 0 and vara = 0 exactly
+        HIPCHK(ctx, dsel.alloc(sizeof(long) * sel.size()));
+        HIPCHK(ctx, hipMemcpyAsync(dsel.p, sel.data(), sizeof(long) * sel.size(), hipMemcpyHostToDevice, ctx->stream));
+        rc = eagle_dev_zero_rows(ctx, ctx->d_a, ctx->d_vara, L, dsel.as<long>(), (long)sel.size(), 0, ctx->stream);
+        if (rc) return rc;
+    }
+    ctx->scan_L = L;
+    HIPCHK(ctx, hipMemcpyAsync(a_out, ctx->d_a, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(vara_out, ctx->d_vara, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return EAGLE_OK;
+}
+
+extern "C" int eagle_last_scan_argmax(eagle_ctx* ctx, long* index_out, double* tsqmax_out, long* n_near_ties) {
+    if (!ctx || !ctx->d_a || ctx->scan_L <= 0) return eagle_fail(ctx, EAGLE_ERR_ARG, "no scan result held");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevBuf scratch, best;
+    HIPCHK(ctx, scratch.alloc(sizeof(double) * 3 * 1024));
+    HIPCHK(ctx, best.alloc(sizeof(eagle_best)));
+    int rc = eagle_dev_tsq_argmax(ctx, ctx->d_a, ctx->d_vara, ctx->scan_L, nullptr, best.as<eagle_best>(), scratch.as<double>(),
+                                  ctx->stream);
+    if (rc) return rc;
+    eagle_best h;
+    HIPCHK(ctx, hipMemcpyAsync(&h, best.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (index_out) *index_out = h.index0 + 1;  // R is 1-based; 0 = every tsq was NaN
+    if (tsqmax_out) *tsqmax_out = h.tsqmax;
+    if (n_near_ties) *n_near_ties = h.near_ties;
+    return EAGLE_OK;
+}
+
+extern "C" int eagle_calculate_reduced_a(eagle_ctx* ctx, const char* f_name_ascii, double varG, const double* P,
+                                         const double* y, double max_memory_in_Gbytes, const long dims[2],
+                                         const double* selected_loci, long n_selected, int quiet, double* ar_out) {
+    if (!ctx) return EAGLE_ERR_ARG;
+    const long n = dims[0], L = dims[1];
+    if (n <= 0 || L <= 0) return eagle_fail(ctx, EAGLE_ERR_ARG, "bad dims");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<long> sel;
+    int rc = parse_selected(ctx, selected_loci, n_selected, L, sel);
+    if (rc) return rc;
+    // calculate_reduced_a_rcpp.cpp:56: sizeof(double)/1000000000 is integer 0, so "memory needed" is 0 and the
+    // in-memory branch runs iff 0 < availmemGb; otherwise the block size comes out negative (:92-103).
+    if (!quiet) {
+        say(ctx, "Inside internal function calculate_reduced_a_rcpp. Memory needed (gigabytes): 0");
+        say(ctx, "Inside internal function calculate_reduced_a_rcpp. Memory available (gigabytes): %g", max_memory_in_Gbytes);
+    }
+    if (!(0.0 < max_memory_in_Gbytes)) {
+        say(ctx, " Note:  Increasing availmemGb would improve performance... ");
+        say(ctx, "Error:  availmemGb is set to %g", max_memory_in_Gbytes);
+        ar_out[0] = 0.0;
+        eagle_fail(ctx, EAGLE_SOFT_SENTINEL, "availmemGb: cannot even read in a single row of data into memory");
+        return EAGLE_SOFT_SENTINEL;
+    }
+    GenoEntry* g = nullptr;
+    rc = get_resident(ctx, f_name_ascii, L, n, max_memory_in_Gbytes, host_threads(), &g);
+    if (rc) return rc;
+    const long np = g->ld, Lp = g->rows_pad;
+    DevBuf Pa, yv, py, out, dsel;
+    HIPCHK(ctx, Pa.alloc(sizeof(double) * (size_t)np * np));
+    HIPCHK(ctx, yv.alloc(sizeof(double) * np)); HIPCHK(ctx, py.alloc(sizeof(double) * np));
+    HIPCHK(ctx, out.alloc(sizeof(double) * Lp));
+    if ((rc = upload_square(ctx, P, n, np, Pa.as<double>()))) return rc;
+    if ((rc = upload_vec(ctx, y, n, np, yv.as<double>()))) return rc;
+    rc = eagle_dev_colgemv(ctx, Pa.as<double>(), n, np, yv.as<double>(), py.as<double>(), ctx->stream);  // :82
+    if (rc) return rc;
+    rc = eagle_dev_gemv_i8(ctx, g->dev, Lp, np, g->ld, py.as<double>(), varG, out.as<double>(), ctx->stream);  // :83-84
+    if (rc) return rc;
+    if (!sel.empty()) {  // :74-78
+        HIPCHK(ctx, dsel.alloc(sizeof(long) * sel.size()));
+        HIPCHK(ctx, hipMemcpyAsync(dsel.p, sel.data(), sizeof(long) * sel.size(), hipMemcpyHostToDevice, ctx->stream));
+        rc = eagle_dev_zero_rows(ctx, out.as<double>(), nullptr, L, dsel.as<long>(), (long)sel.size(), 0, ctx->stream);
+        if (rc) return rc;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ar_out, out.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return EAGLE_OK;
+}

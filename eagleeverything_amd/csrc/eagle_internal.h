@@ -1,0 +1,20 @@
+// eagle_internal.h -- shared between eagle_api.cpp and eagle_kernels.hip (not part of the public ABI)
+#ifndef EAGLE_INTERNAL_H
+#define EAGLE_INTERNAL_H
+#include <hip/hip_runtime.h>
+
+#include "../../include/eagle_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+int eagle_fail(eagle_ctx* ctx, int code, const char* msg);
+int eagle_fail_hip(eagle_ctx* ctx, hipError_t e, const char* where);
+// C = A * B, all row-major np x np fp64, np % 128 == 0
+int eagle_dev_gemm_f64(eagle_ctx* ctx, const double* A, const double* B, double* C, long np, void* stream);
+// out = A x where At is the row-major image of A^T (i.e. the column-major R matrix), n_pad % 64 == 0
+int eagle_dev_colgemv(eagle_ctx* ctx, const double* At, long n, long n_pad, const double* x, double* out, void* stream);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,771 @@
+// eagle_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the Eagle hot path and their launchers
+// (section 2 of include/eagle_hip.h).  Written for 64-wide wavefronts and MFMA; no other target.
+//
+//   k_decode_ascii ........ text tile '0','1','2' -> int8 {-1,0,1}     (E/src/ReadBlock.cpp:52-55)
+//   k_syrk_i8 ............. MM^T partial sums on v_mfma_i32_32x32x32_i8 (E/src/calculateMMt_rcpp.cpp:95)
+//   k_gemm_f64<..> ........ fp64 MFMA GEMM core (v_mfma_f64_16x16x4_f64):
+//                             A = f64 : W = S (V S)                     (calculate_a_and_vara_rcpp.cpp:97-98)
+//                             A = int8: T = Mt W fused with the row-dot (calculate_a_and_vara_rcpp.cpp:103-112)
+//   k_gemv_i8 ............. a = Mt v                                    (calculate_a_and_vara_rcpp.cpp:91,
+//                                                                        calculate_reduced_a_rcpp.cpp:83-84)
+//   k_tsq_* ............... tsq = a^2/vara, first arg-max ignoring NaN  (E/R/find_qtl.R:71-83)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/eagle_hip.h"
+#include "eagle_internal.h"
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+#define WAVE 64
+
+// ------------------------------------------------------------------------------------------------
+// decode: raw[row*line_stride + c] in {'0','1','2'} -> out[row*ld_out + c] = c - '0' - 1 ; pad = 0.
+// Also checks the fixed-width assumption: byte `cols` of every line must be '\n' (or '\r') when
+// line_stride > cols.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_decode_ascii(const uint8_t* __restrict__ raw, long rows, long cols,
+                                                      long line_stride, int8_t* __restrict__ out, long ld_out,
+                                                      int* __restrict__ bad) {
+    const long row = blockIdx.y;
+    const long c4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c4 >= ld_out) return;
+    const uint8_t* src = raw + row * line_stride;
+    int nbad = 0;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        long c = c4 + q;
+        int v = 0;
+        if (c < cols) {
+            int ch = src[c];
+            v = ch - '0' - 1;
+            if (ch < '0' || ch > '2') nbad++;
+        }
+        packed |= ((uint32_t)(uint8_t)(int8_t)v) << (8 * q);
+    }
+    const bool owns_eol = (cols >= c4 && cols < c4 + 4) || (cols == ld_out && c4 + 4 == ld_out);
+    if (owns_eol && line_stride > cols) {
+        int ch = src[cols];
+        if (ch != '\n' && ch != '\r') nbad++;
+    }
+    *(uint32_t*)(out + row * ld_out + c4) = packed;
+    if (nbad) atomicAdd(bad, nbad);
+}
+
+// 64x64-byte tile transpose through LDS. rows, cols multiples of 64.
+__global__ __launch_bounds__(256) void k_transpose_i8(const int8_t* __restrict__ in, long ld_in,
+                                                      int8_t* __restrict__ out, long ld_out) {
+    __shared__ __attribute__((aligned(16))) int8_t tile[64][80];
+    const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
+    const int t = threadIdx.x;
+    {
+        int r = t >> 2, ch = (t & 3) * 16;
+        i32x4 v = *(const i32x4*)(in + (r0 + r) * ld_in + c0 + ch);
+        *(i32x4*)(&tile[r][ch]) = v;
+    }
+    __syncthreads();
+    {
+        int c = t >> 2, ch = (t & 3) * 16;  // output row c0+c, bytes r0+ch .. +15
+        union { i32x4 v; int8_t b[16]; } u;
+#pragma unroll
+        for (int q = 0; q < 16; q++) u.b[q] = tile[ch + q][c];
+        *(i32x4*)(out + (c0 + c) * ld_out + r0 + ch) = u.v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_i8_to_f64_colmajor(const int8_t* __restrict__ in, long rows, long cols,
+                                                            long ld_in, double* __restrict__ out) {
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * cols) return;
+    long r = idx % rows, c = idx / rows;
+    out[idx] = (double)in[r * ld_in + c];
+}
+
+// ------------------------------------------------------------------------------------------------
+// int8 NT tile product on v_mfma_i32_32x32x32_i8.
+//   C[i][j] += sum_k A[i][k] * B[j][k],  A rows / B rows int8, K contiguous.
+// Block = 256 threads = 4 waves (2 x 2), block tile 128 x 128, wave tile 64 x 64 (2 x 2 MFMA tiles),
+// K step 64 bytes, LDS double buffered, global->register->LDS staging with the loads of tile t+1 issued
+// before the MFMAs of tile t.  LDS rows are 64 B; the 16-B chunk index is XOR-swizzled with (row>>2)&3 so
+// that the ds_read_b128 of a 32-row operand fragment is bank-conflict free.
+// Both operands use the same (lane>>5, byte) -> k map, so the k order inside the instruction is immaterial
+// for an exact integer sum.
+// ------------------------------------------------------------------------------------------------
+#define GI_T 128
+#define GI_BK 64
+
+__device__ __forceinline__ int gi_lds_off(int row, int chunk) { return row * GI_BK + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+struct GiStage {
+    i32x4 a[2], b[2];
+};
+
+__device__ __forceinline__ void gi_load(GiStage& s, const int8_t* __restrict__ Ablk, long lda,
+                                        const int8_t* __restrict__ Bblk, long ldb, long k0, int t) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        int c = t + 256 * i;
+        int row = c >> 2, ch = c & 3;
+        s.a[i] = *(const i32x4*)(Ablk + (long)row * lda + k0 + ch * 16);
+        s.b[i] = *(const i32x4*)(Bblk + (long)row * ldb + k0 + ch * 16);
+    }
+}
+__device__ __forceinline__ void gi_store(const GiStage& s, int8_t* ldsA, int8_t* ldsB, int t) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        int c = t + 256 * i;
+        int row = c >> 2, ch = c & 3;
+        *(i32x4*)(ldsA + gi_lds_off(row, ch)) = s.a[i];
+        *(i32x4*)(ldsB + gi_lds_off(row, ch)) = s.b[i];
+    }
+}
+__device__ __forceinline__ void gi_compute(i32x16 (&acc)[2][2], const int8_t* ldsA, const int8_t* ldsB, int wr, int wc,
+                                           int lane) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+        i32x4 a[2], b[2];
+#pragma unroll
+        for (int m = 0; m < 2; m++) a[m] = *(const i32x4*)(ldsA + gi_lds_off(wr * 64 + m * 32 + r, 2 * ks + h));
+#pragma unroll
+        for (int n = 0; n < 2; n++) b[n] = *(const i32x4*)(ldsB + gi_lds_off(wc * 64 + n * 32 + r, 2 * ks + h));
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int n = 0; n < 2; n++) acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
+}
+
+// MM^T: grid.x = upper-triangular tile pairs, grid.y = K splits; integer atomics into C32.
+__global__ __launch_bounds__(256, 2) void k_syrk_i8(const int8_t* __restrict__ M8, long ld, int ntile, long ksteps_total,
+                                                    long ksteps_per_split, int32_t* __restrict__ C, long ldc) {
+    __shared__ __attribute__((aligned(16))) int8_t lds[2][2][GI_T * GI_BK];
+    int ti = 0, rem = blockIdx.x;
+    while (rem >= ntile - ti) { rem -= ntile - ti; ti++; }
+    const int tj = ti + rem;
+    const long ks0 = (long)blockIdx.y * ksteps_per_split;
+    long ks1 = ks0 + ksteps_per_split;
+    if (ks1 > ksteps_total) ks1 = ksteps_total;
+    if (ks0 >= ks1) return;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
+    const int8_t* Ablk = M8 + (long)ti * GI_T * ld;
+    const int8_t* Bblk = M8 + (long)tj * GI_T * ld;
+    i32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[m][n][q] = 0;
+    GiStage st;
+    gi_load(st, Ablk, ld, Bblk, ld, ks0 * GI_BK, t);
+    gi_store(st, lds[0][0], lds[0][1], t);
+    __syncthreads();
+    int cur = 0;
+    for (long ks = ks0; ks < ks1; ks++) {
+        const bool more = ks + 1 < ks1;
+        if (more) gi_load(st, Ablk, ld, Bblk, ld, (ks + 1) * GI_BK, t);
+        gi_compute(acc, lds[cur][0], lds[cur][1], wr, wc, lane);
+        if (more) gi_store(st, lds[cur ^ 1][0], lds[cur ^ 1][1], t);
+        __syncthreads();
+        cur ^= 1;
+    }
+    // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const int col = lane & 31, rq = 4 * (lane >> 5);
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                long i = (long)ti * GI_T + wr * 64 + m * 32 + (q & 3) + 8 * (q >> 2) + rq;
+                long j = (long)tj * GI_T + wc * 64 + n * 32 + col;
+                int v = acc[m][n][q];
+                if (v) atomicAdd(&C[i * ldc + j], v);
+            }
+}
+
+__global__ __launch_bounds__(256) void k_mmt_downdate(const int8_t* __restrict__ M8, long n_pad, long ld,
+                                                      const long* __restrict__ cols, long ncols,
+                                                      int32_t* __restrict__ C, long ldc) {
+    long j = (long)blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= n_pad) return;
+    int s = 0;
+    for (long q = 0; q < ncols; q++) {
+        long c = cols[q];
+        bool dup = false;  // zeroing a column twice is zeroing it once
+        for (long p = 0; p < q; p++) dup |= (cols[p] == c);
+        if (!dup) s += (int)M8[i * ld + c] * (int)M8[j * ld + c];
+    }
+    // only the upper-triangular tiles of C are live
+    if ((i >> 7) <= (j >> 7)) C[i * ldc + j] -= s;
+}
+
+__global__ __launch_bounds__(256) void k_mmt_finish(const int32_t* __restrict__ C, long n, long ldc,
+                                                    double* __restrict__ out, long ld_out,
+                                                    unsigned long long* __restrict__ maxbits) {
+    long j = (long)blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    double v = 0.0;
+    if (j < n) {
+        int c = ((i >> 7) <= (j >> 7)) ? C[i * ldc + j] : C[j * ldc + i];
+        v = (double)c;
+        out[i * ld_out + j] = v;
+    }
+    // block max (values >= 0 on the diagonal, so the maximum is non-negative: ordered as raw bits)
+    double m = v > 0.0 ? v : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { double x = __shfl_down(m, o); m = x > m ? x : m; }
+    __shared__ double sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+        if (m > 0.0) atomicMax(maxbits, (unsigned long long)__double_as_longlong(m));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mmt_normalise(double* __restrict__ A, long n, long ld,
+                                                       const double* __restrict__ maxv) {
+    long j = (long)blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= n) return;
+    double v = A[i * ld + j] / *maxv;  // E/R/calcMMt.R:13
+    if (i == j) v = v + 0.95;
+    A[i * ld + j] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp64 MFMA GEMM core, C = A * B, v_mfma_f64_16x16x4_f64.
+// Block = 256 threads = 4 waves (2 x 2); block tile 128 x 128; wave tile 64 x 64 = 4 x 4 MFMA tiles;
+// K block 16.  Inside a K block the lane group g = lane>>4 owns k = 4g + s for MFMA step s, so a lane reads
+// 4 consecutive k of its A row at once (the k order of an fp64 sum is a free choice; it is fixed, hence
+// deterministic).
+//   AMODE 0: A is fp64 row-major.   AMODE 1: A is int8 row-major (genotypes), converted in registers.
+//   EPI 0  : store C.
+//   EPI 1  : row-dot: out[i] = sum_c C[i][c] * A8[i][c] over ALL column tiles, accumulated in registers
+//            (one block owns 128 markers and walks every column tile; B is upper triangular (Wu), so
+//            column tile ct only needs k < (ct+1)*128).
+// LDS rows: A f64 [128][16] doubles (+2 pad), A i8 [128][16] bytes, B [16][128] doubles (+4 pad).
+// ------------------------------------------------------------------------------------------------
+#define GF_T 128
+#define GF_BK 16
+#define GF_LDB (GF_T + 4)   /* doubles per B row in LDS: 4*stride*8 mod 256 == 128 -> the 4 k-groups hit distinct banks */
+#define GF_LDA (GF_BK + 2)  /* doubles per A row in LDS */
+
+template <int AMODE>
+struct GfStage {
+    f64x2 b[4];
+    f64x2 a[AMODE == 0 ? 4 : 1];
+    i32x4 a8;
+};
+
+template <int AMODE>
+__device__ __forceinline__ void gf_load(GfStage<AMODE>& s, const void* __restrict__ Ablk, long lda,
+                                        const double* __restrict__ Bblk, long ldb, long k0, int t) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int c = t + 256 * i;           // 1024 chunks of 2 doubles: 16 rows x 64 chunks
+        int kr = c >> 6, cc = c & 63;
+        s.b[i] = *(const f64x2*)(Bblk + (k0 + kr) * ldb + cc * 2);
+    }
+    if (AMODE == 0) {
+        const double* A = (const double*)Ablk;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int c = t + 256 * i;       // 1024 chunks: 128 rows x 8 chunks
+            int row = c >> 3, cc = c & 7;
+            s.a[i] = *(const f64x2*)(A + (long)row * lda + k0 + cc * 2);
+        }
+    } else {
+        const int8_t* A = (const int8_t*)Ablk;
+        if (t < 128) s.a8 = *(const i32x4*)(A + (long)t * lda + k0);
+    }
+}
+template <int AMODE>
+__device__ __forceinline__ void gf_store(const GfStage<AMODE>& s, double* ldsA, double* ldsB, int t) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int c = t + 256 * i;
+        int kr = c >> 6, cc = c & 63;
+        *(f64x2*)(ldsB + kr * GF_LDB + cc * 2) = s.b[i];
+    }
+    if (AMODE == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int c = t + 256 * i;
+            int row = c >> 3, cc = c & 7;
+            *(f64x2*)(ldsA + row * GF_LDA + cc * 2) = s.a[i];
+        }
+    } else {
+        if (t < 128) *(i32x4*)((int8_t*)ldsA + t * 16) = s.a8;
+    }
+}
+template <int AMODE>
+__device__ __forceinline__ void gf_compute(f64x4 (&acc)[4][4], const double* ldsA, const double* ldsB, int wr, int wc,
+                                           int lane) {
+    const int i16 = lane & 15, g = lane >> 4;
+    int w4[4];  // AMODE 1: the lane's 4 consecutive genotype bytes of each row tile
+    if (AMODE == 1) {
+#pragma unroll
+        for (int m = 0; m < 4; m++) w4[m] = *(const int*)((const int8_t*)ldsA + (wr * 64 + m * 16 + i16) * 16 + 4 * g);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        double a[4], b[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            if (AMODE == 0) a[m] = ldsA[(wr * 64 + m * 16 + i16) * GF_LDA + 4 * g + s];
+            else a[m] = (double)((w4[m] << (24 - 8 * s)) >> 24);  // sign-extended byte s
+        }
+#pragma unroll
+        for (int n = 0; n < 4; n++) b[n] = ldsB[(4 * g + s) * GF_LDB + wc * 64 + n * 16 + i16];
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int n = 0; n < 4; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
+}
+
+// LDS bytes: A: 128*18*8 = 18432 (f64) ; B: 16*132*8 = 16896 ; x2 buffers
+#define GF_LDSA_DOUBLES (GF_T * GF_LDA)
+#define GF_LDSB_DOUBLES (GF_BK * GF_LDB)
+
+template <int AMODE, int EPI>
+__global__ __launch_bounds__(256, 2) void k_gemm_f64(const void* __restrict__ A, long lda, const double* __restrict__ B,
+                                                     long ldb, double* __restrict__ C, long ldc, int n_coltiles,
+                                                     long K) {
+    __shared__ __attribute__((aligned(16))) double lds[2][GF_LDSA_DOUBLES + GF_LDSB_DOUBLES];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
+    const int i16 = lane & 15, g = lane >> 4;
+    const long row0 = (long)blockIdx.x * GF_T;
+    const void* Ablk = (AMODE == 0) ? (const void*)((const double*)A + row0 * lda) : (const void*)((const int8_t*)A + row0 * lda);
+    double part[4][4];  // EPI 1: per-lane partial row-dots [row tile][reg]
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) part[m][q] = 0.0;
+
+    const int ct0 = (EPI == 0) ? blockIdx.y : 0;
+    const int ct1 = (EPI == 0) ? blockIdx.y + 1 : n_coltiles;
+    for (int ct = ct0; ct < ct1; ct++) {
+        const double* Bblk = B + (long)ct * GF_T;
+        // EPI 1: B is upper triangular -> rows k >= (ct+1)*128 of this column tile are zero
+        long kend = (EPI == 1) ? ((long)(ct + 1) * GF_T < K ? (long)(ct + 1) * GF_T : K) : K;
+        const long nkb = kend / GF_BK;
+        f64x4 acc[4][4];
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int n = 0; n < 4; n++) acc[m][n] = (f64x4){0.0, 0.0, 0.0, 0.0};
+        GfStage<AMODE> st;
+        gf_load<AMODE>(st, Ablk, lda, Bblk, ldb, 0, t);
+        __syncthreads();  // previous column tile's readers are done with buffer 0
+        gf_store<AMODE>(st, lds[0], lds[0] + GF_LDSA_DOUBLES, t);
+        __syncthreads();
+        int cur = 0;
+        for (long kb = 0; kb < nkb; kb++) {
+            const bool more = kb + 1 < nkb;
+            if (more) gf_load<AMODE>(st, Ablk, lda, Bblk, ldb, (kb + 1) * GF_BK, t);
+            gf_compute<AMODE>(acc, lds[cur], lds[cur] + GF_LDSA_DOUBLES, wr, wc, lane);
+            if (more) gf_store<AMODE>(st, lds[cur ^ 1], lds[cur ^ 1] + GF_LDSA_DOUBLES, t);
+            __syncthreads();
+            cur ^= 1;
+        }
+        // C/D map of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
+        if (EPI == 0) {
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int n = 0; n < 4; n++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        long r = row0 + wr * 64 + m * 16 + g + 4 * q;
+                        long c = (long)ct * GF_T + wc * 64 + n * 16 + i16;
+                        C[r * ldc + c] = acc[m][n][q];
+                    }
+        } else {
+            const int8_t* A8 = (const int8_t*)A;
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    long r = row0 + wr * 64 + m * 16 + g + 4 * q;
+                    const int8_t* mr = A8 + r * lda + (long)ct * GF_T + wc * 64 + i16;
+                    double s = part[m][q];
+#pragma unroll
+                    for (int n = 0; n < 4; n++) s += acc[m][n][q] * (double)mr[n * 16];
+                    part[m][q] = s;
+                }
+        }
+    }
+    if (EPI == 1) {
+        // reduce over the 16 lanes that share a row (lane&15), then over the two waves wc = 0,1 (fixed order)
+        __syncthreads();
+        double* red = lds[0];  // [2][128]
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                double s = part[m][q];
+                s += __shfl_xor(s, 1);
+                s += __shfl_xor(s, 2);
+                s += __shfl_xor(s, 4);
+                s += __shfl_xor(s, 8);
+                if (i16 == 0) red[wc * 128 + wr * 64 + m * 16 + g + 4 * q] = s;
+            }
+        __syncthreads();
+        if (t < 128) C[row0 + t] = red[t] + red[128 + t];
+    }
+}
+
+// Wu[j][k] = Wt[j][k] + Wt[k][j] (j<k) ; Wt[k][k] (j==k) ; 0 (j>k).  Wt = row-major image of W^T.
+__global__ __launch_bounds__(256) void k_fold_upper(const double* __restrict__ Wt, long np, double* __restrict__ Wu) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const long bj = (long)blockIdx.y * 32, bk = (long)blockIdx.x * 32;
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = Wt[(bk + r) * np + bj + tx];  // tile[kk][jj] = Wt[bk+kk][bj+jj]
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        long j = bj + r, k = bk + tx;
+        double direct = Wt[j * np + k];
+        double v = (j < k) ? direct + tile[tx][r] : (j == k ? direct : 0.0);
+        Wu[j * np + k] = v;
+    }
+}
+
+// out[i] = sum_j At[j][i] * x[j]   (At row-major = column-major image of the R matrix: out = A x)
+// Block = 4 waves x 64 columns; wave w sums j = w, w+4, ... ; fixed-order LDS combine.
+__global__ __launch_bounds__(256) void k_colgemv(const double* __restrict__ At, long n, long np,
+                                                 const double* __restrict__ x, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + lane;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    long j = w;
+    for (; j + 12 < n; j += 16) {
+        s0 += At[j * np + i] * x[j];
+        s1 += At[(j + 4) * np + i] * x[j + 4];
+        s2 += At[(j + 8) * np + i] * x[j + 8];
+        s3 += At[(j + 12) * np + i] * x[j + 12];
+    }
+    for (; j < n; j += 4) s0 += At[j * np + i] * x[j];
+    __shared__ double red[4][64];
+    red[w][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (w == 0) out[i] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// a_i = scale * sum_j Mt8[i][j] v[j].  One wave owns 4 marker rows at a time; every lane streams 16
+// genotype bytes per row per step (coalesced 1 KiB per wave-instruction) and the 16 matching v values,
+// then a wavefront shuffle reduction.  HBM-bound on the genotype bytes.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gemv_i8(const int8_t* __restrict__ Mt8, long L_pad, long n_pad, long ld,
+                                                 const double* __restrict__ v, double scale, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * 256) >> 6;
+    for (long r0 = wave * 4; r0 < L_pad; r0 += nwaves * 4) {
+        double s[4] = {0, 0, 0, 0};
+        for (long c = (long)lane * 16; c < n_pad; c += 1024) {
+            union { i32x4 q; int8_t b[16]; } m[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) m[r].q = *(const i32x4*)(Mt8 + (r0 + r) * ld + c);
+            double vv[16];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                f64x2 x = *(const f64x2*)(v + c + 2 * q);
+                vv[2 * q] = x[0];
+                vv[2 * q + 1] = x[1];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int q = 0; q < 16; q++) s[r] += (double)m[r].b[q] * vv[q];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            double x = s[r];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
+            if (lane == 0) out[r0 + r] = scale * x;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_zero_rows(double* __restrict__ a, double* __restrict__ vara, long L,
+                                                   const long* __restrict__ rows, long nrows, long row_offset) {
+    long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nrows) return;
+    long r = rows[q] - row_offset;
+    if (r < 0 || r >= L) return;
+    if (a) a[r] = 0.0;
+    if (vara) vara[r] = 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tsq = a^2 / vara ; first index of the maximum, NaN ignored (find_qtl.R:71-83).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void best_merge(double& bv, long& bi, double v, long i) {
+    // (v, i) beats (bv, bi) if bi < 0, or v > bv, or v == bv and i < bi ; i < 0 means "none"
+    if (i >= 0 && (bi < 0 || v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
+}
+__global__ __launch_bounds__(256) void k_tsq_partial(const double* __restrict__ a, const double* __restrict__ vara, long L,
+                                                     double* __restrict__ tsq_out, double* __restrict__ pv,
+                                                     long* __restrict__ pi) {
+    double bv = 0.0;
+    long bi = -1;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L; i += (long)gridDim.x * 256) {
+        double x = a[i];
+        double t = (x * x) / vara[i];
+        if (tsq_out) tsq_out[i] = t;
+        if (t == t) best_merge(bv, bi, t, i);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        double ov = __shfl_down(bv, o);
+        long oi = __shfl_down(bi, o);
+        best_merge(bv, bi, ov, oi);
+    }
+    __shared__ double sv[4];
+    __shared__ long si[4];
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) best_merge(bv, bi, sv[w], si[w]);
+        pv[blockIdx.x] = bv;
+        pi[blockIdx.x] = bi;
+    }
+}
+__global__ __launch_bounds__(256) void k_tsq_final(const double* __restrict__ pv, const long* __restrict__ pi, int nparts,
+                                                   eagle_best* __restrict__ best) {
+    double bv = 0.0;
+    long bi = -1;
+    for (int p = threadIdx.x; p < nparts; p += 256) best_merge(bv, bi, pv[p], pi[p]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        double ov = __shfl_down(bv, o);
+        long oi = __shfl_down(bi, o);
+        best_merge(bv, bi, ov, oi);
+    }
+    __shared__ double sv[4];
+    __shared__ long si[4];
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) best_merge(bv, bi, sv[w], si[w]);
+        best->tsqmax = bi >= 0 ? bv : __longlong_as_double(0x7ff8000000000000LL);
+        best->index0 = bi;
+        best->near_ties = 0;
+    }
+}
+__global__ __launch_bounds__(256) void k_tsq_near(const double* __restrict__ a, const double* __restrict__ vara, long L,
+                                                  eagle_best* __restrict__ best) {
+    const double mx = best->tsqmax;
+    if (!(mx == mx)) return;
+    const double thr = isinf(mx) ? mx : mx - fabs(mx) * 1e-9;
+    int cnt = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L; i += (long)gridDim.x * 256) {
+        double x = a[i];
+        double t = (x * x) / vara[i];
+        if (t == t && t >= thr) cnt++;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd((unsigned long long*)&best->near_ties, (unsigned long long)cnt);
+}
+
+// ================================================================================================
+// launchers (section 2 of eagle_hip.h)
+// ================================================================================================
+#define LAUNCH_CHECK(ctx)                                                   \
+    do {                                                                    \
+        hipError_t e__ = hipGetLastError();                                 \
+        if (e__ != hipSuccess) return eagle_fail_hip(ctx, e__, __func__);   \
+    } while (0)
+
+extern "C" long eagle_pad128(long x) { return (x + 127) / 128 * 128; }
+
+extern "C" int eagle_dev_decode_ascii(eagle_ctx* ctx, const uint8_t* raw, long rows, long cols, long line_stride,
+                                      int8_t* out, long ld_out, int* bad_chars_dev, void* stream) {
+    if (rows <= 0) return EAGLE_OK;
+    if (ld_out % 4 || cols > ld_out || rows > 65535L * 32768L) return eagle_fail(ctx, EAGLE_ERR_ARG, "decode_ascii: bad shape");
+    // grid.y is limited to 65535: walk row bands
+    for (long r0 = 0; r0 < rows; r0 += 65535) {
+        long nr = rows - r0 < 65535 ? rows - r0 : 65535;
+        dim3 grid((unsigned)((ld_out / 4 + 255) / 256), (unsigned)nr);
+        hipLaunchKernelGGL(k_decode_ascii, grid, dim3(256), 0, (hipStream_t)stream, raw + r0 * line_stride, nr, cols,
+                           line_stride, out + r0 * ld_out, ld_out, bad_chars_dev);
+    }
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+
+extern "C" int eagle_dev_transpose_i8(eagle_ctx* ctx, const int8_t* in, long rows, long cols, long ld_in, int8_t* out,
+                                      long ld_out, void* stream) {
+    if (rows % 64 || cols % 64 || ld_in % 16 || ld_out % 16 || cols > ld_in || rows > ld_out)
+        return eagle_fail(ctx, EAGLE_ERR_ARG, "transpose_i8: dims must be multiples of 64");
+    for (long r0 = 0; r0 < rows; r0 += 64L * 65535) {
+        long nr = rows - r0 < 64L * 65535 ? rows - r0 : 64L * 65535;
+        dim3 grid((unsigned)(cols / 64), (unsigned)(nr / 64));
+        hipLaunchKernelGGL(k_transpose_i8, grid, dim3(256), 0, (hipStream_t)stream, in + r0 * ld_in, ld_in, out + r0,
+                           ld_out);
+    }
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+
+extern "C" int eagle_dev_i8_to_f64_colmajor(eagle_ctx* ctx, const int8_t* in, long rows, long cols, long ld_in,
+                                            double* out_colmajor, void* stream) {
+    long tot = rows * cols;
+    if (tot <= 0) return EAGLE_OK;
+    hipLaunchKernelGGL(k_i8_to_f64_colmajor, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in,
+                       rows, cols, ld_in, out_colmajor);
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+
+extern "C" int eagle_dev_mmt_accumulate(eagle_ctx* ctx, const int8_t* M8, long n_pad, long L_pad, long ld, int32_t* C32,
+                                        void* stream) {
+    if (n_pad % GI_T || L_pad % GI_BK || ld % 16 || L_pad > ld || n_pad <= 0)
+        return eagle_fail(ctx, EAGLE_ERR_ARG, "mmt_accumulate: layout contract violated");
+    if (L_pad == 0) return EAGLE_OK;
+    const int nt = (int)(n_pad / GI_T);
+    const long npairs = (long)nt * (nt + 1) / 2;
+    const long ksteps = L_pad / GI_BK;
+    // enough blocks to fill 256 CUs several times over, but K runs long enough to amortise the atomics
+    long want = (8L * 256 + npairs - 1) / npairs;
+    long maxsplit = ksteps / 32 > 0 ? ksteps / 32 : 1;
+    long nsplit = want < maxsplit ? want : maxsplit;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > 65535) nsplit = 65535;
+    long per = (ksteps + nsplit - 1) / nsplit;
+    nsplit = (ksteps + per - 1) / per;
+    dim3 grid((unsigned)npairs, (unsigned)nsplit);
+    hipLaunchKernelGGL(k_syrk_i8, grid, dim3(256), 0, (hipStream_t)stream, M8, ld, nt, ksteps, per, C32, n_pad);
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+
+extern "C" int eagle_dev_mmt_downdate(eagle_ctx* ctx, const int8_t* M8, long n_pad, long ld, const long* cols_dev,
+                                      long ncols, int32_t* C32, void* stream) {
+    if (ncols <= 0) return EAGLE_OK;
+    dim3 grid((unsigned)((n_pad + 255) / 256), (unsigned)n_pad);
+    if (n_pad > 65535) return eagle_fail(ctx, EAGLE_ERR_ARG, "mmt_downdate: n too large");
+    hipLaunchKernelGGL(k_mmt_downdate, grid, dim3(256), 0, (hipStream_t)stream, M8, n_pad, ld, cols_dev, ncols, C32, n_pad);
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+
+extern "C" int eagle_dev_mmt_finish(eagle_ctx* ctx, const int32_t* C32, long n, long n_pad, double* MMt, long ld_out,
+                                    double* max_dev, void* stream) {
+    if (n > 65535) return eagle_fail(ctx, EAGLE_ERR_ARG, "mmt_finish: n too large");
+    hipError_t e = hipMemsetAsync(max_dev, 0, sizeof(double), (hipStream_t)stream);
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "mmt_finish memset");
+    dim3 grid((unsigned)((n + 255) / 256), (unsigned)n);
+    hipLaunchKernelGGL(k_mmt_finish, grid, dim3(256), 0, (hipStream_t)stream, C32, n, n_pad, MMt, ld_out,
+                       (unsigned long long*)max_dev);
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+
+extern "C" int eagle_dev_mmt_normalise(eagle_ctx* ctx, double* MMt, long n, long ld, const double* max_dev, void* stream) {
+    if (n > 65535) return eagle_fail(ctx, EAGLE_ERR_ARG, "mmt_normalise: n too large");
+    dim3 grid((unsigned)((n + 255) / 256), (unsigned)n);
+    hipLaunchKernelGGL(k_mmt_normalise, grid, dim3(256), 0, (hipStream_t)stream, MMt, n, ld, max_dev);
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+
+extern "C" int eagle_dev_gemm_f64(eagle_ctx* ctx, const double* A, const double* B, double* C, long np, void* stream) {
+    if (np % GF_T || np <= 0) return eagle_fail(ctx, EAGLE_ERR_ARG, "gemm_f64: size must be a multiple of 128");
+    dim3 grid((unsigned)(np / GF_T), (unsigned)(np / GF_T));
+    hipLaunchKernelGGL((k_gemm_f64<0, 0>), grid, dim3(256), 0, (hipStream_t)stream, (const void*)A, np, B, np, C, np,
+                       (int)(np / GF_T), np);
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+
+extern "C" int eagle_dev_scan_operands(eagle_ctx* ctx, const double* Sa, const double* Va, const double* ahat, long n,
+                                       long n_pad, double* v_out, double* Wu_out, double* tmp, void* stream) {
+    if (n_pad % GF_T || n > n_pad) return eagle_fail(ctx, EAGLE_ERR_ARG, "scan_operands: bad padding");
+    hipStream_t s = (hipStream_t)stream;
+    // v = S a_hat ; Sa is the row-major image of S^T, so v_i = sum_j Sa[j][i] a_hat[j]
+    hipError_t e = hipMemsetAsync(v_out, 0, sizeof(double) * n_pad, s);
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "scan_operands memset");
+    hipLaunchKernelGGL(k_colgemv, dim3((unsigned)(n_pad / 64)), dim3(256), 0, s, Sa, n, n_pad, ahat, v_out);
+    LAUNCH_CHECK(ctx);
+    // Xt = (V S)^T = S^T V^T = Sa * Va ; Wt = (S X)^T = X^T S^T = Xt * Sa        (row-major images)
+    int rc = eagle_dev_gemm_f64(ctx, Sa, Va, tmp, n_pad, stream);
+    if (rc) return rc;
+    rc = eagle_dev_gemm_f64(ctx, tmp, Sa, Wu_out, n_pad, stream);
+    if (rc) return rc;
+    // fold W into its upper triangle (in place is not possible: reads the transposed element) -> via tmp
+    e = hipMemcpyAsync(tmp, Wu_out, sizeof(double) * n_pad * n_pad, hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "scan_operands copy");
+    dim3 grid((unsigned)(n_pad / 32), (unsigned)(n_pad / 32));
+    hipLaunchKernelGGL(k_fold_upper, grid, dim3(256), 0, s, tmp, n_pad, Wu_out);
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+
+extern "C" int eagle_dev_colgemv(eagle_ctx* ctx, const double* At, long n, long n_pad, const double* x, double* out,
+                                 void* stream) {
+    if (n_pad % 64) return eagle_fail(ctx, EAGLE_ERR_ARG, "colgemv: bad padding");
+    hipLaunchKernelGGL(k_colgemv, dim3((unsigned)(n_pad / 64)), dim3(256), 0, (hipStream_t)stream, At, n, n_pad, x, out);
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+
+extern "C" int eagle_dev_gemv_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* v,
+                                 double scale, double* out, void* stream) {
+    if (L_pad % 4 || n_pad % 16 || ld % 16 || n_pad > ld) return eagle_fail(ctx, EAGLE_ERR_ARG, "gemv_i8: layout contract violated");
+    if (L_pad == 0) return EAGLE_OK;
+    long waves = L_pad / 4;
+    long blocks = (waves + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_gemv_i8, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, Mt8, L_pad, n_pad, ld, v,
+                       scale, out);
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+
+extern "C" int eagle_dev_vara_f64(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu,
+                                  double* vara_out, void* stream) {
+    if (L_pad % GF_T || n_pad % GF_T || ld % 16 || n_pad > ld)
+        return eagle_fail(ctx, EAGLE_ERR_ARG, "vara_f64: layout contract violated");
+    if (L_pad == 0) return EAGLE_OK;
+    dim3 grid((unsigned)(L_pad / GF_T));
+    hipLaunchKernelGGL((k_gemm_f64<1, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const void*)Mt8, ld, Wu, n_pad,
+                       vara_out, 0L, (int)(n_pad / GF_T), n_pad);
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+
+extern "C" int eagle_dev_zero_rows(eagle_ctx* ctx, double* a, double* vara, long L, const long* rows_dev, long nrows,
+                                   long row_offset, void* stream) {
+    if (nrows <= 0) return EAGLE_OK;
+    hipLaunchKernelGGL(k_zero_rows, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, vara, L,
+                       rows_dev, nrows, row_offset);
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+
+extern "C" int eagle_dev_tsq_argmax(eagle_ctx* ctx, const double* a, const double* vara, long L, double* tsq_out,
+                                    eagle_best* best_dev, double* block_scratch, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    int nparts = (int)((L + 255) / 256);
+    if (nparts > 1024) nparts = 1024;
+    if (nparts < 1) nparts = 1;
+    double* pv = block_scratch;
+    long* pi = (long*)(block_scratch + 1024);
+    hipLaunchKernelGGL(k_tsq_partial, dim3(nparts), dim3(256), 0, s, a, vara, L, tsq_out, pv, pi);
+    hipLaunchKernelGGL(k_tsq_final, dim3(1), dim3(256), 0, s, pv, pi, nparts, best_dev);
+    hipLaunchKernelGGL(k_tsq_near, dim3(nparts), dim3(256), 0, s, a, vara, L, best_dev);
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+
+// ---- int8-slice vara path: implemented in eagle_vara_i8.hip ----

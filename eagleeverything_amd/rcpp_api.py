@@ -1,0 +1,182 @@
+"""Host-side mirror of the reference's exported C++ functions, over the C ABI of libeaglehip.so.
+
+Same names, argument order and error behaviour as the functions registered in
+E/src/RcppExports.cpp:154-170 (E/ = MyPackage/Eagle/ of the reference), so a parity test reads like a
+call into the reference:
+
+    ReadBlock(asciifname, start_row, numcols, numrows_in_block)                          RcppExports.cpp:9
+    calculateMMt_rcpp(f_name_ascii, max_memory_in_Gbytes, num_cores, selected_loci, dims, quiet, message)   :37
+    calculate_a_and_vara_rcpp(f_name_ascii, selected_loci, inv_MMt_sqrt, dim_reduced_vara,
+                              max_memory_in_Gbytes, dims, a, quiet, message)             :54
+    calculate_reduced_a_rcpp(f_name_ascii, varG, P, y, max_memory_in_Gbytes, dims, selected_loci, quiet, message)  :73
+
+R matrices are column-major; numpy arrays are converted to Fortran order on the way in and come back so.
+NA is numpy.nan.  Every call runs on the GPU; nothing here computes.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import EagleError, c_dp, c_lp
+
+_ctx = {}
+_callbacks = {}
+
+
+def context(device=0):
+    """The per-device eagle_ctx (opened on first use; fails loudly without a gfx950 device)."""
+    if device not in _ctx:
+        L = _lib.load()
+        h = L.eagle_open(int(device))
+        if not h:
+            raise EagleError(-6, L.eagle_open_error().decode())
+        _ctx[device] = h
+    return _ctx[device]
+
+
+def close_all():
+    L = _lib.load()
+    for h in _ctx.values():
+        L.eagle_close(h)
+    _ctx.clear()
+    _callbacks.clear()
+
+
+def _check(ctx, rc, soft_ok=False):
+    if rc < 0 or (rc > 0 and not soft_ok):
+        raise EagleError(rc, _lib.load().eagle_last_error(ctx).decode())
+    return rc
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_dp)
+
+
+def _f64F(a):
+    return np.require(np.asarray(a, dtype=np.float64), requirements=["F", "ALIGNED"])
+
+
+def _sel(selected_loci):
+    s = np.atleast_1d(np.asarray(selected_loci, dtype=np.float64)).copy()
+    return s, _dp(s), s.size
+
+
+def _dims(dims):
+    d = (C.c_long * 2)(int(dims[0]), int(dims[1]))
+    return d
+
+
+def _set_message(ctx, message):
+    L = _lib.load()
+    if message is None:
+        L.eagle_set_message_callback(ctx, C.cast(None, _lib.MESSAGE_FN), None)
+        _callbacks.pop(ctx, None)
+    else:
+        cb = _lib.MESSAGE_FN(lambda text, user: message(text.decode()))
+        _callbacks[ctx] = cb  # keep alive
+        L.eagle_set_message_callback(ctx, cb, None)
+
+
+def device_info(device=0):
+    L = _lib.load()
+    ctx = context(device)
+    arch = C.create_string_buffer(64)
+    cu = C.c_int()
+    hbm = C.c_int64()
+    _check(ctx, L.eagle_device_info(ctx, arch, 64, C.byref(cu), C.byref(hbm)))
+    return {"arch": arch.value.decode(), "cu_count": cu.value, "hbm_bytes": hbm.value}
+
+
+def set_scan_mode(mode, device=0):
+    """0 = fp64 MFMA vara kernel, 1 = int8-slice vara kernel."""
+    ctx = context(device)
+    _check(ctx, _lib.load().eagle_set_scan_mode(ctx, int(mode)))
+
+
+def drop_cache(device=0):
+    _lib.load().eagle_drop_cache(context(device))
+
+
+def ReadBlock(asciifname, start_row, numcols, numrows_in_block, device=0):
+    L = _lib.load()
+    ctx = context(device)
+    out = np.zeros((int(numrows_in_block), int(numcols)), dtype=np.float64, order="F")
+    _check(ctx, L.eagle_read_block(ctx, os.fsencode(asciifname), int(start_row), int(numcols), int(numrows_in_block),
+                                   _dp(out)))
+    return out
+
+
+def calculateMMt_rcpp(f_name_ascii, max_memory_in_Gbytes, num_cores, selected_loci, dims, quiet=True, message=None,
+                      device=0):
+    L = _lib.load()
+    ctx = context(device)
+    _set_message(ctx, message)
+    n = int(dims[0])
+    s, sp, ns = _sel(selected_loci)
+    out = np.zeros((n, n), dtype=np.float64, order="F")
+    _check(ctx, L.eagle_calculateMMt(ctx, os.fsencode(f_name_ascii), float(max_memory_in_Gbytes), int(num_cores), sp, ns,
+                                     _dims(dims), int(bool(quiet)), _dp(out)))
+    return out
+
+
+def calculate_a_and_vara_rcpp(f_name_ascii, selected_loci, inv_MMt_sqrt, dim_reduced_vara, max_memory_in_Gbytes, dims,
+                              a, quiet=True, message=None, device=0):
+    L = _lib.load()
+    ctx = context(device)
+    _set_message(ctx, message)
+    Lm, n = int(dims[0]), int(dims[1])
+    S = _f64F(inv_MMt_sqrt)
+    V = _f64F(dim_reduced_vara)
+    ah = _f64F(np.ravel(a))
+    if S.shape != (n, n) or V.shape != (n, n) or ah.size != n:
+        raise ValueError("inv_MMt_sqrt / dim_reduced_vara must be n x n and a of length n")
+    s, sp, ns = _sel(selected_loci)
+    a_out = np.zeros(Lm)
+    v_out = np.zeros(Lm)
+    rc = _check(ctx, L.eagle_calculate_a_and_vara(ctx, os.fsencode(f_name_ascii), sp, ns, _dp(S), _dp(V),
+                                                  float(max_memory_in_Gbytes), _dims(dims), _dp(ah), int(bool(quiet)),
+                                                  _dp(a_out), _dp(v_out)), soft_ok=True)
+    if rc == 1:  # List(a = 0, vara = 0), calculate_a_and_vara_rcpp.cpp:141-142
+        return {"a": np.zeros(1), "vara": np.zeros(1)}
+    return {"a": a_out.reshape(Lm, 1), "vara": v_out.reshape(Lm, 1)}
+
+
+def calculate_reduced_a_rcpp(f_name_ascii, varG, P, y, max_memory_in_Gbytes, dims, selected_loci, quiet=True,
+                             message=None, device=0):
+    L = _lib.load()
+    ctx = context(device)
+    _set_message(ctx, message)
+    n, Lm = int(dims[0]), int(dims[1])
+    Pm = _f64F(P)
+    yv = _f64F(np.ravel(y))
+    s, sp, ns = _sel(selected_loci)
+    out = np.zeros(Lm)
+    rc = _check(ctx, L.eagle_calculate_reduced_a(ctx, os.fsencode(f_name_ascii), float(varG), _dp(Pm), _dp(yv),
+                                                 float(max_memory_in_Gbytes), _dims(dims), sp, ns, int(bool(quiet)),
+                                                 _dp(out)), soft_ok=True)
+    if rc == 1:  # 1 x 1 zero matrix, calculate_reduced_a_rcpp.cpp:94-103
+        return np.zeros((1, 1))
+    return out.reshape(Lm, 1)
+
+
+def last_scan_argmax(device=0):
+    """find_qtl.R:71-83 evaluated on the device on the last scan: (1-based index, tsq max, near ties)."""
+    L = _lib.load()
+    ctx = context(device)
+    idx = C.c_long()
+    mx = C.c_double()
+    ties = C.c_long()
+    _check(ctx, L.eagle_last_scan_argmax(ctx, C.byref(idx), C.byref(mx), C.byref(ties)))
+    return idx.value, mx.value, ties.value
+
+
+def last_mmt_normalised(n, device=0):
+    """calcMMt.R:13 applied on the device to the last calculateMMt result."""
+    L = _lib.load()
+    ctx = context(device)
+    out = np.zeros((n, n), dtype=np.float64, order="F")
+    mx = C.c_double()
+    _check(ctx, L.eagle_last_mmt_normalised(ctx, _dp(out), C.byref(mx)))
+    return out, mx.value

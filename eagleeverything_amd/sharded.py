@@ -1,0 +1,224 @@
+"""Marker-sharded multi-GPU driver: one process per GPU, torch.distributed over RCCL (backend "nccl" on ROCm).
+
+The reference is single-process and has no collective; SURVEY.md section 8(e) derives the sharding:
+markers are independent units for the scan (calculate_a_and_vara_rcpp.cpp:103-112) and a k-split for
+MM^T = sum_s M_s M_s^T (calculateMMt_rcpp.cpp:95).
+
+  rank r owns the contiguous marker range shard_range(L, r, world): a row range of Mt.ascii, a column window of
+  M.ascii, resident in its HBM as int8.
+  MM^T : each rank accumulates its exact int32 partial -> ONE all-reduce (sum) -> identical fp64 MM^T everywhere.
+         Integer sum: order independent, bit-exact.
+  scan : every rank holds S, V, a_hat (n x n host algebra, broadcast from rank 0), scans its shard, and the
+         per-shard (max tsq, first global index) pairs are all-gathered (16 B/rank); the winner is the largest
+         tsq, ties broken by the smallest global index = which(tsq == max)[1] of E/R/find_qtl.R:76-80.
+
+`Collectives` only needs torch.distributed (works with gloo on CPU, which is how the N>1 logic is tested);
+`DeviceShard` needs a GPU and calls the device-resident C ABI (section 2 of include/eagle_hip.h).
+"""
+import ctypes as C
+
+import numpy as np
+
+
+def shard_range(L, rank, world):
+    """Contiguous marker range [m0, m1) of `rank`: floor split, remainder to the first ranks."""
+    base, rem = divmod(int(L), int(world))
+    m0 = rank * base + min(rank, rem)
+    return m0, m0 + base + (1 if rank < rem else 0)
+
+
+class Collectives:
+    """The two exchange steps of the sharded path."""
+
+    def __init__(self, dist=None):
+        self.dist = dist
+        self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+
+    def sum_partial_mmt(self, c32):
+        """In-place sum of the int32 partial MM^T tensors of all ranks (exact)."""
+        if self.world > 1:
+            self.dist.all_reduce(c32, op=self.dist.ReduceOp.SUM)
+        return c32
+
+    def broadcast_(self, t, src=0):
+        if self.world > 1:
+            self.dist.broadcast(t, src=src)
+        return t
+
+    def best_marker(self, local_tsqmax, local_index0_global, device=None):
+        """All-gather (tsqmax, global 0-based index or -1) and pick find_qtl.R:76-80's marker.
+        Returns (1-based global index or 0, tsqmax)."""
+        import torch
+        mine = torch.tensor([float(local_tsqmax), float(local_index0_global)], dtype=torch.float64, device=device)
+        if self.world > 1:
+            allv = [torch.empty_like(mine) for _ in range(self.world)]
+            self.dist.all_gather(allv, mine)
+            allv = torch.stack(allv).cpu().numpy()
+        else:
+            allv = mine.cpu().numpy()[None, :]
+        return pick_best(allv[:, 0], allv[:, 1].astype(np.int64))
+
+
+def pick_best(tsqmax, index0):
+    """Largest tsq among shards that have a valid index; ties -> smallest global index. NaN shards skipped."""
+    best_v, best_i = np.nan, -1
+    for v, i in zip(tsqmax, index0):
+        if i < 0 or np.isnan(v):
+            continue
+        if best_i < 0 or v > best_v or (v == best_v and i < best_i):
+            best_v, best_i = float(v), int(i)
+    return best_i + 1, best_v
+
+
+class DeviceShard:
+    """One rank's genotype shard resident in HBM + the device-resident hot path on it."""
+
+    def __init__(self, n, L_local, first_marker=0, device=0):
+        import torch
+
+        from . import _lib, rcpp_api
+        self.torch = torch
+        self.L = _lib.load()
+        self.ctx = rcpp_api.context(device)
+        self.dev = torch.device("cuda", device)
+        self.n, self.Lloc, self.first = int(n), int(L_local), int(first_marker)
+        self.np_ = int(self.L.eagle_pad128(self.n))
+        self.Lp = int(self.L.eagle_pad128(self.Lloc))
+        self.Mt8 = torch.zeros((self.Lp, self.np_), dtype=torch.int8, device=self.dev)  # marker-major
+        self.M8 = None                                                                   # individual-major
+        self.a = torch.zeros(self.Lp, dtype=torch.float64, device=self.dev)
+        self.vara = torch.zeros(self.Lp, dtype=torch.float64, device=self.dev)
+        self._scratch = torch.zeros(3 * 1024, dtype=torch.float64, device=self.dev)
+        self._best = torch.zeros(3, dtype=torch.int64, device=self.dev)  # eagle_best: {f64, i64, i64}
+        self.Sa = self.Va = self.ahat = self.v = self.Wu = self.tmp = None
+        self.ws = None
+        self.mode = 0
+        self.nslices = 8
+
+    # ---- plumbing -------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def _check(self, rc):
+        if rc != 0:
+            from ._lib import EagleError
+            raise EagleError(rc, self.L.eagle_last_error(self.ctx).decode())
+
+    # ---- genotype shard -------------------------------------------------------------------------
+    def fill_synthetic(self, seed=20240601, chunk=8192):
+        """HWE genotypes generated on the device: p_j ~ U(0.05,0.5), g_ij ~ Bin(2,p_j)."""
+        torch = self.torch
+        gen = torch.Generator(device=self.dev)
+        for m0 in range(0, self.Lloc, chunk):
+            m1 = min(self.Lloc, m0 + chunk)
+            gen.manual_seed(int(seed) * 1000003 + (self.first + m0))
+            p = torch.rand((m1 - m0, 1), generator=gen, device=self.dev) * 0.45 + 0.05
+            u1 = torch.rand((m1 - m0, self.n), generator=gen, device=self.dev)
+            u2 = torch.rand((m1 - m0, self.n), generator=gen, device=self.dev)
+            g = (u1 < p).to(torch.int8) + (u2 < p).to(torch.int8) - 1
+            self.Mt8[m0:m1, : self.n] = g
+        self.M8 = None
+
+    def load_Mt_ascii(self, path, max_mem_gb=8.0, threads=8):
+        """Rows [first, first+Lloc) of Mt.ascii (the shard is a contiguous byte range of the file)."""
+        self.Mt8.zero_()
+        self.torch.cuda.synchronize(self.dev)
+        self._check(self.L.eagle_dev_load_ascii(self.ctx, path.encode(), self.first, self.Lloc, 0, self.n,
+                                                self.Mt8.data_ptr(), self.np_, float(max_mem_gb), int(threads)))
+        self.M8 = None
+
+    def load_M_ascii(self, path, max_mem_gb=8.0, threads=8):
+        """Column window [first, first+Lloc) of every line of M.ascii."""
+        torch = self.torch
+        self.M8 = torch.zeros((self.np_, self.Lp), dtype=torch.int8, device=self.dev)
+        torch.cuda.synchronize(self.dev)
+        self._check(self.L.eagle_dev_load_ascii(self.ctx, path.encode(), 0, self.n, self.first, self.Lloc,
+                                                self.M8.data_ptr(), self.Lp, float(max_mem_gb), int(threads)))
+
+    def individual_major(self):
+        if self.M8 is None:
+            self.M8 = self.torch.empty((self.np_, self.Lp), dtype=self.torch.int8, device=self.dev)
+            self._check(self.L.eagle_dev_transpose_i8(self.ctx, self.Mt8.data_ptr(), self.Lp, self.np_, self.np_,
+                                                      self.M8.data_ptr(), self.Lp, self._stream()))
+        return self.M8
+
+    # ---- MM^T -----------------------------------------------------------------------------------
+    def mmt_partial(self, out=None):
+        """Exact int32 partial M_s M_s^T of this shard (upper-triangular 128-tiles live)."""
+        torch = self.torch
+        M8 = self.individual_major()
+        c32 = out if out is not None else torch.empty((self.np_, self.np_), dtype=torch.int32, device=self.dev)
+        c32.zero_()
+        self._check(self.L.eagle_dev_mmt_accumulate(self.ctx, M8.data_ptr(), self.np_, self.Lp, self.Lp, c32.data_ptr(),
+                                                    self._stream()))
+        return c32
+
+    def mmt_finish(self, c32, normalise=False):
+        torch = self.torch
+        out = torch.empty((self.n, self.n), dtype=torch.float64, device=self.dev)
+        mx = torch.zeros(1, dtype=torch.float64, device=self.dev)
+        self._check(self.L.eagle_dev_mmt_finish(self.ctx, c32.data_ptr(), self.n, self.np_, out.data_ptr(), self.n,
+                                                mx.data_ptr(), self._stream()))
+        if normalise:  # calcMMt.R:13
+            self._check(self.L.eagle_dev_mmt_normalise(self.ctx, out.data_ptr(), self.n, self.n, mx.data_ptr(),
+                                                       self._stream()))
+        return out, mx
+
+    # ---- scan -----------------------------------------------------------------------------------
+    def set_operands(self, S, V, ahat):
+        """S = inv_MMt_sqrt, V = dim_reduced_vara (n x n, any torch/numpy layout, as MATRICES), a_hat (n)."""
+        torch = self.torch
+        n, np_ = self.n, self.np_
+
+        def pad_t(Mx):  # row-major image of the transpose == the column-major R matrix, zero padded
+            Mx = torch.as_tensor(Mx, dtype=torch.float64, device=self.dev)
+            out = torch.zeros((np_, np_), dtype=torch.float64, device=self.dev)
+            out[:n, :n] = Mx.t()
+            return out
+        self.Sa, self.Va = pad_t(S), pad_t(V)
+        self.ahat = torch.zeros(np_, dtype=torch.float64, device=self.dev)
+        self.ahat[:n] = torch.as_tensor(ahat, dtype=torch.float64, device=self.dev).reshape(-1)
+        if self.v is None:
+            self.v = torch.zeros(np_, dtype=torch.float64, device=self.dev)
+            self.Wu = torch.zeros((np_, np_), dtype=torch.float64, device=self.dev)
+            self.tmp = torch.zeros((np_, np_), dtype=torch.float64, device=self.dev)
+
+    def scan_operands(self):
+        self._check(self.L.eagle_dev_scan_operands(self.ctx, self.Sa.data_ptr(), self.Va.data_ptr(), self.ahat.data_ptr(),
+                                                   self.n, self.np_, self.v.data_ptr(), self.Wu.data_ptr(),
+                                                   self.tmp.data_ptr(), self._stream()))
+
+    def gemv_a(self):
+        self._check(self.L.eagle_dev_gemv_i8(self.ctx, self.Mt8.data_ptr(), self.Lp, self.np_, self.np_, self.v.data_ptr(),
+                                             1.0, self.a.data_ptr(), self._stream()))
+
+    def vara_kernel(self):
+        if self.mode == 0:
+            self._check(self.L.eagle_dev_vara_f64(self.ctx, self.Mt8.data_ptr(), self.Lp, self.np_, self.np_,
+                                                  self.Wu.data_ptr(), self.vara.data_ptr(), self._stream()))
+        else:
+            if self.ws is None:
+                nb = int(self.L.eagle_vara_i8_workspace_bytes(self.np_, self.Lp, self.nslices))
+                self.ws = self.torch.empty(nb, dtype=self.torch.uint8, device=self.dev)
+            self._check(self.L.eagle_dev_vara_i8(self.ctx, self.Mt8.data_ptr(), self.Lp, self.np_, self.np_,
+                                                 self.Wu.data_ptr(), self.nslices, self.ws.data_ptr(), self.vara.data_ptr(),
+                                                 None, self._stream()))
+
+    def argmax(self):
+        self._check(self.L.eagle_dev_tsq_argmax(self.ctx, self.a.data_ptr(), self.vara.data_ptr(), self.Lloc, None,
+                                                self._best.data_ptr(), self._scratch.data_ptr(), self._stream()))
+
+    def scan(self):
+        """calculate_a_and_vara_rcpp.cpp:90-112 + find_qtl.R:71-83 on this shard, all on the current stream."""
+        self.scan_operands()
+        self.gemv_a()
+        self.vara_kernel()
+        self.argmax()
+
+    def best(self):
+        """(tsqmax, GLOBAL 0-based index or -1, near ties) of the last scan (synchronises)."""
+        b = self._best.cpu().numpy()
+        tsqmax = float(np.frombuffer(b[:1].tobytes(), dtype=np.float64)[0])
+        idx0 = int(b[1])
+        return tsqmax, (idx0 + self.first if idx0 >= 0 else -1), int(b[2])

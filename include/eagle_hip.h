@@ -1,0 +1,191 @@
+/*
+ * eagle_hip.h -- C ABI of libeaglehip.so, the MI355X (gfx950) backend for the Eagle/WMAM hot path.
+ *
+ * The drop-in boundary of the reference is the .Call table of Eagle.so
+ * (E/src/RcppExports.cpp:154-170, E/ = MyPackage/Eagle/).  The functions of section 1 below are what the
+ * bodies of the reference's exported C++ functions are replaced with; each one cites the interface it
+ * replaces.  The R-side binding (plain R C API, no Rcpp) is shown in INTEGRATION.md and in
+ * eagleeverything_amd/shim/eagle_rshim.c.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; matrices crossing section 1 are COLUMN-major doubles (R / Eigen).
+ *   - every function returns an int status: 0 ok, < 0 hard error (text via eagle_last_error), 1 = the
+ *     reference's "soft" sentinel return (message printed, placeholder value written, see each function).
+ *   - selected_loci is passed as the raw R doubles (NA = NaN).  Masking fires iff element 0 is not NA
+ *     (calculateMMt_rcpp.cpp:88, calculate_a_and_vara_rcpp.cpp:79, calculate_reduced_a_rcpp.cpp:74).
+ *   - caller owns every pointer it passes; nothing is retained past return except the HBM-resident
+ *     genotype cache inside the ctx (keyed by path, size, mtime), freed by eagle_close / eagle_drop_cache.
+ *   - no function throws; none calls back except through the message callback, on the calling thread.
+ *   - there is NO CPU fallback: without a gfx950 device eagle_open fails.
+ */
+#ifndef EAGLE_HIP_H
+#define EAGLE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EAGLE_OK 0
+#define EAGLE_SOFT_SENTINEL 1
+#define EAGLE_ERR_OPEN (-1)    /* ReadBlock.cpp:42-45: "ERROR: Could not open <file>" */
+#define EAGLE_ERR_FORMAT (-2)  /* short file / short line / character outside '0'..'2' */
+#define EAGLE_ERR_ARG (-3)
+#define EAGLE_ERR_NOMEM (-4)
+#define EAGLE_ERR_HIP (-5)
+#define EAGLE_ERR_NODEVICE (-6)
+
+typedef struct eagle_ctx eagle_ctx;
+
+/* Receives what the reference sends through its `message` R closure argument
+ * (calculateMMt_rcpp.cpp:36,107; calculate_a_and_vara_rcpp.cpp:69,124). */
+typedef void (*eagle_message_fn)(const char* text, void* user);
+
+/* ---------------------------------------------------------------------------------------------
+ * 0. Context
+ * ------------------------------------------------------------------------------------------- */
+/* Opens HIP device `device` (must be gfx950).  Returns NULL on failure; the reason is available from
+ * eagle_open_error().  One ctx per device; a process that drives several GPUs opens one ctx each. */
+eagle_ctx* eagle_open(int device);
+const char* eagle_open_error(void);
+void eagle_close(eagle_ctx* ctx);
+const char* eagle_last_error(eagle_ctx* ctx);
+void eagle_set_message_callback(eagle_ctx* ctx, eagle_message_fn fn, void* user);
+/* Drops HBM-resident genotype copies kept between calls. */
+void eagle_drop_cache(eagle_ctx* ctx);
+/* "gfx950", CU count, HBM bytes -- for logs and bench JSON. */
+int eagle_device_info(eagle_ctx* ctx, char* arch_out, int arch_len, int* cu_count, int64_t* hbm_bytes);
+/* vara kernel: 0 = fp64 MFMA (v_mfma_f64_16x16x4_f64), 1 = exact int8 slices of W on v_mfma_i32_32x32x32_i8
+ * with a per-call error certificate; default is chosen by the library. */
+int eagle_set_scan_mode(eagle_ctx* ctx, int mode);
+
+/* ---------------------------------------------------------------------------------------------
+ * 1. Reference-shaped entry points (host pointers, files on disk)
+ * ------------------------------------------------------------------------------------------- */
+
+/* Replaces  Eigen::MatrixXd ReadBlock(std::string asciifname, long start_row, long numcols,
+ *           long numrows_in_block)               E/src/ReadBlock.cpp:16-68, RcppExports.cpp:9-21
+ * out: numrows_in_block x numcols column-major, value (char-'0')-1.  The text tile is decoded on the
+ * device (raw bytes -> HBM -> int8 -> fp64) and copied back. */
+int eagle_read_block(eagle_ctx* ctx, const char* asciifname, long start_row, long numcols,
+                     long numrows_in_block, double* out);
+
+/* Replaces  Eigen::MatrixXd calculateMMt_rcpp(CharacterVector f_name_ascii, double max_memory_in_Gbytes,
+ *           int num_cores, NumericVector selected_loci, std::vector<long> dims, bool quiet,
+ *           Function message)                    E/src/calculateMMt_rcpp.cpp:19-185, RcppExports.cpp:37-52
+ * dims = (n, L) of M.ascii.  MMt_out: n x n column-major.  max_memory_in_Gbytes bounds HOST staging
+ * (the genotype tiles are streamed through pinned memory); num_cores bounds host reader threads. */
+int eagle_calculateMMt(eagle_ctx* ctx, const char* f_name_ascii, double max_memory_in_Gbytes, int num_cores,
+                       const double* selected_loci, long n_selected, const long dims[2], int quiet,
+                       double* MMt_out);
+
+/* Replaces  Rcpp::List calculate_a_and_vara_rcpp(CharacterVector f_name_ascii, NumericVector selected_loci,
+ *           Map<MatrixXd> inv_MMt_sqrt, Map<MatrixXd> dim_reduced_vara, double max_memory_in_Gbytes,
+ *           std::vector<long> dims, VectorXd a, bool quiet, Function message)
+ *                                                E/src/calculate_a_and_vara_rcpp.cpp:22-241, RcppExports.cpp:54-71
+ * dims = (L, n) of Mt.ascii.  inv_MMt_sqrt, dim_reduced_vara: n x n column-major; a: n.
+ * a_out, vara_out: L doubles each (the "a" and "vara" L x 1 matrices of the returned list).
+ * Returns EAGLE_SOFT_SENTINEL with a_out[0] = vara_out[0] = 0 where the reference returns
+ * List(a = 0, vara = 0) (:133-144). */
+int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_ascii, const double* selected_loci,
+                               long n_selected, const double* inv_MMt_sqrt, const double* dim_reduced_vara,
+                               double max_memory_in_Gbytes, const long dims[2], const double* a, int quiet,
+                               double* a_out, double* vara_out);
+
+/* Replaces  Eigen::MatrixXd calculate_reduced_a_rcpp(CharacterVector f_name_ascii, double varG,
+ *           Map<MatrixXd> P, Map<MatrixXd> y, double max_memory_in_Gbytes, std::vector<long> dims,
+ *           NumericVector selected_loci, bool quiet, Function message)
+ *                                                E/src/calculate_reduced_a_rcpp.cpp:20-171, RcppExports.cpp:73-90
+ * dims = (n, L) of M; the file is Mt.ascii.  ar_out: L doubles.  Returns EAGLE_SOFT_SENTINEL with
+ * ar_out[0] = 0 where the reference returns its 1 x 1 zero matrix (:94-103). */
+int eagle_calculate_reduced_a(eagle_ctx* ctx, const char* f_name_ascii, double varG, const double* P,
+                              const double* y, double max_memory_in_Gbytes, const long dims[2],
+                              const double* selected_loci, long n_selected, int quiet, double* ar_out);
+
+/* Replaces the R tail of .find_qtl:  tsq <- a^2/vara ; which(tsq == max(tsq, na.rm=TRUE))[1]
+ *                                                E/R/find_qtl.R:71-83
+ * Evaluated on the device on the a / vara of the LAST eagle_calculate_a_and_vara call of this ctx (still in
+ * HBM).  index_out is 1-based (0 if every tsq is NaN); n_near_ties counts markers whose tsq is within a
+ * relative 1e-9 of the maximum (1 = unambiguous). */
+int eagle_last_scan_argmax(eagle_ctx* ctx, long* index_out, double* tsqmax_out, long* n_near_ties);
+
+/* MMt/max(MMt) + 0.95 I  (E/R/calcMMt.R:13) of the LAST eagle_calculateMMt result, on the device. */
+int eagle_last_mmt_normalised(eagle_ctx* ctx, double* MMt_norm_out, double* max_out);
+
+/* ---------------------------------------------------------------------------------------------
+ * 2. Device-resident entry points (all pointers are HBM addresses on ctx's device; `stream` is a
+ *    hipStream_t passed as void*, NULL = default stream).  Used by the marker-sharded multi-GPU driver
+ *    and by bench.py, which keep genotype shards resident in HBM between calls.
+ *
+ *    Layout contract for genotype matrices (int8, values {-1,0,1}):
+ *      Mt8: marker-major  [L_pad][ld]  ld >= n, ld % 128 == 0, L_pad % 128 == 0, padding bytes ZERO
+ *      M8 : individual-major [n_pad][ld] ld >= L, ld % 128 == 0, n_pad % 128 == 0, padding bytes ZERO
+ *    fp64 square operands: row-major [np][np], np = eagle_pad128(n), padding ZERO.
+ * ------------------------------------------------------------------------------------------- */
+long eagle_pad128(long x);
+
+/* Lines [row0,row0+nrows) x characters [col0,col0+ncols) of a no-space ASCII genotype file (M.ascii / Mt.ascii,
+ * as ReadBlock reads them, E/src/ReadBlock.cpp:47-58) -> int8 at dst[r*ld + c] in HBM.  Fixed-width files are
+ * pread() into pinned memory by `threads` workers, double-buffered against the H2D copy and the decode kernel;
+ * max_mem_gb bounds the pinned staging.  A marker shard is a row range of Mt.ascii or a column window of M.ascii. */
+int eagle_dev_load_ascii(eagle_ctx* ctx, const char* path, long row0, long nrows, long col0, long ncols, int8_t* dst,
+                         long ld, double max_mem_gb, int threads);
+
+/* raw text tile (rows of `line_stride` bytes, first `cols` bytes used) -> int8 (value char-'0'-1);
+ * *bad_chars_dev (device int, caller-zeroed) counts bytes outside '0'..'2'. */
+int eagle_dev_decode_ascii(eagle_ctx* ctx, const uint8_t* raw, long rows, long cols, long line_stride,
+                           int8_t* out, long ld_out, int* bad_chars_dev, void* stream);
+int eagle_dev_transpose_i8(eagle_ctx* ctx, const int8_t* in, long rows, long cols, long ld_in, int8_t* out,
+                           long ld_out, void* stream);
+int eagle_dev_i8_to_f64_colmajor(eagle_ctx* ctx, const int8_t* in, long rows, long cols, long ld_in,
+                                 double* out_colmajor, void* stream);
+
+/* C32[np][np] (int32, row-major, caller-zeroed) += M8 * M8^T over the marker columns [0, L_pad).
+ * Upper-triangular tiles only; exact integers, order independent (integer atomics). */
+int eagle_dev_mmt_accumulate(eagle_ctx* ctx, const int8_t* M8, long n_pad, long L_pad, long ld, int32_t* C32,
+                             void* stream);
+/* C32 -= sum over the listed marker columns of m_c m_c^T  (the selected_loci masking of
+ * calculateMMt_rcpp.cpp:88-92 applied as an exact rank-k downdate). cols_dev: device array of long. */
+int eagle_dev_mmt_downdate(eagle_ctx* ctx, const int8_t* M8, long n_pad, long ld, const long* cols_dev,
+                           long ncols, int32_t* C32, void* stream);
+/* Mirror the upper triangle, convert to fp64 (n x n, leading dimension ld_out, symmetric so layout-free),
+ * and write max(MMt) to *max_dev (device double). */
+int eagle_dev_mmt_finish(eagle_ctx* ctx, const int32_t* C32, long n, long n_pad, double* MMt, long ld_out,
+                         double* max_dev, void* stream);
+int eagle_dev_mmt_normalise(eagle_ctx* ctx, double* MMt, long n, long ld, const double* max_dev, void* stream);
+
+/* Scan operands from the reference's arguments (n_pad x n_pad row-major images of the COLUMN-major
+ * inputs, i.e. Sa = S^T, Va = V^T):  v = S a_hat ; Wu = upper-triangular fold of W = S (V S) with
+ * Wu[j][k] = W[j][k] + W[k][j] (j<k), W[k][k] (j=k), 0 (j>k), so that m^T W m = sum_k m_k sum_{j<=k} m_j Wu[j][k].
+ * tmp: n_pad*n_pad doubles of scratch. */
+int eagle_dev_scan_operands(eagle_ctx* ctx, const double* Sa, const double* Va, const double* ahat, long n,
+                            long n_pad, double* v_out, double* Wu_out, double* tmp, void* stream);
+/* a_i = sum_j Mt8[i][j] v[j]  (scale * ...) for L_pad rows: calculate_a_and_vara_rcpp.cpp:91,
+ * calculate_reduced_a_rcpp.cpp:83-84. */
+int eagle_dev_gemv_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* v,
+                      double scale, double* out, void* stream);
+/* vara_i = m_i^T W m_i for L_pad rows (calculate_a_and_vara_rcpp.cpp:103-112), fp64 MFMA kernel. */
+int eagle_dev_vara_f64(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu,
+                       double* vara_out, void* stream);
+/* Same result from int8 slices of Wu on the int8 MFMA (exact integer partial sums).
+ * ws: workspace, eagle_vara_i8_workspace_bytes(n_pad, L_pad, nslices) bytes.
+ * err_bound_dev (device double, may be NULL): certified absolute error bound of every vara_i. */
+int64_t eagle_vara_i8_workspace_bytes(long n_pad, long L_pad, int nslices);
+int eagle_dev_vara_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu,
+                      int nslices, void* ws, double* vara_out, double* err_bound_dev, void* stream);
+/* zero a[i], vara[i] at the listed rows (row masking of calculate_a_and_vara_rcpp.cpp:79-84: a zeroed
+ * marker row yields exactly a = 0, vara = 0). rows_dev: device array of long, entries outside [0,L) ignored. */
+int eagle_dev_zero_rows(eagle_ctx* ctx, double* a, double* vara, long L, const long* rows_dev, long nrows,
+                        long row_offset, void* stream);
+/* tsq = a^2/vara, first index of the maximum ignoring NaN (find_qtl.R:71-83).
+ * best_dev: device struct {double tsqmax; long index0; long near_ties;} index0 = -1 if all NaN.
+ * tsq_out may be NULL. block_scratch: 3*1024 doubles. */
+typedef struct { double tsqmax; long index0; long near_ties; } eagle_best;
+int eagle_dev_tsq_argmax(eagle_ctx* ctx, const double* a, const double* vara, long L, double* tsq_out,
+                         eagle_best* best_dev, double* block_scratch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EAGLE_HIP_H */

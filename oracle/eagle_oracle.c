@@ -533,3 +533,9 @@ int eo_num_threads(void) {
     return 1;
 #endif
 }
+
+void eo_set_num_threads(int t) {
+#ifdef _OPENMP
+    if (t > 0) omp_set_num_threads(t);
+#endif
+}

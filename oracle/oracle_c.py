@@ -45,6 +45,8 @@ def lib():
         L.eo_tsq_argmax.argtypes = [c_dp, c_dp, C.c_long, c_dp, c_dp]
         L.eo_tsq_argmax.restype = C.c_long
         L.eo_num_threads.restype = C.c_int
+        L.eo_set_num_threads.argtypes = [C.c_int]
+        L.eo_set_num_threads.restype = None
         _lib = L
     return _lib
 
@@ -183,3 +185,7 @@ def scan_from_i8_with_W(Mt8, v, W_rm):
 
 def num_threads():
     return int(lib().eo_num_threads())
+
+
+def set_num_threads(t):
+    lib().eo_set_num_threads(int(t))

@@ -1,0 +1,235 @@
+"""GPU parity tests: every call goes through the C ABI of libeaglehip.so (rcpp_api mirrors the reference's
+exported functions) and is compared with the CPU oracle / the golden vectors on the same inputs.
+
+Bars:  MM^T and ReadBlock bit-exact (integer data) ; a, vara, tsq within 1e-9 relative (north_star allows
+1e-6; the fp64 kernels only differ from the oracle in summation order) ; selected index identical.
+parity unpinned for fp64 outputs (the reference records none; see oracle/eagle_oracle.c).
+"""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_CASES
+from eagleeverything_amd import synth
+
+pytestmark = pytest.mark.gpu
+NA = np.nan
+RTOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def api():
+    from eagleeverything_amd import rcpp_api
+    info = rcpp_api.device_info()
+    assert info["arch"].startswith("gfx950")
+    yield rcpp_api
+    rcpp_api.close_all()
+
+
+@pytest.fixture(scope="module")
+def files(tmp_path_factory, golden):
+    out = {}
+    for case in GOLDEN_CASES:
+        g = golden(case)
+        d = tmp_path_factory.mktemp(case)
+        out[case] = (g, synth.write_geno_pair(str(d), np.ascontiguousarray(g["M8"].T)))
+    return out
+
+
+def _close(x, ref, rtol=RTOL, scale=None):
+    x = np.ravel(x); ref = np.ravel(ref)
+    s = np.abs(ref).max() if scale is None else scale
+    np.testing.assert_allclose(x, ref, rtol=rtol, atol=1e-12 * s)
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_readblock_bit_exact(case, files, api, oracle):
+    g, geno = files[case]
+    n, L = g["M8"].shape
+    M = api.ReadBlock(geno["asciifileM"], 0, L, n)
+    assert M.shape == (n, L) and M.flags.f_contiguous
+    np.testing.assert_array_equal(M, g["M8"].astype(np.float64))
+    for (start, cols, rows) in [(7, n - 5, 11), (0, 1, 1), (L - 3, n, 3), (5, min(64, n), min(128, L - 5))]:
+        blk = api.ReadBlock(geno["asciifileMt"], start, cols, rows)
+        np.testing.assert_array_equal(blk, oracle.ReadBlock(geno["asciifileMt"], start, cols, rows))
+
+
+def test_readblock_errors(api, tmp_path):
+    from eagleeverything_amd._lib import EagleError
+    with pytest.raises(EagleError, match="Could not open"):
+        api.ReadBlock(str(tmp_path / "missing.ascii"), 0, 3, 3)
+    p = synth.write_ascii(str(tmp_path / "s.ascii"), np.zeros((4, 6), np.int8))
+    with pytest.raises(EagleError):
+        api.ReadBlock(p, 2, 6, 5)
+    with pytest.raises(EagleError):
+        api.ReadBlock(p, 0, 9, 2)
+    assert api.ReadBlock(p, 1, 0, 0).shape == (0, 0)
+    # a file that is not fixed-width is still read line by line (ReadBlock uses getline)
+    q = tmp_path / "ragged.ascii"
+    q.write_text("0120\n21012\n000\n")
+    np.testing.assert_array_equal(api.ReadBlock(str(q), 0, 3, 3), np.array([[-1, 0, 1], [1, 0, -1], [-1, -1, -1.0]]))
+    # characters outside '0'..'2' are rejected (the reference would silently produce other integers)
+    r = tmp_path / "bad.ascii"
+    r.write_text("01a\n012\n")
+    with pytest.raises(EagleError, match="outside"):
+        api.ReadBlock(str(r), 0, 3, 2)
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_mmt_bit_exact_and_masking_rule(case, files, api):
+    g, geno = files[case]
+    n, L = g["M8"].shape
+    msgs = []
+    mmt = api.calculateMMt_rcpp(geno["asciifileM"], 8.0, 2, NA, (n, L), quiet=False, message=msgs.append)
+    assert mmt.shape == (n, n)
+    np.testing.assert_array_equal(mmt, g["MMt"].astype(np.float64))
+    assert any("Number of cores" in m for m in msgs)
+    # tiny availmemGb: the reference would take its row-block branch; results are identical
+    need = (n * n * 8 + 2 * n * L * 8) / 1e9
+    np.testing.assert_array_equal(api.calculateMMt_rcpp(geno["asciifileM"], need / 6, 2, NA, (n, L)), mmt)
+    # masking fires iff element 0 is not NA
+    np.testing.assert_array_equal(api.calculateMMt_rcpp(geno["asciifileM"], 8.0, 1, g["sel_masked"], (n, L)),
+                                  g["MMt_masked"].astype(np.float64))
+    np.testing.assert_array_equal(api.calculateMMt_rcpp(geno["asciifileM"], 8.0, 1, np.array([NA, 3.0, 17.0]), (n, L)), mmt)
+    dup = np.concatenate([g["sel_masked"], g["sel_masked"][:1]])  # zeroing a column twice = once
+    np.testing.assert_array_equal(api.calculateMMt_rcpp(geno["asciifileM"], 8.0, 1, dup, (n, L)),
+                                  g["MMt_masked"].astype(np.float64))
+    # calcMMt.R:13 on the device
+    from eagleeverything_amd import r_api
+    norm = r_api.calcMMt(geno, 8.0, 2, NA, True)
+    exp = g["MMt"] / g["MMt"].max() + 0.95 * np.eye(n)
+    np.testing.assert_allclose(norm, exp, rtol=0, atol=2e-16)
+
+
+@pytest.mark.parametrize("mode", [0])
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_scan_matches_oracle(case, mode, files, api, oracle):
+    g, geno = files[case]
+    n, L = g["M8"].shape
+    api.set_scan_mode(mode)
+    ref = oracle.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, g["S"], g["V"], 8.0, (L, n), g["ahat"])
+    res = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, g["S"], g["V"], 8.0, (L, n), g["ahat"])
+    assert res["a"].shape == (L, 1) and res["vara"].shape == (L, 1)
+    _close(res["a"], ref["a"])
+    # markers that are constant over individuals have vara == 0 up to rounding noise (X holds the intercept):
+    # an absolute floor of 1e-12 * max|vara| keeps those out of the relative comparison
+    vs = np.abs(ref["vara"]).max()
+    np.testing.assert_allclose(res["vara"].ravel(), ref["vara"].ravel(), rtol=RTOL, atol=1e-12 * vs)
+    np.testing.assert_allclose(res["vara"].ravel(), g["vara"], rtol=RTOL, atol=1e-12 * vs)  # golden (numpy restatement)
+    tsq_ref, idx_ref, mx_ref = oracle.tsq_argmax(ref["a"], ref["vara"])
+    idx, mx, near = api.last_scan_argmax()
+    assert idx == idx_ref == int(g["argmax"])
+    np.testing.assert_allclose(mx, mx_ref, rtol=1e-8)
+    # identical marker columns (perfect LD) tie exactly; the first one is selected (find_qtl.R:80)
+    assert near == int(np.sum(tsq_ref >= mx_ref * (1 - 1e-9)))
+    # masked rows: a = vara = 0 there, tsq NaN there and ignored by the arg-max
+    resm = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], g["sel_masked"], g["S"], g["V"], 8.0, (L, n), g["ahat"])
+    np.testing.assert_allclose(resm["vara"].ravel(), g["vara_masked"], rtol=RTOL, atol=1e-12 * vs)
+    for s in g["sel_masked"].astype(int):
+        assert resm["a"][s, 0] == 0.0 and resm["vara"][s, 0] == 0.0
+    idx, _, _ = api.last_scan_argmax()
+    assert idx == int(g["argmax_masked"])
+    api.set_scan_mode(0)
+
+
+def test_scan_branch_rules_and_sentinels(files, api):
+    from eagleeverything_amd._lib import EagleError
+    g, geno = files["synth_203x1531"]
+    n, L = g["M8"].shape
+    with pytest.raises(EagleError, match="zero rows"):
+        api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, g["S"], g["V"], 0.0, (L, n), g["ahat"])
+    neg = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, g["S"], g["V"], -1.0, (L, n), g["ahat"])
+    assert neg["a"].shape == (1,) and neg["a"][0] == 0 and neg["vara"][0] == 0
+    with pytest.raises(EagleError, match="Could not open"):
+        api.calculate_a_and_vara_rcpp(geno["asciifileMt"] + ".nope", NA, g["S"], g["V"], 8.0, (L, n), g["ahat"])
+    with pytest.raises(EagleError):
+        api.calculate_a_and_vara_rcpp(geno["asciifileMt"], np.array([5.0, NA]), g["S"], g["V"], 8.0, (L, n), g["ahat"])
+
+
+def test_reduced_a(files, api, oracle):
+    g, geno = files["synth_203x1531"]
+    n, L = g["M8"].shape
+    ref = oracle.calculate_reduced_a_rcpp(geno["asciifileMt"], float(g["varG"]), g["P"], g["y"], 8.0, (n, L), NA)
+    ar = api.calculate_reduced_a_rcpp(geno["asciifileMt"], float(g["varG"]), g["P"], g["y"], 8.0, (n, L), NA)
+    assert ar.shape == (L, 1)
+    _close(ar, ref)
+    z = api.calculate_reduced_a_rcpp(geno["asciifileMt"], float(g["varG"]), g["P"], g["y"], 0.0, (n, L), NA)
+    assert z.shape == (1, 1) and z[0, 0] == 0.0
+    arm = api.calculate_reduced_a_rcpp(geno["asciifileMt"], float(g["varG"]), g["P"], g["y"], 8.0, (n, L), np.array([5.0, 9.0]))
+    assert arm[5, 0] == 0.0 and arm[9, 0] == 0.0
+    _close(np.delete(arm.ravel(), [5, 9]), np.delete(ref.ravel(), [5, 9]), scale=np.abs(ref).max())
+
+
+def test_find_qtl_mirror_selects_same_marker(files, api, oracle):
+    from eagleeverything_amd import host_model, r_api
+    g, geno = files["genoDemo_150x4998"]
+    n, L = g["M8"].shape
+    MMt = r_api.calcMMt(geno, 8.0, 2, NA, True)
+    invMMt = np.linalg.inv(MMt)
+    sel = np.array([NA])  # AM.R:260: selected_loci starts as NA, so masking never fires
+    idx, st = r_api.find_qtl(geno, 8.0, sel, MMt, invMMt, float(g["varE"]), float(g["varG"]), g["X"], 2, True, g["y"],
+                             return_stats=True)
+    assert idx == int(g["argmax"])
+    np.testing.assert_allclose(st["tsqmax"], float(g["tsqmax"]), rtol=1e-7)
+
+
+# ---- larger seeded case, ragged sizes, cache reuse, cross-check by properties ---------------------------
+@pytest.fixture(scope="module")
+def big(tmp_path_factory):
+    n, L = 1003, 20011
+    Mt8 = synth.genotypes_marker_major(n, L, seed=5)
+    d = tmp_path_factory.mktemp("big")
+    geno = synth.write_geno_pair(str(d), Mt8)
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((n, n)) / np.sqrt(n)
+    S = A @ A.T + np.eye(n)            # SPD like MMt^-1/2
+    Bm = rng.standard_normal((n, 8))
+    V = 0.7 * np.eye(n) - 0.01 * (Bm @ Bm.T)
+    ahat = rng.standard_normal(n)
+    return Mt8, geno, S, V, ahat
+
+
+def test_big_mmt_exact(big, api):
+    Mt8, geno, *_ = big
+    L, n = Mt8.shape
+    mmt = api.calculateMMt_rcpp(geno["asciifileM"], 8.0, 4, NA, (n, L))
+    G = Mt8.astype(np.float64)
+    np.testing.assert_array_equal(mmt, G.T @ G)
+    assert np.array_equal(mmt, mmt.T)
+
+
+def test_big_scan(big, api, oracle):
+    Mt8, geno, S, V, ahat = big
+    L, n = Mt8.shape
+    res = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat)
+    a_ref, v_ref = oracle.scan_from_i8(Mt8, S, V, ahat)
+    _close(res["a"], a_ref)
+    np.testing.assert_allclose(res["vara"].ravel(), v_ref, rtol=RTOL)
+    # second call hits the HBM-resident tile and is bit-identical (deterministic reduction order)
+    res2 = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat)
+    np.testing.assert_array_equal(res["a"], res2["a"])
+    np.testing.assert_array_equal(res["vara"], res2["vara"])
+    # linearity of a in a_hat, quadratic scaling of vara in S
+    res3 = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, 2.0 * S, V, 8.0, (L, n), ahat)
+    np.testing.assert_allclose(res3["a"], 2.0 * res["a"], rtol=1e-12)
+    np.testing.assert_allclose(res3["vara"], 4.0 * res["vara"], rtol=1e-12)
+    idx, mx, near = api.last_scan_argmax()
+    tsq, idx_ref, mx_ref = oracle.tsq_argmax(a_ref * 2, v_ref * 4)
+    assert idx == idx_ref
+
+
+def test_dev_gemm_f64_layout(api):
+    """The fp64 MFMA fragment maps, checked with asymmetric integer-valued data (exact in fp64)."""
+    import torch
+    from eagleeverything_amd import _lib
+    L = _lib.load()
+    ctx = api.context(0)
+    n = 256
+    rng = np.random.default_rng(0)
+    A = rng.integers(-8, 9, size=(n, n)).astype(np.float64)
+    B = rng.integers(-8, 9, size=(n, n)).astype(np.float64)
+    dA = torch.from_numpy(A).cuda(); dB = torch.from_numpy(B).cuda(); dC = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    rc = L.eagle_dev_gemm_f64(ctx, dA.data_ptr(), dB.data_ptr(), dC.data_ptr(), n, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(dC.cpu().numpy(), A @ B)
