@@ -36,7 +36,7 @@ SIGNATURES = {
                                             C.c_long, C.c_int, c_dp]),
     "eagle_last_scan_argmax": (C.c_int, [C.c_void_p, c_lp, c_dp, c_lp]),
     "eagle_last_mmt_normalised": (C.c_int, [C.c_void_p, c_dp, c_dp]),
-    "eagle_pad128": (C.c_long, [C.c_long]),
+    "eagle_pad": (C.c_long, [C.c_long]),
     "eagle_dev_load_ascii": (C.c_int, [C.c_void_p, C.c_char_p, C.c_long, C.c_long, C.c_long, C.c_long, C.c_void_p,
                                        C.c_long, C.c_double, C.c_int]),
     "eagle_dev_decode_ascii": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_long,

@@ -422,7 +422,7 @@ static int get_resident(eagle_ctx* ctx, const char* path, long rows, long cols, 
         if (ctx->cache[i].path == path) { (void)hipFree(ctx->cache[i].dev); ctx->cache.erase(ctx->cache.begin() + i); } else i++;
     GenoEntry g;
     g.path = path; g.size = st.st_size; g.mtime_ns = mt; g.rows = rows; g.cols = cols;
-    g.rows_pad = eagle_pad128(rows); g.ld = eagle_pad128(cols);
+    g.rows_pad = eagle_pad(rows); g.ld = eagle_pad(cols);
     size_t bytes = (size_t)g.rows_pad * (size_t)g.ld;
     size_t freeb = 0, totalb = 0;
     HIPCHK(ctx, hipMemGetInfo(&freeb, &totalb));
@@ -465,7 +465,7 @@ extern "C" int eagle_read_block(eagle_ctx* ctx, const char* asciifname, long sta
         FileInfo fi;
         return open_file(ctx, asciifname, fi);
     }
-    const long ld = eagle_pad128(numcols);
+    const long ld = eagle_pad(numcols);
     DevBuf tile, dbl;
     HIPCHK(ctx, tile.alloc((size_t)numrows * ld));
     HIPCHK(ctx, dbl.alloc(sizeof(double) * (size_t)numrows * numcols));
@@ -598,7 +598,7 @@ extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_asc
     rc = eagle_dev_gemv_i8(ctx, g->dev, Lp, np, g->ld, v.as<double>(), 1.0, ctx->d_a, ctx->stream);
     if (rc) return rc;
     if (ctx->scan_mode == 1) {
-        const int nslices = 8;
+        const int nslices = 7;  // 7 x 8 bits: the whole fp64 mantissa of max|W|
         HIPCHK(ctx, ws.alloc((size_t)eagle_vara_i8_workspace_bytes(np, Lp, nslices)));
         rc = eagle_dev_vara_i8(ctx, g->dev, Lp, np, g->ld, Wu.as<double>(), nslices, ws.p, ctx->d_vara, nullptr, ctx->stream);
     } else {

@@ -1,0 +1,400 @@
+// eagle_i8mfma.hip -- the int8 MFMA tile engine (v_mfma_i32_32x32x32_i8) and the two kernels built on it.
+//
+//   k_syrk_i8  : MM^T partial sums, C32 += M8 * M8^T                        (E/src/calculateMMt_rcpp.cpp:95)
+//   k_vara_i8  : vara_i = m_i^T W m_i from exact int8 digit slices of W     (E/src/calculate_a_and_vara_rcpp.cpp:97-112)
+//
+// Tile engine.  Workgroup = 512 threads = 8 waves arranged 2 (M) x 4 (N); block tile 256 x 256; wave tile
+// 128 x 64 = 4 x 2 MFMA tiles of 32 x 32 (128 accumulator registers); K step 128 bytes.  Both operands are
+// "row-major, K contiguous" int8 (NT product C[i][j] = sum_k A[i][k] B[j][k]).  Operand tiles (256 rows x 128 B
+// = 32 KiB each) go global -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB = 8 rows per wave-instruction, no
+// VGPR staging, no ds_write), double buffered (2 x 64 KiB), the loads of stage t+1 in flight under the 32 MFMAs
+// per wave of stage t.  LDS rows are 128 B; the 16-byte chunk index is XOR-swizzled with (row>>1)&7, applied to
+// the per-lane SOURCE address of the DMA (its LDS destination is lane-linear) and to the ds_read_b128 address,
+// which makes the 32-row fragment reads bank-conflict free.
+// A and B fragments use the same (lane>>5, byte) -> k map, so the k order inside the instruction is immaterial
+// for an exact integer sum.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/eagle_hip.h"
+#include "eagle_internal.h"
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+#define T8 256          /* block tile (rows of A, rows of B) */
+#define BK8 128         /* K bytes per stage */
+#define TILE_BYTES (T8 * BK8)
+
+// Per-lane constants of the tile engine.
+//  DMA source: group g = 4w+i covers rows 8g .. 8g+7; lane l writes LDS bytes [1024 g + 16 l, +16) = row 8g + (l>>3),
+//  physical chunk l&7, which must hold logical chunk (l&7) ^ ((row>>1)&7) = (l&7) ^ ((l>>4) + 4(i&1)).  So the per-lane
+//  byte offset is voffE for even i and voffE ^ 64 for odd i (ld % 128 == 0), everything else is wave-uniform and goes
+//  into the scalar offset of a buffer_load ... lds.
+//  Fragment read: lane (r = l&31, h = l>>5) reads logical chunk 2ks+h of row R+r at physical chunk (2ks+h) ^ ((r>>1)&7).
+struct T8Lane {
+    int voffE, voffO;  // DMA source offsets (bytes) for even / odd row groups
+};
+__device__ __forceinline__ T8Lane t8_lane(int lane, int ld) {
+    T8Lane x;
+    x.voffE = (lane >> 3) * ld + (((lane & 7) ^ (lane >> 4)) << 4);
+    x.voffO = x.voffE ^ 64;
+    return x;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t t8_rsrc(const int8_t* base, int ld) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, T8 * ld, 0x00020000);
+}
+// One operand tile (256 rows x 128 B at byte column k0): 32 groups of 8 rows; wave w issues groups 4w .. 4w+3.
+__device__ __forceinline__ void t8_stage(__amdgpu_buffer_rsrc_t rs, const T8Lane& ln, int ld, int k0, int8_t* ldsTile, int w) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int grp = w * 4 + i;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(ldsTile + grp * 1024), 16,
+                                                 (i & 1) ? ln.voffO : ln.voffE, grp * 8 * ld + k0, 0, 0);
+    }
+}
+
+struct T8Frag {
+    i32x4 a[4], b[2];
+};
+__device__ __forceinline__ void t8_frag_load(T8Frag& f, const int8_t* pa, const int8_t* pb, int ch) {
+#pragma unroll
+    for (int m = 0; m < 4; m++) f.a[m] = *(const i32x4*)(pa + m * (32 * BK8) + ch);
+#pragma unroll
+    for (int n = 0; n < 2; n++) f.b[n] = *(const i32x4*)(pb + n * (32 * BK8) + ch);
+}
+__device__ __forceinline__ void t8_frag_mma(i32x16 (&acc)[4][2], const T8Frag& f) {
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++) acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[m], f.b[n], acc[m][n], 0, 0, 0);
+}
+// 4 k-steps of 32 bytes; the fragments of step ks+1 are read from LDS while the 8 MFMAs of step ks run.
+__device__ __forceinline__ void t8_compute(i32x16 (&acc)[4][2], const int8_t* ldsA, const int8_t* ldsB, int wr, int wc,
+                                           int lane) {
+    const int r = lane & 31, h = lane >> 5, swz = (r >> 1) & 7;
+    const int8_t* pa = ldsA + wr * (128 * BK8) + r * BK8;
+    const int8_t* pb = ldsB + wc * (64 * BK8) + r * BK8;
+    T8Frag f0, f1;
+    t8_frag_load(f0, pa, pb, ((0 + h) ^ swz) << 4);
+    t8_frag_load(f1, pa, pb, ((2 + h) ^ swz) << 4);
+    t8_frag_mma(acc, f0);
+    t8_frag_load(f0, pa, pb, ((4 + h) ^ swz) << 4);
+    t8_frag_mma(acc, f1);
+    t8_frag_load(f1, pa, pb, ((6 + h) ^ swz) << 4);
+    t8_frag_mma(acc, f0);
+    t8_frag_mma(acc, f1);
+}
+
+__device__ __forceinline__ void t8_zero(i32x16 (&acc)[4][2]) {
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[m][n][q] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MM^T: grid.x = upper-triangular 256-tile pairs, grid.y = K splits.  Integer atomics: exact, any order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void k_syrk_i8(const int8_t* __restrict__ M8, long ld, int ntile, long nstages,
+                                                    long stages_per_split, int32_t* __restrict__ C, long ldc) {
+    __shared__ __attribute__((aligned(1024))) int8_t lds[2][2][TILE_BYTES];
+    int ti = 0, rem = blockIdx.x;
+    while (rem >= ntile - ti) { rem -= ntile - ti; ti++; }
+    const int tj = ti + rem;
+    const long s0 = (long)blockIdx.y * stages_per_split;
+    long s1 = s0 + stages_per_split;
+    if (s1 > nstages) s1 = nstages;
+    if (s0 >= s1) return;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = w >> 2, wc = w & 3;
+    const int ldi = (int)ld;
+    const T8Lane ln = t8_lane(lane, ldi);
+    const __amdgpu_buffer_rsrc_t rsA = t8_rsrc(M8 + (long)ti * T8 * ld, ldi);
+    const __amdgpu_buffer_rsrc_t rsB = t8_rsrc(M8 + (long)tj * T8 * ld, ldi);
+    i32x16 acc[4][2];
+    t8_zero(acc);
+    t8_stage(rsA, ln, ldi, (int)(s0 * BK8), lds[0][0], w);
+    t8_stage(rsB, ln, ldi, (int)(s0 * BK8), lds[0][1], w);
+    __syncthreads();
+    int cur = 0;
+    for (long s = s0; s < s1; s++) {
+        if (s + 1 < s1) {
+            t8_stage(rsA, ln, ldi, (int)((s + 1) * BK8), lds[cur ^ 1][0], w);
+            t8_stage(rsB, ln, ldi, (int)((s + 1) * BK8), lds[cur ^ 1][1], w);
+        }
+        t8_compute(acc, lds[cur][0], lds[cur][1], wr, wc, lane);
+        __syncthreads();
+        cur ^= 1;
+    }
+    // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const int col = lane & 31, rq = 4 * (lane >> 5);
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                long i = (long)ti * T8 + wr * 128 + m * 32 + (q & 3) + 8 * (q >> 2) + rq;
+                long j = (long)tj * T8 + wc * 64 + n * 32 + col;
+                int v = acc[m][n][q];
+                if (v) atomicAdd(&C[i * ldc + j], v);
+            }
+}
+
+extern "C" int eagle_dev_mmt_accumulate(eagle_ctx* ctx, const int8_t* M8, long n_pad, long L_pad, long ld, int32_t* C32,
+                                        void* stream) {
+    if (n_pad % T8 || L_pad % BK8 || ld % 128 || L_pad > ld || n_pad <= 0 || (double)ld * T8 >= 2147483648.0)
+        return eagle_fail(ctx, EAGLE_ERR_ARG, "mmt_accumulate: layout contract violated (n_pad % 256, L_pad % 128, ld % 128, ld < 2^23)");
+    if (L_pad == 0) return EAGLE_OK;
+    const int nt = (int)(n_pad / T8);
+    const long npairs = (long)nt * (nt + 1) / 2;
+    const long nstages = L_pad / BK8;
+    // one workgroup per CU (128 KiB LDS): aim at ~10 waves of 256 workgroups, K runs of at least 16 stages
+    long want = (10L * 256 + npairs - 1) / npairs;
+    long maxsplit = nstages / 16 > 0 ? nstages / 16 : 1;
+    long nsplit = want < maxsplit ? want : maxsplit;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > 65535) nsplit = 65535;
+    long per = (nstages + nsplit - 1) / nsplit;
+    nsplit = (nstages + per - 1) / per;
+    dim3 grid((unsigned)npairs, (unsigned)nsplit);
+    hipLaunchKernelGGL(k_syrk_i8, grid, dim3(512), 0, (hipStream_t)stream, M8, ld, nt, nstages, per, C32, n_pad);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "k_syrk_i8");
+    return EAGLE_OK;
+}
+
+// ================================================================================================
+// vara from int8 digit slices of Wu.
+//
+//   Wu (upper triangular fold of W, fp64) = 2^(e+2) * sum_{s<S} D_s * 256^-(s+1)  +  R,   |R_jk| <= 2^(e+1-8S)
+//   with max|Wu| < 2^e, D_0 in [-65,65], D_s in [-128,127]: the balanced base-256 digits of the exact integer
+//   round(Wu * 2^(8S-e-2)) (below 2^(8S-2) <= 2^62, so int64 arithmetic; a balanced digit set needs 257 values per
+//   level when produced most-significant first, so the digits are peeled least-significant first with a carry).
+//   q_s[i] = sum_k m_ik sum_{j<=k} m_ij D_s[j][k]   is an exact integer (int32 MFMA sums, int64 across tiles), so
+//   vara_i = 2^(e+2) * sum_s 256^-(s+1) q_s[i]  carries only the truncation R: |error| <= (sum_j |m_ij|)^2 * 2^(e+1-8S),
+//   and the final S-term fp64 sum (smallest term first).  S = 7 covers the whole 53-bit mantissa of the largest
+//   element of W.  Nothing depends on the order in which tiles finish: bitwise reproducible.
+//
+// Slices are stored transposed, Bs[s][k][j] = D_s[j][k] (row = output column k, K = j contiguous), so the scan is the
+// NT product  T_s[i][k] = sum_j Mt8[i][j] * Bs[s][k][j]  with k-tile ct needing only j < (ct+1)*256 (lower
+// triangular image).  The row-dot with m_ik is fused into the tile epilogue.
+//
+// Work decomposition.  Job = (slice s, column-tile pair {p, nct-1-p}): every job runs (nct+1)*2 stages, so jobs are
+// equal.  A marker tile (256 markers) is served by W workgroups ("workers") that take jobs round-robin; their
+// integer partial row-dots meet in q[s][i] by int64 atomics.  Workgroup b runs on XCD b%8 (observed dealing); the
+// 32 concurrently resident workgroups of an XCD are laid out as 32/W consecutive marker tiles x W workers, so the
+// workers of one marker tile share its genotype panel in that XCD's L2 and equal-numbered workers of neighbouring
+// marker tiles stream the same W-slice tiles in lock-step (a placement guess that only affects speed).
+// ================================================================================================
+#define VW 4 /* workers per marker tile */
+
+__global__ __launch_bounds__(256) void k_absmax(const double* __restrict__ x, long n, unsigned long long* __restrict__ bits) {
+    double m = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        double v = fabs(x[i]);
+        m = v > m ? v : m;  // NaN never wins
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { double y = __shfl_down(m, o); m = y > m ? y : m; }
+    if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(bits, (unsigned long long)__double_as_longlong(m));
+}
+
+// Bs[s][k][j] = digit s of Wu[j][k].  32x32 tiles through LDS so both sides are coalesced.
+__global__ __launch_bounds__(256) void k_slice_w(const double* __restrict__ Wu, long np, const double* __restrict__ maxabs,
+                                                 int nslices, int8_t* __restrict__ Bs) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long bj = (long)blockIdx.y * 32, bk = (long)blockIdx.x * 32;
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = Wu[(bj + r) * np + bk + tx];  // tile[jj][kk]
+    __syncthreads();
+    int e = 0;
+    const double mx = *maxabs;
+    if (mx > 0.0) { (void)frexp(mx, &e); }  // mx = f * 2^e, f in [0.5,1)  ->  mx < 2^e
+    for (int r = ty; r < 32; r += 8) {
+        // output element (k = bk + r, j = bj + tx):  Q = round(Wu * 2^(8S - e - 2)) is an exact integer below 2^(8S-2)
+        // (llrint of a double of that size is exact); its balanced base-256 digits, least significant first,
+        // d = ((Q + 128) mod 256) - 128 in [-128,127], Q <- (Q - d)/256; the leading digit ends in [-65,65].
+        long long Q = llrint(ldexp(tile[tx][r], 8 * nslices - (e + 2)));
+        for (int s = nslices - 1; s >= 0; s--) {
+            long long d = ((Q + 128) & 255) - 128;
+            Q = (Q - d) >> 8;
+            Bs[(long)s * np * np + (bk + r) * np + bj + tx] = (int8_t)d;
+        }
+    }
+}
+
+struct VaraIt {  // position in a worker's flattened stage sequence
+    int job, half, s, ct, kt, nk;
+    bool valid;
+};
+__device__ __forceinline__ void vit_set_tile(VaraIt& it, int nct, int npair, int njobs) {
+    // (job, half) -> (s, ct); skips the duplicate middle tile of an odd nct
+    while (it.job < njobs) {
+        it.s = it.job / npair;
+        int p = it.job - it.s * npair;
+        int ct = it.half == 0 ? p : nct - 1 - p;
+        if (it.half == 1 && ct == p) { it.job += VW; it.half = 0; continue; }
+        it.ct = ct;
+        it.kt = 0;
+        it.nk = 2 * (ct + 1);
+        it.valid = true;
+        return;
+    }
+    it.valid = false;
+}
+__device__ __forceinline__ void vit_advance(VaraIt& it, int nct, int npair, int njobs) {
+    if (++it.kt < it.nk) return;
+    if (it.half == 0) it.half = 1; else { it.half = 0; it.job += VW; }
+    vit_set_tile(it, nct, npair, njobs);
+}
+
+__global__ __launch_bounds__(512, 2) void k_vara_i8(const int8_t* __restrict__ Mt8, long ld, int ntm, const int8_t* __restrict__ Bs,
+                                                    long np, int nslices, long long* __restrict__ q, long Lp) {
+    __shared__ __attribute__((aligned(1024))) int8_t lds[2][2][TILE_BYTES];
+    // XCD-aware placement (speed only): b -> (xcd, slot); slot -> (marker tile within the XCD's sequence, worker)
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int mt = (slot / VW) * 8 + xcd, worker = slot % VW;
+    if (mt >= ntm) return;
+    const int nct = (int)(np / T8), npair = (nct + 1) / 2, njobs = nslices * npair;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = w >> 2, wc = w & 3;
+    const int8_t* Ablk = Mt8 + (long)mt * T8 * ld;
+    const int ldi = (int)ld, npi = (int)np;
+    const T8Lane lnA = t8_lane(lane, ldi), lnB = t8_lane(lane, npi);
+    const __amdgpu_buffer_rsrc_t rsA = t8_rsrc(Ablk, ldi);
+
+    VaraIt cur, nxt;
+    cur.job = worker; cur.half = 0; vit_set_tile(cur, nct, npair, njobs);
+    if (!cur.valid) return;
+    nxt = cur;
+    i32x16 acc[4][2];
+    t8_zero(acc);
+    // Tile epilogue: per 32-row MFMA tile m a reduce-scatter butterfly over lane bits 0..3 leaves lane l with the
+    // sum (over 16 of the 32 column lanes) of register x = xsel, one more exchange over bit 4 completes it.  keep[m]
+    // accumulates those row sums across the tiles of a slice (int64) and is flushed once per slice.
+    long long keep[4] = {0, 0, 0, 0};
+    const int col = lane & 31, hrow = 4 * (lane >> 5);
+    const int xsel = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
+
+    t8_stage(rsA, lnA, ldi, nxt.kt * BK8, lds[0][0], w);
+    t8_stage(t8_rsrc(Bs + (long)nxt.s * np * np + (long)nxt.ct * T8 * np, npi), lnB, npi, nxt.kt * BK8, lds[0][1], w);
+    vit_advance(nxt, nct, npair, njobs);
+    __syncthreads();
+    int buf = 0;
+    while (cur.valid) {
+        if (nxt.valid) {
+            t8_stage(rsA, lnA, ldi, nxt.kt * BK8, lds[buf ^ 1][0], w);
+            t8_stage(t8_rsrc(Bs + (long)nxt.s * np * np + (long)nxt.ct * T8 * np, npi), lnB, npi, nxt.kt * BK8, lds[buf ^ 1][1], w);
+            vit_advance(nxt, nct, npair, njobs);
+        }
+        t8_compute(acc, lds[buf][0], lds[buf][1], wr, wc, lane);
+        if (cur.kt == cur.nk - 1) {
+            // tile done: v[x] = sum over this lane's 2 columns of T[row][col] * m[row][col]
+            // (m from global: these genotype bytes were just streamed as the A operand, L2-resident)
+            // one per-lane VGPR offset + scalar offsets through the A-tile descriptor (no 64-bit row pointers)
+            const int mvoff = (wr * 128 + hrow) * ldi + wc * 64 + col;
+            const int msoff = cur.ct * T8;
+            const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                int v16[16], v8[8], v4[4], v2[2];
+#pragma unroll
+                for (int x = 0; x < 16; x++) {
+                    const int so = (m * 32 + (x & 3) + 8 * (x >> 2)) * ldi + msoff;
+                    const int m0 = (int)(int8_t)__builtin_amdgcn_raw_buffer_load_b8(rsA, mvoff, so, 0);
+                    const int m1 = (int)(int8_t)__builtin_amdgcn_raw_buffer_load_b8(rsA, mvoff, so + 32, 0);
+                    v16[x] = acc[m][0][x] * m0 + acc[m][1][x] * m1;
+                    acc[m][0][x] = 0;
+                    acc[m][1][x] = 0;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++) { int snd = b0 ? v16[i] : v16[i + 8]; int kp = b0 ? v16[i + 8] : v16[i]; v8[i] = kp + __shfl_xor(snd, 1); }
+#pragma unroll
+                for (int i = 0; i < 4; i++) { int snd = b1 ? v8[i] : v8[i + 4]; int kp = b1 ? v8[i + 4] : v8[i]; v4[i] = kp + __shfl_xor(snd, 2); }
+#pragma unroll
+                for (int i = 0; i < 2; i++) { int snd = b2 ? v4[i] : v4[i + 2]; int kp = b2 ? v4[i + 2] : v4[i]; v2[i] = kp + __shfl_xor(snd, 4); }
+                int v1 = (b3 ? v2[1] : v2[0]) + __shfl_xor(b3 ? v2[0] : v2[1], 8);
+                v1 += __shfl_xor(v1, 16);
+                keep[m] += v1;
+                __builtin_amdgcn_sched_barrier(0);  // keep the 4 m-tiles' epilogues apart: bounds live registers
+            }
+            const int s_done = cur.s;
+            vit_advance(cur, nct, npair, njobs);  // kt == nk-1: moves to the next tile (or ends)
+            if (!cur.valid || cur.s != s_done) {
+                // slice finished for this worker: add into q[s][row] (int64 atomics: exact, order independent)
+                long long* qs = q + (long)s_done * Lp + (long)mt * T8 + wr * 128 + hrow + (xsel & 3) + 8 * (xsel >> 2);
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    if ((lane & 16) == 0 && keep[m]) atomicAdd((unsigned long long*)&qs[m * 32], (unsigned long long)keep[m]);
+                    keep[m] = 0;
+                }
+            }
+        } else {
+            cur.kt++;
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_vara_i8_finish(const long long* __restrict__ q, long Lp, int nslices,
+                                                        const double* __restrict__ maxabs, double* __restrict__ vara) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Lp) return;
+    int e = 0;
+    const double mx = *maxabs;
+    if (mx > 0.0) (void)frexp(mx, &e);
+    double s = 0.0;
+    for (int k = nslices - 1; k >= 0; k--) s += ldexp((double)q[(long)k * Lp + i], e + 2 - 8 * (k + 1));  // smallest first
+    vara[i] = s;
+}
+
+__global__ void k_vara_i8_bound(const double* __restrict__ maxabs, long n, int nslices, double* __restrict__ out) {
+    int e = 0;
+    const double mx = *maxabs;
+    if (mx > 0.0) (void)frexp(mx, &e);
+    *out = ldexp((double)n * (double)n, e + 1 - 8 * nslices);  // (sum_j |m_ij|)^2 <= n^2
+}
+
+// workspace: [ maxabs (8 B, padded to 256) | q: nslices*L_pad int64 | Bs: nslices*n_pad*n_pad int8 ]
+static size_t ws_q_off() { return 256; }
+static size_t ws_bs_off(long L_pad, int nslices) { return (256 + (size_t)nslices * L_pad * 8 + 255) / 256 * 256; }
+
+extern "C" int64_t eagle_vara_i8_workspace_bytes(long n_pad, long L_pad, int nslices) {
+    return (int64_t)(ws_bs_off(L_pad, nslices) + (size_t)nslices * n_pad * n_pad);
+}
+
+extern "C" int eagle_dev_vara_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu,
+                                 int nslices, void* ws, double* vara_out, double* err_bound_dev, void* stream) {
+    if (L_pad % T8 || n_pad % T8 || ld % 128 || n_pad > ld || nslices < 1 || nslices > 8 || (double)ld * T8 >= 2147483648.0)
+        return eagle_fail(ctx, EAGLE_ERR_ARG, "vara_i8: layout contract violated (L_pad % 256, n_pad % 256, 1 <= nslices <= 8)");
+    // per-lane int32 partial of one slice: 2 columns per column tile, |T*m| <= 128*n_pad each
+    if (2.0 * ((double)(n_pad / T8) / VW + 2.0) * 128.0 * (double)n_pad >= 2147483648.0)
+        return eagle_fail(ctx, EAGLE_ERR_ARG, "vara_i8: n too large for the int32 per-slice partial sums; use the fp64 kernel");
+    if (L_pad == 0) return EAGLE_OK;
+    hipStream_t s = (hipStream_t)stream;
+    double* maxabs = (double*)ws;
+    long long* q = (long long*)((char*)ws + ws_q_off());
+    int8_t* Bs = (int8_t*)((char*)ws + ws_bs_off(L_pad, nslices));
+    hipError_t e = hipMemsetAsync(ws, 0, ws_bs_off(L_pad, nslices), s);  // maxabs and q
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "vara_i8 memset");
+    hipLaunchKernelGGL(k_absmax, dim3(1024), dim3(256), 0, s, Wu, n_pad * n_pad, (unsigned long long*)maxabs);
+    dim3 g2((unsigned)(n_pad / 32), (unsigned)(n_pad / 32));
+    hipLaunchKernelGGL(k_slice_w, g2, dim3(256), 0, s, Wu, n_pad, maxabs, nslices, Bs);
+    const int ntm = (int)(L_pad / T8);
+    const int groups = (ntm + 7) / 8;
+    hipLaunchKernelGGL(k_vara_i8, dim3((unsigned)(groups * 8 * VW)), dim3(512), 0, s, Mt8, ld, ntm, Bs, n_pad, nslices, q, L_pad);
+    hipLaunchKernelGGL(k_vara_i8_finish, dim3((unsigned)((L_pad + 255) / 256)), dim3(256), 0, s, q, L_pad, nslices, maxabs,
+                       vara_out);
+    if (err_bound_dev) hipLaunchKernelGGL(k_vara_i8_bound, dim3(1), dim3(1), 0, s, maxabs, n_pad, nslices, err_bound_dev);
+    e = hipGetLastError();
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "vara_i8");
+    return EAGLE_OK;
+}

@@ -2,7 +2,7 @@
 // (section 2 of include/eagle_hip.h).  Written for 64-wide wavefronts and MFMA; no other target.
 //
 //   k_decode_ascii ........ text tile '0','1','2' -> int8 {-1,0,1}     (E/src/ReadBlock.cpp:52-55)
-//   k_syrk_i8 ............. MM^T partial sums on v_mfma_i32_32x32x32_i8 (E/src/calculateMMt_rcpp.cpp:95)
+//   (k_syrk_i8 / k_vara_i8: the int8 MFMA tile engine lives in eagle_i8mfma.hip)
 //   k_gemm_f64<..> ........ fp64 MFMA GEMM core (v_mfma_f64_16x16x4_f64):
 //                             A = f64 : W = S (V S)                     (calculate_a_and_vara_rcpp.cpp:97-98)
 //                             A = int8: T = Mt W fused with the row-dot (calculate_a_and_vara_rcpp.cpp:103-112)
@@ -85,110 +85,6 @@ __global__ __launch_bounds__(256) void k_i8_to_f64_colmajor(const int8_t* __rest
     out[idx] = (double)in[r * ld_in + c];
 }
 
-// ------------------------------------------------------------------------------------------------
-// int8 NT tile product on v_mfma_i32_32x32x32_i8.
-//   C[i][j] += sum_k A[i][k] * B[j][k],  A rows / B rows int8, K contiguous.
-// Block = 256 threads = 4 waves (2 x 2), block tile 128 x 128, wave tile 64 x 64 (2 x 2 MFMA tiles),
-// K step 64 bytes, LDS double buffered, global->register->LDS staging with the loads of tile t+1 issued
-// before the MFMAs of tile t.  LDS rows are 64 B; the 16-B chunk index is XOR-swizzled with (row>>2)&3 so
-// that the ds_read_b128 of a 32-row operand fragment is bank-conflict free.
-// Both operands use the same (lane>>5, byte) -> k map, so the k order inside the instruction is immaterial
-// for an exact integer sum.
-// ------------------------------------------------------------------------------------------------
-#define GI_T 128
-#define GI_BK 64
-
-__device__ __forceinline__ int gi_lds_off(int row, int chunk) { return row * GI_BK + ((chunk ^ ((row >> 2) & 3)) << 4); }
-
-struct GiStage {
-    i32x4 a[2], b[2];
-};
-
-__device__ __forceinline__ void gi_load(GiStage& s, const int8_t* __restrict__ Ablk, long lda,
-                                        const int8_t* __restrict__ Bblk, long ldb, long k0, int t) {
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        int c = t + 256 * i;
-        int row = c >> 2, ch = c & 3;
-        s.a[i] = *(const i32x4*)(Ablk + (long)row * lda + k0 + ch * 16);
-        s.b[i] = *(const i32x4*)(Bblk + (long)row * ldb + k0 + ch * 16);
-    }
-}
-__device__ __forceinline__ void gi_store(const GiStage& s, int8_t* ldsA, int8_t* ldsB, int t) {
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        int c = t + 256 * i;
-        int row = c >> 2, ch = c & 3;
-        *(i32x4*)(ldsA + gi_lds_off(row, ch)) = s.a[i];
-        *(i32x4*)(ldsB + gi_lds_off(row, ch)) = s.b[i];
-    }
-}
-__device__ __forceinline__ void gi_compute(i32x16 (&acc)[2][2], const int8_t* ldsA, const int8_t* ldsB, int wr, int wc,
-                                           int lane) {
-    const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-        i32x4 a[2], b[2];
-#pragma unroll
-        for (int m = 0; m < 2; m++) a[m] = *(const i32x4*)(ldsA + gi_lds_off(wr * 64 + m * 32 + r, 2 * ks + h));
-#pragma unroll
-        for (int n = 0; n < 2; n++) b[n] = *(const i32x4*)(ldsB + gi_lds_off(wc * 64 + n * 32 + r, 2 * ks + h));
-#pragma unroll
-        for (int m = 0; m < 2; m++)
-#pragma unroll
-            for (int n = 0; n < 2; n++) acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b[n], acc[m][n], 0, 0, 0);
-    }
-}
-
-// MM^T: grid.x = upper-triangular tile pairs, grid.y = K splits; integer atomics into C32.
-__global__ __launch_bounds__(256, 2) void k_syrk_i8(const int8_t* __restrict__ M8, long ld, int ntile, long ksteps_total,
-                                                    long ksteps_per_split, int32_t* __restrict__ C, long ldc) {
-    __shared__ __attribute__((aligned(16))) int8_t lds[2][2][GI_T * GI_BK];
-    int ti = 0, rem = blockIdx.x;
-    while (rem >= ntile - ti) { rem -= ntile - ti; ti++; }
-    const int tj = ti + rem;
-    const long ks0 = (long)blockIdx.y * ksteps_per_split;
-    long ks1 = ks0 + ksteps_per_split;
-    if (ks1 > ksteps_total) ks1 = ksteps_total;
-    if (ks0 >= ks1) return;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
-    const int8_t* Ablk = M8 + (long)ti * GI_T * ld;
-    const int8_t* Bblk = M8 + (long)tj * GI_T * ld;
-    i32x16 acc[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; m++)
-#pragma unroll
-        for (int n = 0; n < 2; n++)
-#pragma unroll
-            for (int q = 0; q < 16; q++) acc[m][n][q] = 0;
-    GiStage st;
-    gi_load(st, Ablk, ld, Bblk, ld, ks0 * GI_BK, t);
-    gi_store(st, lds[0][0], lds[0][1], t);
-    __syncthreads();
-    int cur = 0;
-    for (long ks = ks0; ks < ks1; ks++) {
-        const bool more = ks + 1 < ks1;
-        if (more) gi_load(st, Ablk, ld, Bblk, ld, (ks + 1) * GI_BK, t);
-        gi_compute(acc, lds[cur][0], lds[cur][1], wr, wc, lane);
-        if (more) gi_store(st, lds[cur ^ 1][0], lds[cur ^ 1][1], t);
-        __syncthreads();
-        cur ^= 1;
-    }
-    // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    const int col = lane & 31, rq = 4 * (lane >> 5);
-#pragma unroll
-    for (int m = 0; m < 2; m++)
-#pragma unroll
-        for (int n = 0; n < 2; n++)
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                long i = (long)ti * GI_T + wr * 64 + m * 32 + (q & 3) + 8 * (q >> 2) + rq;
-                long j = (long)tj * GI_T + wc * 64 + n * 32 + col;
-                int v = acc[m][n][q];
-                if (v) atomicAdd(&C[i * ldc + j], v);
-            }
-}
-
 __global__ __launch_bounds__(256) void k_mmt_downdate(const int8_t* __restrict__ M8, long n_pad, long ld,
                                                       const long* __restrict__ cols, long ncols,
                                                       int32_t* __restrict__ C, long ldc) {
@@ -202,7 +98,7 @@ __global__ __launch_bounds__(256) void k_mmt_downdate(const int8_t* __restrict__
         if (!dup) s += (int)M8[i * ld + c] * (int)M8[j * ld + c];
     }
     // only the upper-triangular tiles of C are live
-    if ((i >> 7) <= (j >> 7)) C[i * ldc + j] -= s;
+    if ((i >> 8) <= (j >> 8)) C[i * ldc + j] -= s;
 }
 
 __global__ __launch_bounds__(256) void k_mmt_finish(const int32_t* __restrict__ C, long n, long ldc,
@@ -211,7 +107,7 @@ __global__ __launch_bounds__(256) void k_mmt_finish(const int32_t* __restrict__ 
     long j = (long)blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
     double v = 0.0;
     if (j < n) {
-        int c = ((i >> 7) <= (j >> 7)) ? C[i * ldc + j] : C[j * ldc + i];
+        int c = ((i >> 8) <= (j >> 8)) ? C[i * ldc + j] : C[j * ldc + i];
         v = (double)c;
         out[i * ld_out + j] = v;
     }
@@ -586,7 +482,7 @@ __global__ __launch_bounds__(256) void k_tsq_near(const double* __restrict__ a, 
         if (e__ != hipSuccess) return eagle_fail_hip(ctx, e__, __func__);   \
     } while (0)
 
-extern "C" long eagle_pad128(long x) { return (x + 127) / 128 * 128; }
+extern "C" long eagle_pad(long x) { return (x + 255) / 256 * 256; }
 
 extern "C" int eagle_dev_decode_ascii(eagle_ctx* ctx, const uint8_t* raw, long rows, long cols, long line_stride,
                                       int8_t* out, long ld_out, int* bad_chars_dev, void* stream) {
@@ -623,28 +519,6 @@ extern "C" int eagle_dev_i8_to_f64_colmajor(eagle_ctx* ctx, const int8_t* in, lo
     if (tot <= 0) return EAGLE_OK;
     hipLaunchKernelGGL(k_i8_to_f64_colmajor, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in,
                        rows, cols, ld_in, out_colmajor);
-    LAUNCH_CHECK(ctx);
-    return EAGLE_OK;
-}
-
-extern "C" int eagle_dev_mmt_accumulate(eagle_ctx* ctx, const int8_t* M8, long n_pad, long L_pad, long ld, int32_t* C32,
-                                        void* stream) {
-    if (n_pad % GI_T || L_pad % GI_BK || ld % 16 || L_pad > ld || n_pad <= 0)
-        return eagle_fail(ctx, EAGLE_ERR_ARG, "mmt_accumulate: layout contract violated");
-    if (L_pad == 0) return EAGLE_OK;
-    const int nt = (int)(n_pad / GI_T);
-    const long npairs = (long)nt * (nt + 1) / 2;
-    const long ksteps = L_pad / GI_BK;
-    // enough blocks to fill 256 CUs several times over, but K runs long enough to amortise the atomics
-    long want = (8L * 256 + npairs - 1) / npairs;
-    long maxsplit = ksteps / 32 > 0 ? ksteps / 32 : 1;
-    long nsplit = want < maxsplit ? want : maxsplit;
-    if (nsplit < 1) nsplit = 1;
-    if (nsplit > 65535) nsplit = 65535;
-    long per = (ksteps + nsplit - 1) / nsplit;
-    nsplit = (ksteps + per - 1) / per;
-    dim3 grid((unsigned)npairs, (unsigned)nsplit);
-    hipLaunchKernelGGL(k_syrk_i8, grid, dim3(256), 0, (hipStream_t)stream, M8, ld, nt, ksteps, per, C32, n_pad);
     LAUNCH_CHECK(ctx);
     return EAGLE_OK;
 }
@@ -768,4 +642,3 @@ extern "C" int eagle_dev_tsq_argmax(eagle_ctx* ctx, const double* a, const doubl
     return EAGLE_OK;
 }
 
-// ---- int8-slice vara path: implemented in eagle_vara_i8.hip ----

@@ -83,8 +83,8 @@ class DeviceShard:
         self.ctx = rcpp_api.context(device)
         self.dev = torch.device("cuda", device)
         self.n, self.Lloc, self.first = int(n), int(L_local), int(first_marker)
-        self.np_ = int(self.L.eagle_pad128(self.n))
-        self.Lp = int(self.L.eagle_pad128(self.Lloc))
+        self.np_ = int(self.L.eagle_pad(self.n))
+        self.Lp = int(self.L.eagle_pad(self.Lloc))
         self.Mt8 = torch.zeros((self.Lp, self.np_), dtype=torch.int8, device=self.dev)  # marker-major
         self.M8 = None                                                                   # individual-major
         self.a = torch.zeros(self.Lp, dtype=torch.float64, device=self.dev)
@@ -94,7 +94,7 @@ class DeviceShard:
         self.Sa = self.Va = self.ahat = self.v = self.Wu = self.tmp = None
         self.ws = None
         self.mode = 0
-        self.nslices = 8
+        self.nslices = 7
 
     # ---- plumbing -------------------------------------------------------------------------------
     def _stream(self):
@@ -145,7 +145,7 @@ class DeviceShard:
 
     # ---- MM^T -----------------------------------------------------------------------------------
     def mmt_partial(self, out=None):
-        """Exact int32 partial M_s M_s^T of this shard (upper-triangular 128-tiles live)."""
+        """Exact int32 partial M_s M_s^T of this shard (upper-triangular 256-tiles live)."""
         torch = self.torch
         M8 = self.individual_major()
         c32 = out if out is not None else torch.empty((self.np_, self.np_), dtype=torch.int32, device=self.dev)

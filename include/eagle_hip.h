@@ -119,11 +119,11 @@ int eagle_last_mmt_normalised(eagle_ctx* ctx, double* MMt_norm_out, double* max_
  *    and by bench.py, which keep genotype shards resident in HBM between calls.
  *
  *    Layout contract for genotype matrices (int8, values {-1,0,1}):
- *      Mt8: marker-major  [L_pad][ld]  ld >= n, ld % 128 == 0, L_pad % 128 == 0, padding bytes ZERO
- *      M8 : individual-major [n_pad][ld] ld >= L, ld % 128 == 0, n_pad % 128 == 0, padding bytes ZERO
- *    fp64 square operands: row-major [np][np], np = eagle_pad128(n), padding ZERO.
+ *      Mt8: marker-major  [L_pad][ld]  ld >= n, ld % 256 == 0, L_pad % 256 == 0, padding bytes ZERO
+ *      M8 : individual-major [n_pad][ld] ld >= L, ld % 256 == 0, n_pad % 256 == 0, padding bytes ZERO
+ *    fp64 square operands: row-major [np][np], np = eagle_pad(n) (next multiple of 256), padding ZERO.
  * ------------------------------------------------------------------------------------------- */
-long eagle_pad128(long x);
+long eagle_pad(long x);
 
 /* Lines [row0,row0+nrows) x characters [col0,col0+ncols) of a no-space ASCII genotype file (M.ascii / Mt.ascii,
  * as ReadBlock reads them, E/src/ReadBlock.cpp:47-58) -> int8 at dst[r*ld + c] in HBM.  Fixed-width files are

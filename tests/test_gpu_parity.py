@@ -100,11 +100,13 @@ def test_mmt_bit_exact_and_masking_rule(case, files, api):
     np.testing.assert_allclose(norm, exp, rtol=0, atol=2e-16)
 
 
-@pytest.mark.parametrize("mode", [0])
+@pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("case", GOLDEN_CASES)
-def test_scan_matches_oracle(case, mode, files, api, oracle):
+def test_scan_matches_oracle(case, mode, files, api, oracle, request):
     g, geno = files[case]
     n, L = g["M8"].shape
+    api.set_scan_mode(0)
+    request.addfinalizer(lambda: api.set_scan_mode(0))
     api.set_scan_mode(mode)
     ref = oracle.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, g["S"], g["V"], 8.0, (L, n), g["ahat"])
     res = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, g["S"], g["V"], 8.0, (L, n), g["ahat"])
@@ -215,6 +217,28 @@ def test_big_scan(big, api, oracle):
     idx, mx, near = api.last_scan_argmax()
     tsq, idx_ref, mx_ref = oracle.tsq_argmax(a_ref * 2, v_ref * 4)
     assert idx == idx_ref
+
+
+def test_big_scan_int8_slices_match_fp64_kernel(big, api, oracle):
+    """The int8-slice vara kernel (exact integer partial sums) against the fp64 MFMA kernel and the oracle."""
+    Mt8, geno, S, V, ahat = big
+    L, n = Mt8.shape
+    a_ref, v_ref = oracle.scan_from_i8(Mt8, S, V, ahat)
+    api.set_scan_mode(0)
+    r0 = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat)
+    api.set_scan_mode(1)
+    try:
+        r1 = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat)
+        r1b = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat)
+        idx1, mx1, _ = api.last_scan_argmax()
+    finally:
+        api.set_scan_mode(0)
+    np.testing.assert_array_equal(r1["vara"], r1b["vara"])  # integer atomics: bitwise reproducible
+    np.testing.assert_allclose(r1["vara"].ravel(), v_ref, rtol=RTOL)
+    np.testing.assert_allclose(r1["vara"].ravel(), r0["vara"].ravel(), rtol=RTOL)
+    np.testing.assert_array_equal(r1["a"], r0["a"])
+    _, idx_ref, _ = oracle.tsq_argmax(a_ref, v_ref)
+    assert idx1 == idx_ref
 
 
 def test_dev_gemm_f64_layout(api):
