@@ -60,7 +60,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=5000, help="individuals")
     ap.add_argument("--markers", type=int, default=500000, help="markers per GPU")
-    ap.add_argument("--mode", choices=["f64", "i8"], default=os.environ.get("EAGLE_SCAN_MODE", "f64"))
+    ap.add_argument("--mode", choices=["f64", "i8"], default=os.environ.get("EAGLE_SCAN_MODE", "i8"))
+    ap.add_argument("--slices", type=int, default=7, help="int8 digit slices of W (i8 mode)")
     ap.add_argument("--mmt-reps", type=int, default=2)
     ap.add_argument("--cpu-sample", type=int, default=32768, help="markers in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--simple-operands", action="store_true", help="seeded random SPD S / V instead of the model algebra")
@@ -106,6 +107,7 @@ def main():
     t0 = time.time()
     sh = DeviceShard(n, Lloc, first_marker=rank * Lloc, device=local_rank)
     sh.mode = 0 if args.mode == "f64" else 1
+    sh.nslices = args.slices
     sh.fill_synthetic()
     sh.individual_major()
     torch.cuda.synchronize(dev)
@@ -256,11 +258,11 @@ def main():
             "metric": "markers/sec in calculate_a_and_vara scan", "value": value, "unit": "markers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64" if sh.mode == 0 else "i8+f64", "data": "synthetic",
+            "dtype": "f64" if sh.mode == 0 else "i8 (int32/int64 exact sums, f64 finish)", "data": "synthetic",
             "config": {"workload": "synthetic %d individuals x %d SNPs per GPU (HWE genotypes, int8 resident in HBM), "
                                    "single trait, full calculate_a_and_vara pass + tsq arg-max" % (n, Lloc),
                        "n": n, "markers_per_gpu": Lloc, "markers_total": Ltot, "parallelism": "marker-shard x%d" % world,
-                       "scan_mode": args.mode, "operands": "simple" if args.simple_operands else "model algebra on MM^T"},
+                       "scan_mode": args.mode, "slices": (args.slices if sh.mode else None), "operands": "simple" if args.simple_operands else "model algebra on MM^T"},
             "mmt_build_s": mmt_build_s, "selected_marker": int(sel[0]), "tsqmax": sel[1],
             "roofline": roof, "roofline_secondary": secondary, "cpu_baseline": cpu, "parity": parity,
             "device": info, "setup_s": {"genotypes": t_gen, "operands": t_ops},

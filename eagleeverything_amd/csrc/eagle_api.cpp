@@ -46,7 +46,8 @@ struct eagle_ctx {
     char err[1024] = {0};
     eagle_message_fn msg_fn = nullptr;
     void* msg_user = nullptr;
-    int scan_mode = 0;
+    int scan_mode = 1;   // 1 = int8 digit slices on the int8 MFMA (default), 0 = fp64 MFMA
+    int scan_slices = 7; // 7 x 8 bits: the whole fp64 mantissa of max|W|
     std::vector<GenoEntry> cache;
     // results of the last calls, kept in HBM
     double* d_mmt = nullptr; long mmt_n = 0; double* d_mmt_max = nullptr;
@@ -179,6 +180,11 @@ extern "C" int eagle_device_info(eagle_ctx* ctx, char* arch_out, int arch_len, i
 extern "C" int eagle_set_scan_mode(eagle_ctx* ctx, int mode) {
     if (!ctx || mode < 0 || mode > 1) return EAGLE_ERR_ARG;
     ctx->scan_mode = mode;
+    return EAGLE_OK;
+}
+extern "C" int eagle_set_scan_slices(eagle_ctx* ctx, int nslices) {
+    if (!ctx || nslices < 1 || nslices > 8) return EAGLE_ERR_ARG;
+    ctx->scan_slices = nslices;
     return EAGLE_OK;
 }
 
@@ -597,8 +603,8 @@ extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_asc
     if (rc) return rc;
     rc = eagle_dev_gemv_i8(ctx, g->dev, Lp, np, g->ld, v.as<double>(), 1.0, ctx->d_a, ctx->stream);
     if (rc) return rc;
-    if (ctx->scan_mode == 1) {
-        const int nslices = 7;  // 7 x 8 bits: the whole fp64 mantissa of max|W|
+    if (ctx->scan_mode == 1 && 64.0 * 128.0 * (double)np < 2147483648.0) {
+        const int nslices = ctx->scan_slices;
         HIPCHK(ctx, ws.alloc((size_t)eagle_vara_i8_workspace_bytes(np, Lp, nslices)));
         rc = eagle_dev_vara_i8(ctx, g->dev, Lp, np, g->ld, Wu.as<double>(), nslices, ws.p, ctx->d_vara, nullptr, ctx->stream);
     } else {

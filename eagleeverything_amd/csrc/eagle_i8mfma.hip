@@ -184,14 +184,15 @@ extern "C" int eagle_dev_mmt_accumulate(eagle_ctx* ctx, const int8_t* M8, long n
 // NT product  T_s[i][k] = sum_j Mt8[i][j] * Bs[s][k][j]  with k-tile ct needing only j < (ct+1)*256 (lower
 // triangular image).  The row-dot with m_ik is fused into the tile epilogue.
 //
-// Work decomposition.  Job = (slice s, column-tile pair {p, nct-1-p}): every job runs (nct+1)*2 stages, so jobs are
-// equal.  A marker tile (256 markers) is served by W workgroups ("workers") that take jobs round-robin; their
-// integer partial row-dots meet in q[s][i] by int64 atomics.  Workgroup b runs on XCD b%8 (observed dealing); the
-// 32 concurrently resident workgroups of an XCD are laid out as 32/W consecutive marker tiles x W workers, so the
-// workers of one marker tile share its genotype panel in that XCD's L2 and equal-numbered workers of neighbouring
-// marker tiles stream the same W-slice tiles in lock-step (a placement guess that only affects speed).
+// Work decomposition.  A marker tile (256 markers) is served by S workgroups, one per digit slice ("workers").  Every
+// worker walks the same sequence of column-tile pairs {p, nct-1-p} (each pair costs (nct+1)*2 stages) and the same k
+// order inside them, so at any moment the S workers of a marker tile want the SAME genotype stage and differ only in
+// the W-slice they stream: when they sit on one XCD (workgroup b runs on XCD b%8, observed dealing; the workers of a
+// marker tile are given consecutive slots of one XCD) the genotype panel is fetched once into that XCD's L2 and read
+// S times from there, and equal-numbered workers of the XCD's other resident marker tiles stream the same W-slice
+// tiles in lock-step.  This placement is a guess that only affects speed.  The integer partial row-dots of the
+// workers meet in q[s][i] by int64 atomics (one flush per worker).
 // ================================================================================================
-#define VW 4 /* workers per marker tile */
 
 __global__ __launch_bounds__(256) void k_absmax(const double* __restrict__ x, long n, unsigned long long* __restrict__ bits) {
     double m = 0.0;
@@ -228,29 +229,26 @@ __global__ __launch_bounds__(256) void k_slice_w(const double* __restrict__ Wu, 
     }
 }
 
-struct VaraIt {  // position in a worker's flattened stage sequence
-    int job, half, s, ct, kt, nk;
+struct VaraIt {  // position in a worker's flattened stage sequence: pair p, half (tile p, then tile nct-1-p), stage kt
+    int p, half, ct, kt, nk;
     bool valid;
 };
-__device__ __forceinline__ void vit_set_tile(VaraIt& it, int nct, int npair, int njobs) {
-    // (job, half) -> (s, ct); skips the duplicate middle tile of an odd nct
-    while (it.job < njobs) {
-        it.s = it.job / npair;
-        int p = it.job - it.s * npair;
-        int ct = it.half == 0 ? p : nct - 1 - p;
-        if (it.half == 1 && ct == p) { it.job += VW; it.half = 0; continue; }
+__device__ __forceinline__ void vit_set_tile(VaraIt& it, int nct, int npair) {
+    while (it.p < npair) {
+        int ct = it.half == 0 ? it.p : nct - 1 - it.p;
+        if (it.half == 1 && ct == it.p) { it.p++; it.half = 0; continue; }  // middle tile of an odd nct: once only
         it.ct = ct;
         it.kt = 0;
-        it.nk = 2 * (ct + 1);
+        it.nk = (T8 / BK8) * (ct + 1);
         it.valid = true;
         return;
     }
     it.valid = false;
 }
-__device__ __forceinline__ void vit_advance(VaraIt& it, int nct, int npair, int njobs) {
+__device__ __forceinline__ void vit_advance(VaraIt& it, int nct, int npair) {
     if (++it.kt < it.nk) return;
-    if (it.half == 0) it.half = 1; else { it.half = 0; it.job += VW; }
-    vit_set_tile(it, nct, npair, njobs);
+    if (it.half == 0) it.half = 1; else { it.half = 0; it.p++; }
+    vit_set_tile(it, nct, npair);
 }
 
 __global__ __launch_bounds__(512, 2) void k_vara_i8(const int8_t* __restrict__ Mt8, long ld, int ntm, const int8_t* __restrict__ Bs,
@@ -259,9 +257,10 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8(const int8_t* __restrict__ M
     // XCD-aware placement (speed only): b -> (xcd, slot); slot -> (marker tile within the XCD's sequence, worker)
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
-    const int mt = (slot / VW) * 8 + xcd, worker = slot % VW;
+    const int mt = (slot / nslices) * 8 + xcd, sl = slot % nslices;  // worker = digit slice
     if (mt >= ntm) return;
-    const int nct = (int)(np / T8), npair = (nct + 1) / 2, njobs = nslices * npair;
+    const int nct = (int)(np / T8), npair = (nct + 1) / 2;
+    const int8_t* Bsl = Bs + (long)sl * np * np;
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = w >> 2, wc = w & 3;
@@ -271,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8(const int8_t* __restrict__ M
     const __amdgpu_buffer_rsrc_t rsA = t8_rsrc(Ablk, ldi);
 
     VaraIt cur, nxt;
-    cur.job = worker; cur.half = 0; vit_set_tile(cur, nct, npair, njobs);
+    cur.p = 0; cur.half = 0; vit_set_tile(cur, nct, npair);
     if (!cur.valid) return;
     nxt = cur;
     i32x16 acc[4][2];
@@ -284,15 +283,15 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8(const int8_t* __restrict__ M
     const int xsel = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
 
     t8_stage(rsA, lnA, ldi, nxt.kt * BK8, lds[0][0], w);
-    t8_stage(t8_rsrc(Bs + (long)nxt.s * np * np + (long)nxt.ct * T8 * np, npi), lnB, npi, nxt.kt * BK8, lds[0][1], w);
-    vit_advance(nxt, nct, npair, njobs);
+    t8_stage(t8_rsrc(Bsl + (long)nxt.ct * T8 * np, npi), lnB, npi, nxt.kt * BK8, lds[0][1], w);
+    vit_advance(nxt, nct, npair);
     __syncthreads();
     int buf = 0;
     while (cur.valid) {
         if (nxt.valid) {
             t8_stage(rsA, lnA, ldi, nxt.kt * BK8, lds[buf ^ 1][0], w);
-            t8_stage(t8_rsrc(Bs + (long)nxt.s * np * np + (long)nxt.ct * T8 * np, npi), lnB, npi, nxt.kt * BK8, lds[buf ^ 1][1], w);
-            vit_advance(nxt, nct, npair, njobs);
+            t8_stage(t8_rsrc(Bsl + (long)nxt.ct * T8 * np, npi), lnB, npi, nxt.kt * BK8, lds[buf ^ 1][1], w);
+            vit_advance(nxt, nct, npair);
         }
         t8_compute(acc, lds[buf][0], lds[buf][1], wr, wc, lane);
         if (cur.kt == cur.nk - 1) {
@@ -325,23 +324,18 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8(const int8_t* __restrict__ M
                 keep[m] += v1;
                 __builtin_amdgcn_sched_barrier(0);  // keep the 4 m-tiles' epilogues apart: bounds live registers
             }
-            const int s_done = cur.s;
-            vit_advance(cur, nct, npair, njobs);  // kt == nk-1: moves to the next tile (or ends)
-            if (!cur.valid || cur.s != s_done) {
-                // slice finished for this worker: add into q[s][row] (int64 atomics: exact, order independent)
-                long long* qs = q + (long)s_done * Lp + (long)mt * T8 + wr * 128 + hrow + (xsel & 3) + 8 * (xsel >> 2);
-#pragma unroll
-                for (int m = 0; m < 4; m++) {
-                    if ((lane & 16) == 0 && keep[m]) atomicAdd((unsigned long long*)&qs[m * 32], (unsigned long long)keep[m]);
-                    keep[m] = 0;
-                }
-            }
+            vit_advance(cur, nct, npair);  // kt == nk-1: moves to the next tile (or ends)
         } else {
             cur.kt++;
         }
         __syncthreads();
         buf ^= 1;
     }
+    // this worker's slice is complete: add into q[slice][row] (int64 atomics: exact, order independent)
+    long long* qs = q + (long)sl * Lp + (long)mt * T8 + wr * 128 + hrow + (xsel & 3) + 8 * (xsel >> 2);
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+        if ((lane & 16) == 0 && keep[m]) atomicAdd((unsigned long long*)&qs[m * 32], (unsigned long long)keep[m]);
 }
 
 __global__ __launch_bounds__(256) void k_vara_i8_finish(const long long* __restrict__ q, long Lp, int nslices,
@@ -375,8 +369,8 @@ extern "C" int eagle_dev_vara_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, 
                                  int nslices, void* ws, double* vara_out, double* err_bound_dev, void* stream) {
     if (L_pad % T8 || n_pad % T8 || ld % 128 || n_pad > ld || nslices < 1 || nslices > 8 || (double)ld * T8 >= 2147483648.0)
         return eagle_fail(ctx, EAGLE_ERR_ARG, "vara_i8: layout contract violated (L_pad % 256, n_pad % 256, 1 <= nslices <= 8)");
-    // per-lane int32 partial of one slice: 2 columns per column tile, |T*m| <= 128*n_pad each
-    if (2.0 * ((double)(n_pad / T8) / VW + 2.0) * 128.0 * (double)n_pad >= 2147483648.0)
+    // int32 tile row-sum: 64 columns per wave x |T*m| <= 128*n_pad each (accumulation across tiles is int64)
+    if (64.0 * 128.0 * (double)n_pad >= 2147483648.0)
         return eagle_fail(ctx, EAGLE_ERR_ARG, "vara_i8: n too large for the int32 per-slice partial sums; use the fp64 kernel");
     if (L_pad == 0) return EAGLE_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -390,7 +384,7 @@ extern "C" int eagle_dev_vara_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, 
     hipLaunchKernelGGL(k_slice_w, g2, dim3(256), 0, s, Wu, n_pad, maxabs, nslices, Bs);
     const int ntm = (int)(L_pad / T8);
     const int groups = (ntm + 7) / 8;
-    hipLaunchKernelGGL(k_vara_i8, dim3((unsigned)(groups * 8 * VW)), dim3(512), 0, s, Mt8, ld, ntm, Bs, n_pad, nslices, q, L_pad);
+    hipLaunchKernelGGL(k_vara_i8, dim3((unsigned)(groups * 8 * nslices)), dim3(512), 0, s, Mt8, ld, ntm, Bs, n_pad, nslices, q, L_pad);
     hipLaunchKernelGGL(k_vara_i8_finish, dim3((unsigned)((L_pad + 255) / 256)), dim3(256), 0, s, q, L_pad, nslices, maxabs,
                        vara_out);
     if (err_bound_dev) hipLaunchKernelGGL(k_vara_i8_bound, dim3(1), dim3(1), 0, s, maxabs, n_pad, nslices, err_bound_dev);

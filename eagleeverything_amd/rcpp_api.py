@@ -90,9 +90,15 @@ def device_info(device=0):
 
 
 def set_scan_mode(mode, device=0):
-    """0 = fp64 MFMA vara kernel, 1 = int8-slice vara kernel."""
+    """1 (default) = int8-slice vara kernel, 0 = fp64 MFMA vara kernel."""
     ctx = context(device)
     _check(ctx, _lib.load().eagle_set_scan_mode(ctx, int(mode)))
+
+
+def set_scan_slices(nslices, device=0):
+    """Base-256 digits of W used by the int8-slice kernel (1..8, default 7)."""
+    ctx = context(device)
+    _check(ctx, _lib.load().eagle_set_scan_slices(ctx, int(nslices)))
 
 
 def drop_cache(device=0):

@@ -56,9 +56,12 @@ void eagle_set_message_callback(eagle_ctx* ctx, eagle_message_fn fn, void* user)
 void eagle_drop_cache(eagle_ctx* ctx);
 /* "gfx950", CU count, HBM bytes -- for logs and bench JSON. */
 int eagle_device_info(eagle_ctx* ctx, char* arch_out, int arch_len, int* cu_count, int64_t* hbm_bytes);
-/* vara kernel: 0 = fp64 MFMA (v_mfma_f64_16x16x4_f64), 1 = exact int8 slices of W on v_mfma_i32_32x32x32_i8
- * with a per-call error certificate; default is chosen by the library. */
+/* vara kernel: 1 (default) = exact int8 digit slices of W on v_mfma_i32_32x32x32_i8, 0 = fp64 MFMA
+ * (v_mfma_f64_16x16x4_f64; also taken automatically when n is too large for the int32 tile sums).
+ * eagle_set_scan_slices: S in 1..8 base-256 digits of W (default 7 = the whole 53-bit mantissa of max|W|);
+ * every vara_i then differs from the exact m_i^T W m_i by at most (sum_j |m_ij|)^2 * 2^(e+1-8S), max|W| < 2^e. */
 int eagle_set_scan_mode(eagle_ctx* ctx, int mode);
+int eagle_set_scan_slices(eagle_ctx* ctx, int nslices);
 
 /* ---------------------------------------------------------------------------------------------
  * 1. Reference-shaped entry points (host pointers, files on disk)

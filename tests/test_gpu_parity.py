@@ -105,8 +105,7 @@ def test_mmt_bit_exact_and_masking_rule(case, files, api):
 def test_scan_matches_oracle(case, mode, files, api, oracle, request):
     g, geno = files[case]
     n, L = g["M8"].shape
-    api.set_scan_mode(0)
-    request.addfinalizer(lambda: api.set_scan_mode(0))
+    request.addfinalizer(lambda: api.set_scan_mode(1))
     api.set_scan_mode(mode)
     ref = oracle.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, g["S"], g["V"], 8.0, (L, n), g["ahat"])
     res = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, g["S"], g["V"], 8.0, (L, n), g["ahat"])
@@ -130,7 +129,7 @@ def test_scan_matches_oracle(case, mode, files, api, oracle, request):
         assert resm["a"][s, 0] == 0.0 and resm["vara"][s, 0] == 0.0
     idx, _, _ = api.last_scan_argmax()
     assert idx == int(g["argmax_masked"])
-    api.set_scan_mode(0)
+    api.set_scan_mode(1)
 
 
 def test_scan_branch_rules_and_sentinels(files, api):
@@ -227,12 +226,18 @@ def test_big_scan_int8_slices_match_fp64_kernel(big, api, oracle):
     api.set_scan_mode(0)
     r0 = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat)
     api.set_scan_mode(1)
-    try:
-        r1 = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat)
-        r1b = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat)
-        idx1, mx1, _ = api.last_scan_argmax()
-    finally:
-        api.set_scan_mode(0)
+    r1 = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat)
+    r1b = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat)
+    idx1, mx1, _ = api.last_scan_argmax()
+    # fewer digits: the documented bound (sum|m|)^2 * 2^(e+1-8S) must hold
+    for S_ in (4, 5, 6):
+        api.set_scan_slices(S_)
+        rs = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat)
+        Wexact = S @ (V @ S)
+        e = int(np.floor(np.log2(np.abs(np.triu(Wexact + Wexact.T - np.diag(np.diag(Wexact)))).max()))) + 1
+        bound = (np.abs(Mt8).sum(axis=1).astype(np.float64) ** 2) * 2.0 ** (e + 1 - 8 * S_)
+        assert np.all(np.abs(rs["vara"].ravel() - v_ref) <= bound + 1e-9 * np.abs(v_ref))
+    api.set_scan_slices(7)
     np.testing.assert_array_equal(r1["vara"], r1b["vara"])  # integer atomics: bitwise reproducible
     np.testing.assert_allclose(r1["vara"].ravel(), v_ref, rtol=RTOL)
     np.testing.assert_allclose(r1["vara"].ravel(), r0["vara"].ravel(), rtol=RTOL)

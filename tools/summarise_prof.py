@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 csv output (tools/profile_gpu.sh) into the per-kernel summary kept under profiles/."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+OURS = ("k_vara_i8", "k_syrk_i8", "k_gemm_f64", "k_gemv_i8", "k_slice_w", "k_fold_upper", "k_colgemv", "k_tsq", "k_absmax",
+        "k_transpose_i8", "k_mmt_finish", "k_mmt_normalise", "k_decode_ascii", "k_vara_i8_finish")
+
+
+def find(pattern):
+    fs = glob.glob(os.path.join(out, pattern), recursive=True)
+    return fs[0] if fs else None
+
+
+def short(name):
+    for k in OURS:
+        if k in name:
+            if "k_gemm_f64" in name:
+                return "k_gemm_f64<i8A,rowdot>" if "Li1ELi1E" in name or "<1, 1>" in name else "k_gemm_f64<f64A,store>"
+            if k == "k_vara_i8" and "finish" in name:
+                return "k_vara_i8_finish"
+            return k
+    return None
+
+
+print("# rocprofv3 summary of", os.path.basename(out))
+f = find("stats/**/*kernel_stats.csv")
+if f:
+    print("\n## kernel stats (rocprofv3 --kernel-trace --stats), this repo's kernels")
+    print("%-28s %8s %14s %14s %8s" % ("kernel", "calls", "total_ms", "avg_ms", "pct"))
+    for r in csv.DictReader(open(f)):
+        s = short(r["Name"])
+        if s:
+            print("%-28s %8s %14.3f %14.4f %8s" % (s, r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                   float(r["AverageNs"]) / 1e6, r["Percentage"]))
+for tag in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_grbm"):
+    f = find(tag + "/**/*counter_collection.csv")
+    if not f:
+        continue
+    acc = defaultdict(lambda: defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        s = short(r["Kernel_Name"])
+        if s:
+            acc[s][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    print("\n## %s: mean counter value per dispatch" % tag)
+    for k in sorted(acc):
+        for c in sorted(acc[k]):
+            v = acc[k][c]
+            print("%-28s %-28s n=%-4d mean=%.6g" % (k, c, len(v), sum(v) / len(v)))
