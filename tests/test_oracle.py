@@ -155,3 +155,27 @@ def test_inmem_i8_entry_points(golden, oracle):
     np.testing.assert_allclose(a, g["a"], rtol=1e-10, atol=1e-12)
     mmt = oracle.mmt_from_i8(g["M8"])
     np.testing.assert_array_equal(mmt, g["MMt"].astype(np.float64))
+
+
+def test_scan_real_blocked_branch(oracle, tmp_path):
+    """A problem big enough (4*n*L*8 >= 1e9) for calculate_a_and_vara_rcpp.cpp:74 to take the marker-block branch
+    (:117-234), including block-relative masking (:176-190); it must reproduce the in-memory branch exactly."""
+    n, L = 48, 700000
+    rng = np.random.default_rng(1)
+    Mt8 = rng.integers(-1, 2, size=(L, n), dtype=np.int8)
+    p = synth.write_ascii(str(tmp_path / "Mt.ascii"), Mt8)
+    A = rng.standard_normal((n, n)) / 6.0
+    S = A @ A.T + np.eye(n)
+    V = 0.3 * np.eye(n)
+    ah = rng.standard_normal(n)
+    sel = np.array([5.0, 233334.0, 466669.0, float(L - 1)])  # one in every block
+    full, br0 = oracle.calculate_a_and_vara_rcpp(p, sel, S, V, 8.0, (L, n), ah, return_branch=True)
+    blk, br1 = oracle.calculate_a_and_vara_rcpp(p, sel, S, V, 0.5, (L, n), ah, return_branch=True)
+    assert br0 == 0 and 0 < br1 < L  # 0.5e9/(4*48*8) = 325520 rows per block -> 3 blocks
+    np.testing.assert_array_equal(blk["a"], full["a"])
+    np.testing.assert_array_equal(blk["vara"], full["vara"])
+    for s in sel.astype(int):
+        assert blk["a"][s, 0] == 0.0 and blk["vara"][s, 0] == 0.0
+    a_np = Mt8.astype(np.float64) @ (S @ ah)
+    a_np[sel.astype(int)] = 0.0
+    np.testing.assert_allclose(blk["a"].ravel(), a_np, rtol=1e-11, atol=1e-12)

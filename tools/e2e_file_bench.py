@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""PCIe- and file-inclusive timing of the reference-shaped entry points (host files -> host results) on the GPU box.
+Not the bench metric (bench.py times with genotypes resident); reported in DESIGN.md section 5."""
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
+    L = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
+    import torch
+    from eagleeverything_amd import rcpp_api, synth
+    from eagleeverything_amd.sharded import DeviceShard
+    sh = DeviceShard(n, L)
+    sh.fill_synthetic()
+    Mt8 = sh.Mt8[:L, :n].cpu().numpy()
+    del sh
+    torch.cuda.empty_cache()
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((n, 64)) / 8.0
+    S = np.eye(n) + A @ A.T
+    V = 0.5 * np.eye(n) - 0.01 * (A[:, :8] @ A[:, :8].T)
+    ahat = rng.standard_normal(n)
+    out = {"n": n, "L": L}
+    with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
+        t = time.perf_counter()
+        geno = synth.write_geno_pair(d, Mt8)
+        out["write_files_s"] = time.perf_counter() - t
+        for name, fn in (("mmt", lambda: rcpp_api.calculateMMt_rcpp(geno["asciifileM"], 8.0, 16, np.nan, (n, L))),
+                         ("scan", lambda: rcpp_api.calculate_a_and_vara_rcpp(geno["asciifileMt"], np.nan, S, V, 8.0, (L, n), ahat))):
+            t = time.perf_counter(); fn(); cold = time.perf_counter() - t
+            t = time.perf_counter(); fn(); warm = time.perf_counter() - t
+            out[name + "_cold_s"] = cold   # text file (page cache) -> pinned -> HBM -> decode -> compute -> D2H
+            out[name + "_warm_s"] = warm   # genotypes already resident in HBM; operands H2D, results D2H
+        out["scan_cold_markers_per_s"] = L / out["scan_cold_s"]
+        out["scan_warm_markers_per_s"] = L / out["scan_warm_s"]
+        out["file_bytes_each"] = os.path.getsize(geno["asciifileM"])
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
