@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--n", type=int, default=5000, help="individuals")
     ap.add_argument("--markers", type=int, default=500000, help="markers per GPU")
     ap.add_argument("--mode", choices=["f64", "i8"], default=os.environ.get("EAGLE_SCAN_MODE", "i8"))
-    ap.add_argument("--slices", type=int, default=7, help="int8 digit slices of W (i8 mode)")
+    ap.add_argument("--slices", type=int, default=0, help="int8 digit slices of W in i8 mode (0 = chosen from the error bound)")
     ap.add_argument("--mmt-reps", type=int, default=2)
     ap.add_argument("--cpu-sample", type=int, default=32768, help="markers in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--simple-operands", action="store_true", help="seeded random SPD S / V instead of the model algebra")
@@ -197,14 +197,16 @@ def main():
     # ---- roofline of the dominant kernel (vara) ---------------------------------------------------
     np_, Lp = sh.np_, sh.Lp
     nct = np_ // 128
+    S_used, vara_bound = (sh.vara_i8_info()[:2] if sh.mode else (None, None))
     if sh.mode == 0:
         # executed = algorithmic for the triangular fp64 kernel: column tile ct needs k < (ct+1)*128
         flops = sum(2.0 * Lp * 128 * min((ct + 1) * 128, np_) for ct in range(nct))
         roof = {"bound": "mfma", "kernel": "k_gemm_f64<int8 A, row-dot> (v_mfma_f64_16x16x4_f64)", "dtype": "f64",
                 "achieved": flops / kern_s / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
     else:
-        ops = sum(2.0 * Lp * 128 * min((ct + 1) * 128, np_) for ct in range(nct)) * sh.nslices
-        roof = {"bound": "mfma", "kernel": "k_vara_i8 (v_mfma_i32_32x32x32_i8, %d slices)" % sh.nslices, "dtype": "i8",
+        nct8 = np_ // 256
+        ops = sum(2.0 * Lp * 256 * min((ct + 1) * 256, np_) for ct in range(nct8)) * S_used
+        roof = {"bound": "mfma", "kernel": "k_vara_i8 (v_mfma_i32_32x32x32_i8, %d digit slices)" % S_used, "dtype": "i8",
                 "achieved": ops / kern_s / 1e12, "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s"}
     roof["frac"] = roof["achieved"] / roof["peak"]
     roof["traffic"] = None  # HBM bytes per launch from the PMC pass: see profiles/ and DESIGN.md
@@ -262,7 +264,7 @@ def main():
             "config": {"workload": "synthetic %d individuals x %d SNPs per GPU (HWE genotypes, int8 resident in HBM), "
                                    "single trait, full calculate_a_and_vara pass + tsq arg-max" % (n, Lloc),
                        "n": n, "markers_per_gpu": Lloc, "markers_total": Ltot, "parallelism": "marker-shard x%d" % world,
-                       "scan_mode": args.mode, "slices": (args.slices if sh.mode else None), "operands": "simple" if args.simple_operands else "model algebra on MM^T"},
+                       "scan_mode": args.mode, "slices": S_used, "vara_abs_error_bound": vara_bound, "operands": "simple" if args.simple_operands else "model algebra on MM^T"},
             "mmt_build_s": mmt_build_s, "selected_marker": int(sel[0]), "tsqmax": sel[1],
             "roofline": roof, "roofline_secondary": secondary, "cpu_baseline": cpu, "parity": parity,
             "device": info, "setup_s": {"genotypes": t_gen, "operands": t_ops},

@@ -47,7 +47,7 @@ struct eagle_ctx {
     eagle_message_fn msg_fn = nullptr;
     void* msg_user = nullptr;
     int scan_mode = 1;   // 1 = int8 digit slices on the int8 MFMA (default), 0 = fp64 MFMA
-    int scan_slices = 7; // 7 x 8 bits: the whole fp64 mantissa of max|W|
+    int scan_slices = 0; // 0 = chosen per call from the error bound (3..7), 1..8 = fixed
     std::vector<GenoEntry> cache;
     // results of the last calls, kept in HBM
     double* d_mmt = nullptr; long mmt_n = 0; double* d_mmt_max = nullptr;
@@ -183,7 +183,7 @@ extern "C" int eagle_set_scan_mode(eagle_ctx* ctx, int mode) {
     return EAGLE_OK;
 }
 extern "C" int eagle_set_scan_slices(eagle_ctx* ctx, int nslices) {
-    if (!ctx || nslices < 1 || nslices > 8) return EAGLE_ERR_ARG;
+    if (!ctx || nslices < 0 || nslices > 8) return EAGLE_ERR_ARG;
     ctx->scan_slices = nslices;
     return EAGLE_OK;
 }

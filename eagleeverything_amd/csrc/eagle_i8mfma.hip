@@ -54,36 +54,106 @@ __device__ __forceinline__ void t8_stage(__amdgpu_buffer_rsrc_t rs, const T8Lane
     }
 }
 
-struct T8Frag {
+// One k-step (32 bytes of K) of the wave tile: 6 fragment reads + 8 MFMAs.
+__device__ __forceinline__ void t8_kstep(i32x16 (&acc)[4][2], const int8_t* pa, const int8_t* pb, int ch) {
     i32x4 a[4], b[2];
-};
-__device__ __forceinline__ void t8_frag_load(T8Frag& f, const int8_t* pa, const int8_t* pb, int ch) {
 #pragma unroll
-    for (int m = 0; m < 4; m++) f.a[m] = *(const i32x4*)(pa + m * (32 * BK8) + ch);
+    for (int m = 0; m < 4; m++) a[m] = *(const i32x4*)(pa + m * (32 * BK8) + ch);
 #pragma unroll
-    for (int n = 0; n < 2; n++) f.b[n] = *(const i32x4*)(pb + n * (32 * BK8) + ch);
-}
-__device__ __forceinline__ void t8_frag_mma(i32x16 (&acc)[4][2], const T8Frag& f) {
+    for (int n = 0; n < 2; n++) b[n] = *(const i32x4*)(pb + n * (32 * BK8) + ch);
 #pragma unroll
     for (int m = 0; m < 4; m++)
 #pragma unroll
-        for (int n = 0; n < 2; n++) acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[m], f.b[n], acc[m][n], 0, 0, 0);
+        for (int n = 0; n < 2; n++) acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b[n], acc[m][n], 0, 0, 0);
 }
-// 4 k-steps of 32 bytes; the fragments of step ks+1 are read from LDS while the 8 MFMAs of step ks run.
+struct T8Read {  // per-lane LDS read bases and the 4 swizzled chunk offsets of a stage
+    int offA, offB, ch[4];
+};
+__device__ __forceinline__ T8Read t8_read_init(int wr, int wc, int lane) {
+    const int r = lane & 31, h = lane >> 5, swz = (r >> 1) & 7;
+    T8Read x;
+    x.offA = wr * (128 * BK8) + r * BK8;
+    x.offB = wc * (64 * BK8) + r * BK8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) x.ch[ks] = ((2 * ks + h) ^ swz) << 4;
+    return x;
+}
 __device__ __forceinline__ void t8_compute(i32x16 (&acc)[4][2], const int8_t* ldsA, const int8_t* ldsB, int wr, int wc,
                                            int lane) {
-    const int r = lane & 31, h = lane >> 5, swz = (r >> 1) & 7;
-    const int8_t* pa = ldsA + wr * (128 * BK8) + r * BK8;
-    const int8_t* pb = ldsB + wc * (64 * BK8) + r * BK8;
-    T8Frag f0, f1;
-    t8_frag_load(f0, pa, pb, ((0 + h) ^ swz) << 4);
-    t8_frag_load(f1, pa, pb, ((2 + h) ^ swz) << 4);
-    t8_frag_mma(acc, f0);
-    t8_frag_load(f0, pa, pb, ((4 + h) ^ swz) << 4);
-    t8_frag_mma(acc, f1);
-    t8_frag_load(f1, pa, pb, ((6 + h) ^ swz) << 4);
-    t8_frag_mma(acc, f0);
-    t8_frag_mma(acc, f1);
+    const T8Read rd = t8_read_init(wr, wc, lane);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) t8_kstep(acc, ldsA + rd.offA, ldsB + rd.offB, rd.ch[ks]);
+}
+
+// One pipeline stage: compute stage `cur` from (ldsA, ldsB) and, if `more`, DMA the next stage into (nA, nB).
+// Waves w and w+4 share a SIMD.  In lock-step both would first spend their issue slots on the 8 DMA pieces and then
+// both queue MFMAs; staggered (TUNE 1), the younger half runs half of its MFMAs first, so one partner's DMA issue
+// overlaps the other's matrix work.
+template <int TUNE>
+__device__ __forceinline__ void t8_stage_compute(i32x16 (&acc)[4][2], const int8_t* ldsA, const int8_t* ldsB, const T8Read& rd,
+                                                 bool more, __amdgpu_buffer_rsrc_t rsA, const T8Lane& lnA, int ldA, int kA,
+                                                 int8_t* nA, __amdgpu_buffer_rsrc_t rsB, const T8Lane& lnB, int ldB, int kB,
+                                                 int8_t* nB, int w) {
+    const int8_t* pa = ldsA + rd.offA;
+    const int8_t* pb = ldsB + rd.offB;
+    if (TUNE == 1) {
+        // the k-steps are common code; only the position of the DMA block depends on the wave half (scalar branch)
+        if (more && w < 4) { t8_stage(rsA, lnA, ldA, kA, nA, w); t8_stage(rsB, lnB, ldB, kB, nB, w); }
+        __builtin_amdgcn_sched_barrier(0);
+        t8_kstep(acc, pa, pb, rd.ch[0]);
+        t8_kstep(acc, pa, pb, rd.ch[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more && w >= 4) { t8_stage(rsA, lnA, ldA, kA, nA, w); t8_stage(rsB, lnB, ldB, kB, nB, w); }
+        __builtin_amdgcn_sched_barrier(0);
+        t8_kstep(acc, pa, pb, rd.ch[2]);
+        t8_kstep(acc, pa, pb, rd.ch[3]);
+    } else if (TUNE == 5 || TUNE == 6) {
+        // software-pipelined fragments: the 6 ds_read_b128 of k-step ks+1 are pinned between the 8 MFMAs of k-step ks
+        if (TUNE == 5 && more) { t8_stage(rsA, lnA, ldA, kA, nA, w); t8_stage(rsB, lnB, ldB, kB, nB, w); }
+        i32x4 a0[4], b0[2], a1[4], b1[2];
+#define T8_LD(A_, B_, KS)                                                                   \
+    _Pragma("unroll") for (int m = 0; m < 4; m++) A_[m] = *(const i32x4*)(pa + m * (32 * BK8) + rd.ch[KS]); \
+    _Pragma("unroll") for (int n = 0; n < 2; n++) B_[n] = *(const i32x4*)(pb + n * (32 * BK8) + rd.ch[KS]);
+#define T8_MM(A_, B_)                                                                       \
+    _Pragma("unroll") for (int m = 0; m < 4; m++)                                           \
+        _Pragma("unroll") for (int n = 0; n < 2; n++) acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A_[m], B_[n], acc[m][n], 0, 0, 0);
+#define T8_PIN()                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 6; i++) {                                         \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                  \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                  \
+    }                                                                                       \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        T8_LD(a0, b0, 0)
+        T8_LD(a1, b1, 1) T8_MM(a0, b0) T8_PIN()
+        T8_LD(a0, b0, 2) T8_MM(a1, b1) T8_PIN()
+        T8_LD(a1, b1, 3) T8_MM(a0, b0) T8_PIN()
+        T8_MM(a1, b1)
+        if (TUNE == 6 && more) { t8_stage(rsA, lnA, ldA, kA, nA, w); t8_stage(rsB, lnB, ldB, kB, nB, w); }
+#undef T8_LD
+#undef T8_MM
+#undef T8_PIN
+    } else if (TUNE == 3) {  // ablation: no DMA (wrong results): MFMA + fragment reads alone
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) t8_kstep(acc, pa, pb, rd.ch[ks]);
+    } else if (TUNE == 4) {  // ablation: DMA alone, one k-step keeps the accumulators live
+        if (more) { t8_stage(rsA, lnA, ldA, kA, nA, w); t8_stage(rsB, lnB, ldB, kB, nB, w); }
+        t8_kstep(acc, pa, pb, rd.ch[0]);
+    } else if (TUNE == 2) {
+        // DMA pieces spread over the first two k-steps of every wave
+        if (more) t8_stage(rsA, lnA, ldA, kA, nA, w);
+        __builtin_amdgcn_sched_barrier(0);
+        t8_kstep(acc, pa, pb, rd.ch[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) t8_stage(rsB, lnB, ldB, kB, nB, w);
+        __builtin_amdgcn_sched_barrier(0);
+        t8_kstep(acc, pa, pb, rd.ch[1]);
+        t8_kstep(acc, pa, pb, rd.ch[2]);
+        t8_kstep(acc, pa, pb, rd.ch[3]);
+    } else {
+        if (more) { t8_stage(rsA, lnA, ldA, kA, nA, w); t8_stage(rsB, lnB, ldB, kB, nB, w); }
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) t8_kstep(acc, pa, pb, rd.ch[ks]);
+    }
 }
 
 __device__ __forceinline__ void t8_zero(i32x16 (&acc)[4][2]) {
@@ -98,13 +168,21 @@ __device__ __forceinline__ void t8_zero(i32x16 (&acc)[4][2]) {
 // ------------------------------------------------------------------------------------------------
 // MM^T: grid.x = upper-triangular 256-tile pairs, grid.y = K splits.  Integer atomics: exact, any order.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 2) void k_syrk_i8(const int8_t* __restrict__ M8, long ld, int ntile, long nstages,
-                                                    long stages_per_split, int32_t* __restrict__ C, long ldc) {
+template <int TUNE>
+__global__ __launch_bounds__(512, 2) void k_syrk_i8(const int8_t* __restrict__ M8, long ld, const int* __restrict__ pairs,
+                                                    int npairs, int nblocks, long nstages, long stages_per_split,
+                                                    int32_t* __restrict__ C, long ldc) {
     __shared__ __attribute__((aligned(1024))) int8_t lds[2][2][TILE_BYTES];
-    int ti = 0, rem = blockIdx.x;
-    while (rem >= ntile - ti) { rem -= ntile - ti; ti++; }
-    const int tj = ti + rem;
-    const long s0 = (long)blockIdx.y * stages_per_split;
+    // XCD-aware order (speed only): workgroup b runs on XCD b%8 (observed dealing); give each XCD a contiguous range
+    // of the logical work list, which is ordered K-split major and, inside a split, by G x G super-tiles of the
+    // upper triangle, so the ~32 workgroups resident on one XCD stream the same few row/column panels of M8.
+    const int cpx = (gridDim.x + 7) / 8;
+    const int lid = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+    if (lid >= nblocks) return;
+    const int split = lid / npairs;
+    const int pr = pairs[lid - split * npairs];
+    const int ti = pr >> 16, tj = pr & 0xffff;
+    const long s0 = (long)split * stages_per_split;
     long s1 = s0 + stages_per_split;
     if (s1 > nstages) s1 = nstages;
     if (s0 >= s1) return;
@@ -121,12 +199,11 @@ __global__ __launch_bounds__(512, 2) void k_syrk_i8(const int8_t* __restrict__ M
     t8_stage(rsB, ln, ldi, (int)(s0 * BK8), lds[0][1], w);
     __syncthreads();
     int cur = 0;
+    const T8Read rd = t8_read_init(wr, wc, lane);
     for (long s = s0; s < s1; s++) {
-        if (s + 1 < s1) {
-            t8_stage(rsA, ln, ldi, (int)((s + 1) * BK8), lds[cur ^ 1][0], w);
-            t8_stage(rsB, ln, ldi, (int)((s + 1) * BK8), lds[cur ^ 1][1], w);
-        }
-        t8_compute(acc, lds[cur][0], lds[cur][1], wr, wc, lane);
+        const int kn = (int)((s + 1) * BK8);
+        t8_stage_compute<TUNE>(acc, lds[cur][0], lds[cur][1], rd, s + 1 < s1, rsA, ln, ldi, kn, lds[cur ^ 1][0], rsB, ln, ldi, kn,
+                               lds[cur ^ 1][1], w);
         __syncthreads();
         cur ^= 1;
     }
@@ -145,6 +222,133 @@ __global__ __launch_bounds__(512, 2) void k_syrk_i8(const int8_t* __restrict__ M
             }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Ring variant of the engine: the whole 160 KiB of LDS as 10 slots of 16 KiB (128 rows x 128 B of one operand).
+// A stage (K = 128 B) is 4 fills: A rows 0-127, A rows 128-255, B rows 0-127, B rows 128-255; fill f lives in slot
+// f % 10.  After the barrier of stage t the 4 slots of stage t-1 are refilled with fills 4t+6 .. 4t+9, so 6 fills
+// (96 KiB) are in flight under the MFMAs of stage t and every fill is issued 1.5 stages before its first read; a
+// counted s_waitcnt vmcnt(4) (2 fills x 2 DMA instructions per wave) retires exactly the fills of the next stage.
+// The 2-buffer form above must land 64 KiB inside one stage time; measured per-CU fill latency under load is
+// ~1.6 us for 64 KiB against ~1.0 us of matrix work, which is what this hides.
+// ------------------------------------------------------------------------------------------------
+#define R8_SLOTS 10
+#define R8_SLOT_BYTES (128 * BK8)
+
+__device__ __forceinline__ void r8_fill(__amdgpu_buffer_rsrc_t rs, const T8Lane& ln, int ld, int half, int k0, int8_t* slot, int w) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int grp = w * 2 + i;  // 16 groups of 8 rows; parity of grp == parity of i
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(slot + grp * 1024), 16,
+                                                 (i & 1) ? ln.voffO : ln.voffE, (half * 128 + grp * 8) * ld + k0, 0, 0);
+    }
+}
+__device__ __forceinline__ void r8_wait(int fills_ahead) {  // fills issued after the stage about to be read (0..2)
+    if (fills_ahead >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (fills_ahead == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+__device__ __forceinline__ int r8_slot(int s) { return s >= R8_SLOTS ? s - R8_SLOTS : s; }
+// compute one stage whose first fill sits in slot s0
+__device__ __forceinline__ void r8_compute(i32x16 (&acc)[4][2], const int8_t* lds, int s0, int wr, int wc, int lane) {
+    const int r = lane & 31, h = lane >> 5, swz = (r >> 1) & 7;
+    const int8_t* pa = lds + r8_slot(s0 + wr) * R8_SLOT_BYTES + r * BK8;
+    const int8_t* pb = lds + r8_slot(s0 + 2 + (wc >> 1)) * R8_SLOT_BYTES + ((wc & 1) * 64 + r) * BK8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) t8_kstep(acc, pa, pb, ((2 * ks + h) ^ swz) << 4);
+}
+
+__global__ __launch_bounds__(512, 2) void k_syrk_i8_ring(const int8_t* __restrict__ M8, long ld, const int* __restrict__ pairs,
+                                                         int npairs, int nblocks, long nstages, long stages_per_split,
+                                                         int32_t* __restrict__ C, long ldc) {
+    __shared__ __attribute__((aligned(1024))) int8_t lds[R8_SLOTS * R8_SLOT_BYTES];
+    const int cpx = (gridDim.x + 7) / 8;
+    const int lid = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+    if (lid >= nblocks) return;
+    const int split = lid / npairs;
+    const int pr = pairs[lid - split * npairs];
+    const int ti = pr >> 16, tj = pr & 0xffff;
+    const long st0 = (long)split * stages_per_split;
+    long st1 = st0 + stages_per_split;
+    if (st1 > nstages) st1 = nstages;
+    if (st0 >= st1) return;
+    const int nst = (int)(st1 - st0), F = 4 * nst;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = w >> 2, wc = w & 3;
+    const int ldi = (int)ld;
+    const T8Lane ln = t8_lane(lane, ldi);
+    const __amdgpu_buffer_rsrc_t rsA = t8_rsrc(M8 + (long)ti * T8 * ld, ldi);
+    const __amdgpu_buffer_rsrc_t rsB = t8_rsrc(M8 + (long)tj * T8 * ld, ldi);
+    const int kbase = (int)(st0 * BK8);
+    i32x16 acc[4][2];
+    t8_zero(acc);
+    // fill f: stage f>>2, part f&3 (0,1: A halves; 2,3: B halves), slot f % 10
+#define R8_ISSUE(f, slot_)                                                                                    \
+    do {                                                                                                      \
+        const int part_ = (f) & 3;                                                                            \
+        r8_fill(part_ < 2 ? rsA : rsB, ln, ldi, part_ & 1, kbase + ((f) >> 2) * BK8, lds + (slot_) * R8_SLOT_BYTES, w); \
+    } while (0)
+#pragma unroll
+    for (int f = 0; f < 6; f++)
+        if (f < F) R8_ISSUE(f, f);
+    int s0 = 0;
+    for (int st = 0; st < nst; st++) {
+        const int rem = F - (4 * st + 4);
+        r8_wait(rem < 2 ? (rem < 0 ? 0 : rem) : 2);
+#pragma unroll
+        for (int i = 6; i < 10; i++) {
+            const int f = 4 * st + i;
+            if (f < F) R8_ISSUE(f, r8_slot(s0 + i));
+        }
+        r8_compute(acc, lds, s0, wr, wc, lane);
+        s0 = r8_slot(s0 + 4);
+    }
+#undef R8_ISSUE
+    const int col = lane & 31, rq = 4 * (lane >> 5);
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                long i = (long)ti * T8 + wr * 128 + m * 32 + (q & 3) + 8 * (q >> 2) + rq;
+                long j = (long)tj * T8 + wc * 64 + n * 32 + col;
+                int v = acc[m][n][q];
+                if (v) atomicAdd(&C[i * ldc + j], v);
+            }
+}
+
+// Upper-triangular tile pairs (ti<<16 | tj) in super-tile order, cached on the device per tile count.
+#include <map>
+#include <vector>
+static std::map<std::pair<int, int>, int*> g_pair_tables;  // (device, nt) -> device table
+static int syrk_pair_table(eagle_ctx* ctx, int nt, const int** out, hipStream_t stream) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    auto key = std::make_pair(dev, nt);
+    auto it = g_pair_tables.find(key);
+    if (it != g_pair_tables.end()) { *out = it->second; return EAGLE_OK; }
+    const int G = 6;  // 6 x 6 tiles = 36 workgroups ~ one XCD's worth share 6 row panels + 6 column panels
+    std::vector<int> h;
+    for (int si = 0; si < nt; si += G)
+        for (int sj = si; sj < nt; sj += G)
+            for (int i = si; i < si + G && i < nt; i++)
+                for (int j = (sj > i ? sj : i); j < sj + G && j < nt; j++) h.push_back((i << 16) | j);
+    int* d = nullptr;
+    hipError_t e = hipMalloc((void**)&d, h.size() * sizeof(int));
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "pair table alloc");
+    e = hipMemcpy(d, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); return eagle_fail_hip(ctx, e, "pair table copy"); }
+    g_pair_tables[key] = d;
+    *out = d;
+    return EAGLE_OK;
+}
+
+// Experiment switch for the tile-engine schedule (tools/bench_i8_engine.py); 0 is the shipped default.
+static int g_tune = 0;
+extern "C" void eagle_dev_set_tune(int v) { g_tune = v; }
+
 extern "C" int eagle_dev_mmt_accumulate(eagle_ctx* ctx, const int8_t* M8, long n_pad, long L_pad, long ld, int32_t* C32,
                                         void* stream) {
     if (n_pad % T8 || L_pad % BK8 || ld % 128 || L_pad > ld || n_pad <= 0 || (double)ld * T8 >= 2147483648.0)
@@ -158,11 +362,25 @@ extern "C" int eagle_dev_mmt_accumulate(eagle_ctx* ctx, const int8_t* M8, long n
     long maxsplit = nstages / 16 > 0 ? nstages / 16 : 1;
     long nsplit = want < maxsplit ? want : maxsplit;
     if (nsplit < 1) nsplit = 1;
-    if (nsplit > 65535) nsplit = 65535;
     long per = (nstages + nsplit - 1) / nsplit;
     nsplit = (nstages + per - 1) / per;
-    dim3 grid((unsigned)npairs, (unsigned)nsplit);
-    hipLaunchKernelGGL(k_syrk_i8, grid, dim3(512), 0, (hipStream_t)stream, M8, ld, nt, nstages, per, C32, n_pad);
+    const long nblocks = npairs * nsplit;
+    if (nblocks >= (1L << 30)) return eagle_fail(ctx, EAGLE_ERR_ARG, "mmt_accumulate: too many workgroups");
+    const int* pairs = nullptr;
+    int rc = syrk_pair_table(ctx, nt, &pairs, (hipStream_t)stream);
+    if (rc) return rc;
+    dim3 grid((unsigned)((nblocks + 7) / 8 * 8));
+#define SYRK_LAUNCH(T) hipLaunchKernelGGL(k_syrk_i8<T>, grid, dim3(512), 0, (hipStream_t)stream, M8, ld, pairs, (int)npairs, (int)nblocks, nstages, per, C32, n_pad)
+    switch (g_tune) {
+        case 1: SYRK_LAUNCH(1); break;
+        case 2: SYRK_LAUNCH(2); break;
+        case 3: SYRK_LAUNCH(3); break;
+        case 4: SYRK_LAUNCH(4); break;
+        case 5: SYRK_LAUNCH(5); break;
+        case 10: hipLaunchKernelGGL(k_syrk_i8_ring, grid, dim3(512), 0, (hipStream_t)stream, M8, ld, pairs, (int)npairs, (int)nblocks, nstages, per, C32, n_pad); break;
+        default: SYRK_LAUNCH(0);
+    }
+#undef SYRK_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "k_syrk_i8");
     return EAGLE_OK;
@@ -194,33 +412,82 @@ extern "C" int eagle_dev_mmt_accumulate(eagle_ctx* ctx, const int8_t* M8, long n
 // workers meet in q[s][i] by int64 atomics (one flush per worker).
 // ================================================================================================
 
-__global__ __launch_bounds__(256) void k_absmax(const double* __restrict__ x, long n, unsigned long long* __restrict__ bits) {
+struct VaraHdr {        // head of the workspace, written on the device, never read by the host
+    double maxabs_off;  // max |Wu[j][k]|, j != k
+    int S;              // digit slices in use
+    int pad;
+    double bound;       // n_pad^2 * 2^(e+1-8S): absolute error bound of every vara_i
+    double sumdiag;     // sum_k |Wu[k][k]|
+};
+
+__global__ __launch_bounds__(256) void k_absmax_offdiag(const double* __restrict__ x, long np, unsigned long long* __restrict__ bits) {
     double m = 0.0;
+    const long n = np * np;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         double v = fabs(x[i]);
-        m = v > m ? v : m;  // NaN never wins
+        if (i % (np + 1) == 0) v = 0.0;  // the diagonal is handled in fp64 (k_vara_prep / gemv_sq)
+        m = v > m ? v : m;                // NaN never wins
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { double y = __shfl_down(m, o); m = y > m ? y : m; }
     if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(bits, (unsigned long long)__double_as_longlong(m));
 }
 
-// Bs[s][k][j] = digit s of Wu[j][k].  32x32 tiles through LDS so both sides are coalesced.
-__global__ __launch_bounds__(256) void k_slice_w(const double* __restrict__ Wu, long np, const double* __restrict__ maxabs,
-                                                 int nslices, int8_t* __restrict__ Bs) {
+// One block: dW[k] = Wu[k][k] (contiguous copy), sumdiag in a fixed order, then the slice count.
+// forced = 0: smallest S in 3..7 whose bound n^2 * 2^(e+1-8S) is below 1e-9 of the typical vara, taken as
+// 0.5 * sum_k |W_kk| (the diagonal term of a marker with half of its genotypes non-zero); forced = 1..8: that S.
+__global__ __launch_bounds__(256) void k_vara_prep(const double* __restrict__ Wu, long n_pad, int forced, VaraHdr* __restrict__ hdr,
+                                                   double* __restrict__ dW) {
+    double s = 0.0;
+    for (long k = threadIdx.x; k < n_pad; k += 256) {
+        double d = Wu[k * n_pad + k];
+        dW[k] = d;
+        s += fabs(d);
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int e = 0;
+        const double mx = hdr->maxabs_off;
+        if (mx > 0.0) (void)frexp(mx, &e);
+        const double nn = (double)n_pad * (double)n_pad;
+        int S = forced;
+        if (S <= 0) {
+            const double target = 1e-9 * 0.5 * red[0];
+            S = 7;
+            for (int c = 3; c <= 7; c++)
+                if (ldexp(nn, e + 1 - 8 * c) <= target) { S = c; break; }
+        }
+        if (mx == 0.0) S = 1;
+        hdr->S = S;
+        hdr->sumdiag = red[0];
+        hdr->bound = mx > 0.0 ? ldexp(nn, e + 1 - 8 * S) : 0.0;
+    }
+}
+
+// Bs[s][k][j] = digit s of Wu[j][k] (j != k; the diagonal goes through dW).  32x32 tiles through LDS so both sides
+// are coalesced.
+__global__ __launch_bounds__(256) void k_slice_w(const double* __restrict__ Wu, long np, const VaraHdr* __restrict__ hdr,
+                                                 int8_t* __restrict__ Bs) {
     __shared__ double tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const long bj = (long)blockIdx.y * 32, bk = (long)blockIdx.x * 32;
     for (int r = ty; r < 32; r += 8) tile[r][tx] = Wu[(bj + r) * np + bk + tx];  // tile[jj][kk]
     __syncthreads();
     int e = 0;
-    const double mx = *maxabs;
+    const double mx = hdr->maxabs_off;
+    const int nslices = hdr->S;
     if (mx > 0.0) { (void)frexp(mx, &e); }  // mx = f * 2^e, f in [0.5,1)  ->  mx < 2^e
     for (int r = ty; r < 32; r += 8) {
         // output element (k = bk + r, j = bj + tx):  Q = round(Wu * 2^(8S - e - 2)) is an exact integer below 2^(8S-2)
         // (llrint of a double of that size is exact); its balanced base-256 digits, least significant first,
         // d = ((Q + 128) mod 256) - 128 in [-128,127], Q <- (Q - d)/256; the leading digit ends in [-65,65].
-        long long Q = llrint(ldexp(tile[tx][r], 8 * nslices - (e + 2)));
+        long long Q = (bk + r == bj + tx) ? 0 : llrint(ldexp(tile[tx][r], 8 * nslices - (e + 2)));
         for (int s = nslices - 1; s >= 0; s--) {
             long long d = ((Q + 128) & 255) - 128;
             Q = (Q - d) >> 8;
@@ -252,11 +519,12 @@ __device__ __forceinline__ void vit_advance(VaraIt& it, int nct, int npair) {
 }
 
 __global__ __launch_bounds__(512, 2) void k_vara_i8(const int8_t* __restrict__ Mt8, long ld, int ntm, const int8_t* __restrict__ Bs,
-                                                    long np, int nslices, long long* __restrict__ q, long Lp) {
+                                                    long np, const VaraHdr* __restrict__ hdr, long long* __restrict__ q, long Lp) {
     __shared__ __attribute__((aligned(1024))) int8_t lds[2][2][TILE_BYTES];
     // XCD-aware placement (speed only): b -> (xcd, slot); slot -> (marker tile within the XCD's sequence, worker)
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
+    const int nslices = hdr->S;  // the grid is sized for the largest slice count; surplus workgroups leave here
     const int mt = (slot / nslices) * 8 + xcd, sl = slot % nslices;  // worker = digit slice
     if (mt >= ntm) return;
     const int nct = (int)(np / T8), npair = (nct + 1) / 2;
@@ -338,56 +606,65 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8(const int8_t* __restrict__ M
         if ((lane & 16) == 0 && keep[m]) atomicAdd((unsigned long long*)&qs[m * 32], (unsigned long long)keep[m]);
 }
 
-__global__ __launch_bounds__(256) void k_vara_i8_finish(const long long* __restrict__ q, long Lp, int nslices,
-                                                        const double* __restrict__ maxabs, double* __restrict__ vara) {
+__global__ __launch_bounds__(256) void k_vara_i8_finish(const long long* __restrict__ q, long Lp, const VaraHdr* __restrict__ hdr,
+                                                        const double* __restrict__ vdiag, double* __restrict__ vara) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= Lp) return;
     int e = 0;
-    const double mx = *maxabs;
+    const double mx = hdr->maxabs_off;
+    const int nslices = hdr->S;
     if (mx > 0.0) (void)frexp(mx, &e);
     double s = 0.0;
     for (int k = nslices - 1; k >= 0; k--) s += ldexp((double)q[(long)k * Lp + i], e + 2 - 8 * (k + 1));  // smallest first
-    vara[i] = s;
+    vara[i] = vdiag[i] + s;  // diagonal term sum_k m_ik^2 W_kk (fp64) + exact-integer off-diagonal term
 }
 
-__global__ void k_vara_i8_bound(const double* __restrict__ maxabs, long n, int nslices, double* __restrict__ out) {
-    int e = 0;
-    const double mx = *maxabs;
-    if (mx > 0.0) (void)frexp(mx, &e);
-    *out = ldexp((double)n * (double)n, e + 1 - 8 * nslices);  // (sum_j |m_ij|)^2 <= n^2
+__global__ void k_vara_i8_bound(const VaraHdr* __restrict__ hdr, double* __restrict__ out, int* __restrict__ slices_out) {
+    *out = hdr->bound;
+    if (slices_out) *slices_out = hdr->S;
 }
 
-// workspace: [ maxabs (8 B, padded to 256) | q: nslices*L_pad int64 | Bs: nslices*n_pad*n_pad int8 ]
+// workspace: [ VaraHdr (padded to 256) | q: Smax*L_pad int64 | dW: n_pad f64 | vdiag: L_pad f64 | Bs: Smax*n_pad*n_pad int8 ]
+#define VARA_SMAX_AUTO 7
+static int ws_smax(int nslices) { return nslices > 0 ? nslices : VARA_SMAX_AUTO; }
 static size_t ws_q_off() { return 256; }
-static size_t ws_bs_off(long L_pad, int nslices) { return (256 + (size_t)nslices * L_pad * 8 + 255) / 256 * 256; }
+static size_t ws_dw_off(long L_pad, int smax) { return 256 + (size_t)smax * L_pad * 8; }
+static size_t ws_vd_off(long n_pad, long L_pad, int smax) { return ws_dw_off(L_pad, smax) + (size_t)n_pad * 8; }
+static size_t ws_bs_off(long n_pad, long L_pad, int smax) { return (ws_vd_off(n_pad, L_pad, smax) + (size_t)L_pad * 8 + 255) / 256 * 256; }
 
 extern "C" int64_t eagle_vara_i8_workspace_bytes(long n_pad, long L_pad, int nslices) {
-    return (int64_t)(ws_bs_off(L_pad, nslices) + (size_t)nslices * n_pad * n_pad);
+    const int smax = ws_smax(nslices);
+    return (int64_t)(ws_bs_off(n_pad, L_pad, smax) + (size_t)smax * n_pad * n_pad);
 }
 
 extern "C" int eagle_dev_vara_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu,
                                  int nslices, void* ws, double* vara_out, double* err_bound_dev, void* stream) {
-    if (L_pad % T8 || n_pad % T8 || ld % 128 || n_pad > ld || nslices < 1 || nslices > 8 || (double)ld * T8 >= 2147483648.0)
-        return eagle_fail(ctx, EAGLE_ERR_ARG, "vara_i8: layout contract violated (L_pad % 256, n_pad % 256, 1 <= nslices <= 8)");
+    if (L_pad % T8 || n_pad % T8 || ld % 128 || n_pad > ld || nslices < 0 || nslices > 8 || (double)ld * T8 >= 2147483648.0)
+        return eagle_fail(ctx, EAGLE_ERR_ARG, "vara_i8: layout contract violated (L_pad % 256, n_pad % 256, 0 <= nslices <= 8)");
     // int32 tile row-sum: 64 columns per wave x |T*m| <= 128*n_pad each (accumulation across tiles is int64)
     if (64.0 * 128.0 * (double)n_pad >= 2147483648.0)
         return eagle_fail(ctx, EAGLE_ERR_ARG, "vara_i8: n too large for the int32 per-slice partial sums; use the fp64 kernel");
     if (L_pad == 0) return EAGLE_OK;
     hipStream_t s = (hipStream_t)stream;
-    double* maxabs = (double*)ws;
+    const int smax = ws_smax(nslices);
+    VaraHdr* hdr = (VaraHdr*)ws;
     long long* q = (long long*)((char*)ws + ws_q_off());
-    int8_t* Bs = (int8_t*)((char*)ws + ws_bs_off(L_pad, nslices));
-    hipError_t e = hipMemsetAsync(ws, 0, ws_bs_off(L_pad, nslices), s);  // maxabs and q
+    double* dW = (double*)((char*)ws + ws_dw_off(L_pad, smax));
+    double* vdiag = (double*)((char*)ws + ws_vd_off(n_pad, L_pad, smax));
+    int8_t* Bs = (int8_t*)((char*)ws + ws_bs_off(n_pad, L_pad, smax));
+    hipError_t e = hipMemsetAsync(ws, 0, ws_dw_off(L_pad, smax), s);  // header and q
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "vara_i8 memset");
-    hipLaunchKernelGGL(k_absmax, dim3(1024), dim3(256), 0, s, Wu, n_pad * n_pad, (unsigned long long*)maxabs);
+    hipLaunchKernelGGL(k_absmax_offdiag, dim3(1024), dim3(256), 0, s, Wu, n_pad, (unsigned long long*)&hdr->maxabs_off);
+    hipLaunchKernelGGL(k_vara_prep, dim3(1), dim3(256), 0, s, Wu, n_pad, nslices, hdr, dW);
+    int rc = eagle_dev_gemv_i8_sq(ctx, Mt8, L_pad, n_pad, ld, dW, vdiag, stream);  // sum_k m_ik^2 W_kk in fp64
+    if (rc) return rc;
     dim3 g2((unsigned)(n_pad / 32), (unsigned)(n_pad / 32));
-    hipLaunchKernelGGL(k_slice_w, g2, dim3(256), 0, s, Wu, n_pad, maxabs, nslices, Bs);
+    hipLaunchKernelGGL(k_slice_w, g2, dim3(256), 0, s, Wu, n_pad, hdr, Bs);
     const int ntm = (int)(L_pad / T8);
     const int groups = (ntm + 7) / 8;
-    hipLaunchKernelGGL(k_vara_i8, dim3((unsigned)(groups * 8 * nslices)), dim3(512), 0, s, Mt8, ld, ntm, Bs, n_pad, nslices, q, L_pad);
-    hipLaunchKernelGGL(k_vara_i8_finish, dim3((unsigned)((L_pad + 255) / 256)), dim3(256), 0, s, q, L_pad, nslices, maxabs,
-                       vara_out);
-    if (err_bound_dev) hipLaunchKernelGGL(k_vara_i8_bound, dim3(1), dim3(1), 0, s, maxabs, n_pad, nslices, err_bound_dev);
+    hipLaunchKernelGGL(k_vara_i8, dim3((unsigned)(groups * 8 * smax)), dim3(512), 0, s, Mt8, ld, ntm, Bs, n_pad, hdr, q, L_pad);
+    hipLaunchKernelGGL(k_vara_i8_finish, dim3((unsigned)((L_pad + 255) / 256)), dim3(256), 0, s, q, L_pad, hdr, vdiag, vara_out);
+    if (err_bound_dev) hipLaunchKernelGGL(k_vara_i8_bound, dim3(1), dim3(1), 0, s, hdr, err_bound_dev, (int*)nullptr);
     e = hipGetLastError();
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "vara_i8");
     return EAGLE_OK;

@@ -358,6 +358,7 @@ __global__ __launch_bounds__(256) void k_colgemv(const double* __restrict__ At, 
 // genotype bytes per row per step (coalesced 1 KiB per wave-instruction) and the 16 matching v values,
 // then a wavefront shuffle reduction.  HBM-bound on the genotype bytes.
 // ------------------------------------------------------------------------------------------------
+template <bool SQ>  // SQ: sum_j Mt8[i][j]^2 v[j] (the diagonal term of the quadratic form)
 __global__ __launch_bounds__(256) void k_gemv_i8(const int8_t* __restrict__ Mt8, long L_pad, long n_pad, long ld,
                                                  const double* __restrict__ v, double scale, double* __restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(256) void k_gemv_i8(const int8_t* __restrict__ Mt8,
 #pragma unroll
             for (int r = 0; r < 4; r++)
 #pragma unroll
-                for (int q = 0; q < 16; q++) s[r] += (double)m[r].b[q] * vv[q];
+                for (int q = 0; q < 16; q++) s[r] += (double)(SQ ? m[r].b[q] * m[r].b[q] : (int)m[r].b[q]) * vv[q];
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -600,8 +601,20 @@ extern "C" int eagle_dev_gemv_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, 
     long waves = L_pad / 4;
     long blocks = (waves + 3) / 4;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(k_gemv_i8, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, Mt8, L_pad, n_pad, ld, v,
+    hipLaunchKernelGGL(k_gemv_i8<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, Mt8, L_pad, n_pad, ld, v,
                        scale, out);
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+
+extern "C" int eagle_dev_gemv_i8_sq(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* v,
+                                    double* out, void* stream) {
+    if (L_pad % 4 || n_pad % 16 || ld % 16 || n_pad > ld) return eagle_fail(ctx, EAGLE_ERR_ARG, "gemv_i8_sq: layout contract violated");
+    if (L_pad == 0) return EAGLE_OK;
+    long blocks = (L_pad / 4 + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_gemv_i8<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, Mt8, L_pad, n_pad, ld, v,
+                       1.0, out);
     LAUNCH_CHECK(ctx);
     return EAGLE_OK;
 }

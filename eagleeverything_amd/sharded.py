@@ -94,7 +94,7 @@ class DeviceShard:
         self.Sa = self.Va = self.ahat = self.v = self.Wu = self.tmp = None
         self.ws = None
         self.mode = 0
-        self.nslices = 7
+        self.nslices = 0  # 0 = chosen by the library from its error bound
 
     # ---- plumbing -------------------------------------------------------------------------------
     def _stream(self):
@@ -204,6 +204,12 @@ class DeviceShard:
             self._check(self.L.eagle_dev_vara_i8(self.ctx, self.Mt8.data_ptr(), self.Lp, self.np_, self.np_,
                                                  self.Wu.data_ptr(), self.nslices, self.ws.data_ptr(), self.vara.data_ptr(),
                                                  None, self._stream()))
+
+    def vara_i8_info(self):
+        """(slices used, absolute error bound, max |off-diagonal W|) of the last int8-slice vara launch (synchronises)."""
+        h = self.ws[:32].cpu().numpy().tobytes()
+        return (int(np.frombuffer(h[8:12], dtype=np.int32)[0]), float(np.frombuffer(h[16:24], dtype=np.float64)[0]),
+                float(np.frombuffer(h[0:8], dtype=np.float64)[0]))
 
     def argmax(self):
         self._check(self.L.eagle_dev_tsq_argmax(self.ctx, self.a.data_ptr(), self.vara.data_ptr(), self.Lloc, None,

@@ -58,8 +58,10 @@ void eagle_drop_cache(eagle_ctx* ctx);
 int eagle_device_info(eagle_ctx* ctx, char* arch_out, int arch_len, int* cu_count, int64_t* hbm_bytes);
 /* vara kernel: 1 (default) = exact int8 digit slices of W on v_mfma_i32_32x32x32_i8, 0 = fp64 MFMA
  * (v_mfma_f64_16x16x4_f64; also taken automatically when n is too large for the int32 tile sums).
- * eagle_set_scan_slices: S in 1..8 base-256 digits of W (default 7 = the whole 53-bit mantissa of max|W|);
- * every vara_i then differs from the exact m_i^T W m_i by at most (sum_j |m_ij|)^2 * 2^(e+1-8S), max|W| < 2^e. */
+ * eagle_set_scan_slices: S = 1..8 base-256 digits of the off-diagonal part of W, or 0 (default) = chosen per call:
+ * the smallest S in 3..7 whose bound is below 1e-9 of the typical vara (0.5 * sum_k |W_kk|).  The diagonal term
+ * sum_k m_ik^2 W_kk is evaluated in fp64; every vara_i then differs from the exact m_i^T W m_i by at most
+ * (sum_j |m_ij|)^2 * 2^(e+1-8S), max_{j!=k} |W_jk + W_kj| < 2^e, plus fp64 rounding of an n-term and an S-term sum. */
 int eagle_set_scan_mode(eagle_ctx* ctx, int mode);
 int eagle_set_scan_slices(eagle_ctx* ctx, int nslices);
 
@@ -171,9 +173,11 @@ int eagle_dev_gemv_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad,
 /* vara_i = m_i^T W m_i for L_pad rows (calculate_a_and_vara_rcpp.cpp:103-112), fp64 MFMA kernel. */
 int eagle_dev_vara_f64(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu,
                        double* vara_out, void* stream);
-/* Same result from int8 slices of Wu on the int8 MFMA (exact integer partial sums).
- * ws: workspace, eagle_vara_i8_workspace_bytes(n_pad, L_pad, nslices) bytes.
- * err_bound_dev (device double, may be NULL): certified absolute error bound of every vara_i. */
+/* Same result from int8 digit slices of the off-diagonal part of Wu on the int8 MFMA (exact integer partial sums)
+ * plus the fp64 diagonal term.  nslices: 0 = automatic (see eagle_set_scan_slices), 1..8 = fixed.
+ * ws: workspace, eagle_vara_i8_workspace_bytes(n_pad, L_pad, nslices) bytes; its first 32 bytes are written by the
+ * device as { double max|offdiag|; int32 S_used; int32 pad; double bound; double sum|diag| }.
+ * err_bound_dev (device double, may be NULL): the absolute error bound n_pad^2 * 2^(e+1-8S) of every vara_i. */
 int64_t eagle_vara_i8_workspace_bytes(long n_pad, long L_pad, int nslices);
 int eagle_dev_vara_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu,
                       int nslices, void* ws, double* vara_out, double* err_bound_dev, void* stream);
