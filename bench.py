@@ -170,7 +170,10 @@ def main():
         sh.scan_operands()
         if i is not None:
             ev_gemv[i][0].record()
-        sh.gemv_a()
+        if sh.mode == 0:
+            sh.gemv_a()
+        else:
+            sh.vara_prepare()  # slices W; one genotype pass for a = Mt v and the diagonal term of vara
         if i is not None:
             ev_gemv[i][1].record()
             ev[i][0].record()
@@ -214,7 +217,7 @@ def main():
     roof["reference_flops_per_launch"] = 2.0 * Lloc * n * n + 2.0 * Lloc * n
     roof["fp64_equiv_tflops"] = roof["reference_flops_per_launch"] / kern_s / 1e12
     secondary = {
-        "gemv_a": {"bound": "hbm", "achieved": Lp * np_ / gemv_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "genotype_pass (a = Mt v%s)" % ("" if sh.mode == 0 else " + diagonal term + slicing of W"): {"bound": "hbm", "achieved": Lp * np_ / gemv_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": Lp * np_ / gemv_s / 1e9 / HBM_PEAK_GBS, "kernel_ms": gemv_s * 1e3},
         "syrk_i8": {"bound": "mfma", "achieved": (np_ * (np_ + 128.0)) * Lp / syrk_s / 1e12, "peak": I8_MFMA_PEAK_TOPS,
                     "unit": "TFLOP/s", "frac": (np_ * (np_ + 128.0)) * Lp / syrk_s / 1e12 / I8_MFMA_PEAK_TOPS,

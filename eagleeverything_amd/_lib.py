@@ -61,6 +61,10 @@ SIGNATURES = {
     "eagle_vara_i8_workspace_bytes": (C.c_int64, [C.c_long, C.c_long, C.c_int]),
     "eagle_dev_vara_i8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_int,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eagle_dev_vara_i8_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_int,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eagle_dev_vara_i8_mfma": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]),
     "eagle_dev_zero_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_long,
                                       C.c_void_p]),
     "eagle_dev_tsq_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p,

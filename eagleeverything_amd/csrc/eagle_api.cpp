@@ -52,6 +52,7 @@ struct eagle_ctx {
     // results of the last calls, kept in HBM
     double* d_mmt = nullptr; long mmt_n = 0; double* d_mmt_max = nullptr;
     double* d_a = nullptr; double* d_vara = nullptr; long scan_L = 0; long scan_cap = 0;
+    void* d_scratch = nullptr;
     char arch[64] = {0};
     int cu_count = 0;
     int64_t hbm_bytes = 0;
@@ -138,6 +139,11 @@ extern "C" eagle_ctx* eagle_open(int device) {
     snprintf(ctx->arch, sizeof ctx->arch, "%s", prop.gcnArchName);
     ctx->cu_count = prop.multiProcessorCount;
     ctx->hbm_bytes = (int64_t)prop.totalGlobalMem;
+    if ((e = hipMalloc(&ctx->d_scratch, 4096)) != hipSuccess) {
+        snprintf(g_open_err, sizeof g_open_err, "hipMalloc: %s", hipGetErrorString(e));
+        delete ctx;
+        return nullptr;
+    }
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
         snprintf(g_open_err, sizeof g_open_err, "hipStreamCreate: %s", hipGetErrorString(e));
         delete ctx;
@@ -162,10 +168,12 @@ extern "C" void eagle_close(eagle_ctx* ctx) {
     if (ctx->d_mmt_max) (void)hipFree(ctx->d_mmt_max);
     if (ctx->d_a) (void)hipFree(ctx->d_a);
     if (ctx->d_vara) (void)hipFree(ctx->d_vara);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
+extern "C" void* eagle_ctx_scratch(eagle_ctx* ctx) { return ctx->d_scratch; }
 extern "C" const char* eagle_last_error(eagle_ctx* ctx) { return ctx ? ctx->err : g_open_err; }
 extern "C" void eagle_set_message_callback(eagle_ctx* ctx, eagle_message_fn fn, void* user) {
     if (ctx) { ctx->msg_fn = fn; ctx->msg_user = user; }
@@ -601,13 +609,17 @@ extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_asc
     rc = eagle_dev_scan_operands(ctx, Sa.as<double>(), Va.as<double>(), ah.as<double>(), n, np, v.as<double>(), Wu.as<double>(),
                                  tmp.as<double>(), ctx->stream);
     if (rc) return rc;
-    rc = eagle_dev_gemv_i8(ctx, g->dev, Lp, np, g->ld, v.as<double>(), 1.0, ctx->d_a, ctx->stream);
-    if (rc) return rc;
     if (ctx->scan_mode == 1 && 64.0 * 128.0 * (double)np < 2147483648.0) {
         const int nslices = ctx->scan_slices;
         HIPCHK(ctx, ws.alloc((size_t)eagle_vara_i8_workspace_bytes(np, Lp, nslices)));
-        rc = eagle_dev_vara_i8(ctx, g->dev, Lp, np, g->ld, Wu.as<double>(), nslices, ws.p, ctx->d_vara, nullptr, ctx->stream);
+        // one pass over the genotypes gives a = Mt v and the diagonal term of vara; then the int8 MFMA kernel
+        rc = eagle_dev_vara_i8_prepare(ctx, g->dev, Lp, np, g->ld, Wu.as<double>(), nslices, ws.p, v.as<double>(), ctx->d_a,
+                                       ctx->stream);
+        if (rc) return rc;
+        rc = eagle_dev_vara_i8_mfma(ctx, g->dev, Lp, np, g->ld, nslices, ws.p, ctx->d_vara, nullptr, ctx->stream);
     } else {
+        rc = eagle_dev_gemv_i8(ctx, g->dev, Lp, np, g->ld, v.as<double>(), 1.0, ctx->d_a, ctx->stream);
+        if (rc) return rc;
         rc = eagle_dev_vara_f64(ctx, g->dev, Lp, np, g->ld, Wu.as<double>(), ctx->d_vara, ctx->stream);
     }
     if (rc) return rc;

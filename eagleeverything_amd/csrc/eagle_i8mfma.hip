@@ -85,10 +85,15 @@ __device__ __forceinline__ void t8_compute(i32x16 (&acc)[4][2], const int8_t* ld
     for (int ks = 0; ks < 4; ks++) t8_kstep(acc, ldsA + rd.offA, ldsB + rd.offB, rd.ch[ks]);
 }
 
-// One pipeline stage: compute stage `cur` from (ldsA, ldsB) and, if `more`, DMA the next stage into (nA, nB).
-// Waves w and w+4 share a SIMD.  In lock-step both would first spend their issue slots on the 8 DMA pieces and then
-// both queue MFMAs; staggered (TUNE 1), the younger half runs half of its MFMAs first, so one partner's DMA issue
-// overlaps the other's matrix work.
+// One pipeline stage: DMA the next stage into (nA, nB) if `more`, then the 4 k-steps of the current stage.
+// TUNE 3 / 4 are ablations for tools/bench_i8_engine.py (3: no DMA, 4: DMA + one k-step); results are wrong there.
+// Measured on the MM^T SYRK (n = 5000, L = 262144, same process, interleaved): full 2.93 ms, no-DMA 2.32 ms, DMA-only
+// 2.78 ms: the kernel is bound by the L2 -> LDS fill rate (~40 GB/s per CU at a 70-80 % L2 hit rate), not by MFMA issue.
+// Tried and NOT faster (kept out of the code): staggering the DMA issue of waves 4-7 by half a stage (-13 %), spreading
+// the DMA pieces over the k-steps (+-2 %), software-pipelined fragment reads pinned with sched_group_barrier (-3 %),
+// a 10-slot 160 KiB LDS ring with 96 KiB in flight and counted vmcnt (-3 %; DMA-only 2.55 ms), a 4-deep ring of 64-byte
+// K stages (-9 %), tile-major pre-swizzled operand copies so that every DMA instruction reads 1 KiB of consecutive
+// bytes (+-1 %), odd leading dimensions against channel aliasing (+-1 %).
 template <int TUNE>
 __device__ __forceinline__ void t8_stage_compute(i32x16 (&acc)[4][2], const int8_t* ldsA, const int8_t* ldsB, const T8Read& rd,
                                                  bool more, __amdgpu_buffer_rsrc_t rsA, const T8Lane& lnA, int ldA, int kA,
@@ -96,64 +101,9 @@ __device__ __forceinline__ void t8_stage_compute(i32x16 (&acc)[4][2], const int8
                                                  int8_t* nB, int w) {
     const int8_t* pa = ldsA + rd.offA;
     const int8_t* pb = ldsB + rd.offB;
-    if (TUNE == 1) {
-        // the k-steps are common code; only the position of the DMA block depends on the wave half (scalar branch)
-        if (more && w < 4) { t8_stage(rsA, lnA, ldA, kA, nA, w); t8_stage(rsB, lnB, ldB, kB, nB, w); }
-        __builtin_amdgcn_sched_barrier(0);
-        t8_kstep(acc, pa, pb, rd.ch[0]);
-        t8_kstep(acc, pa, pb, rd.ch[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more && w >= 4) { t8_stage(rsA, lnA, ldA, kA, nA, w); t8_stage(rsB, lnB, ldB, kB, nB, w); }
-        __builtin_amdgcn_sched_barrier(0);
-        t8_kstep(acc, pa, pb, rd.ch[2]);
-        t8_kstep(acc, pa, pb, rd.ch[3]);
-    } else if (TUNE == 5 || TUNE == 6) {
-        // software-pipelined fragments: the 6 ds_read_b128 of k-step ks+1 are pinned between the 8 MFMAs of k-step ks
-        if (TUNE == 5 && more) { t8_stage(rsA, lnA, ldA, kA, nA, w); t8_stage(rsB, lnB, ldB, kB, nB, w); }
-        i32x4 a0[4], b0[2], a1[4], b1[2];
-#define T8_LD(A_, B_, KS)                                                                   \
-    _Pragma("unroll") for (int m = 0; m < 4; m++) A_[m] = *(const i32x4*)(pa + m * (32 * BK8) + rd.ch[KS]); \
-    _Pragma("unroll") for (int n = 0; n < 2; n++) B_[n] = *(const i32x4*)(pb + n * (32 * BK8) + rd.ch[KS]);
-#define T8_MM(A_, B_)                                                                       \
-    _Pragma("unroll") for (int m = 0; m < 4; m++)                                           \
-        _Pragma("unroll") for (int n = 0; n < 2; n++) acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A_[m], B_[n], acc[m][n], 0, 0, 0);
-#define T8_PIN()                                                                            \
-    _Pragma("unroll") for (int i = 0; i < 6; i++) {                                         \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                  \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                  \
-    }                                                                                       \
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        T8_LD(a0, b0, 0)
-        T8_LD(a1, b1, 1) T8_MM(a0, b0) T8_PIN()
-        T8_LD(a0, b0, 2) T8_MM(a1, b1) T8_PIN()
-        T8_LD(a1, b1, 3) T8_MM(a0, b0) T8_PIN()
-        T8_MM(a1, b1)
-        if (TUNE == 6 && more) { t8_stage(rsA, lnA, ldA, kA, nA, w); t8_stage(rsB, lnB, ldB, kB, nB, w); }
-#undef T8_LD
-#undef T8_MM
-#undef T8_PIN
-    } else if (TUNE == 3) {  // ablation: no DMA (wrong results): MFMA + fragment reads alone
+    if (TUNE != 3 && more) { t8_stage(rsA, lnA, ldA, kA, nA, w); t8_stage(rsB, lnB, ldB, kB, nB, w); }
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++) t8_kstep(acc, pa, pb, rd.ch[ks]);
-    } else if (TUNE == 4) {  // ablation: DMA alone, one k-step keeps the accumulators live
-        if (more) { t8_stage(rsA, lnA, ldA, kA, nA, w); t8_stage(rsB, lnB, ldB, kB, nB, w); }
-        t8_kstep(acc, pa, pb, rd.ch[0]);
-    } else if (TUNE == 2) {
-        // DMA pieces spread over the first two k-steps of every wave
-        if (more) t8_stage(rsA, lnA, ldA, kA, nA, w);
-        __builtin_amdgcn_sched_barrier(0);
-        t8_kstep(acc, pa, pb, rd.ch[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) t8_stage(rsB, lnB, ldB, kB, nB, w);
-        __builtin_amdgcn_sched_barrier(0);
-        t8_kstep(acc, pa, pb, rd.ch[1]);
-        t8_kstep(acc, pa, pb, rd.ch[2]);
-        t8_kstep(acc, pa, pb, rd.ch[3]);
-    } else {
-        if (more) { t8_stage(rsA, lnA, ldA, kA, nA, w); t8_stage(rsB, lnB, ldB, kB, nB, w); }
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++) t8_kstep(acc, pa, pb, rd.ch[ks]);
-    }
+    for (int ks = 0; ks < (TUNE == 4 ? 1 : 4); ks++) t8_kstep(acc, pa, pb, rd.ch[ks]);
 }
 
 __device__ __forceinline__ void t8_zero(i32x16 (&acc)[4][2]) {
@@ -222,103 +172,6 @@ __global__ __launch_bounds__(512, 2) void k_syrk_i8(const int8_t* __restrict__ M
             }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Ring variant of the engine: the whole 160 KiB of LDS as 10 slots of 16 KiB (128 rows x 128 B of one operand).
-// A stage (K = 128 B) is 4 fills: A rows 0-127, A rows 128-255, B rows 0-127, B rows 128-255; fill f lives in slot
-// f % 10.  After the barrier of stage t the 4 slots of stage t-1 are refilled with fills 4t+6 .. 4t+9, so 6 fills
-// (96 KiB) are in flight under the MFMAs of stage t and every fill is issued 1.5 stages before its first read; a
-// counted s_waitcnt vmcnt(4) (2 fills x 2 DMA instructions per wave) retires exactly the fills of the next stage.
-// The 2-buffer form above must land 64 KiB inside one stage time; measured per-CU fill latency under load is
-// ~1.6 us for 64 KiB against ~1.0 us of matrix work, which is what this hides.
-// ------------------------------------------------------------------------------------------------
-#define R8_SLOTS 10
-#define R8_SLOT_BYTES (128 * BK8)
-
-__device__ __forceinline__ void r8_fill(__amdgpu_buffer_rsrc_t rs, const T8Lane& ln, int ld, int half, int k0, int8_t* slot, int w) {
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int grp = w * 2 + i;  // 16 groups of 8 rows; parity of grp == parity of i
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(slot + grp * 1024), 16,
-                                                 (i & 1) ? ln.voffO : ln.voffE, (half * 128 + grp * 8) * ld + k0, 0, 0);
-    }
-}
-__device__ __forceinline__ void r8_wait(int fills_ahead) {  // fills issued after the stage about to be read (0..2)
-    if (fills_ahead >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (fills_ahead == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-}
-__device__ __forceinline__ int r8_slot(int s) { return s >= R8_SLOTS ? s - R8_SLOTS : s; }
-// compute one stage whose first fill sits in slot s0
-__device__ __forceinline__ void r8_compute(i32x16 (&acc)[4][2], const int8_t* lds, int s0, int wr, int wc, int lane) {
-    const int r = lane & 31, h = lane >> 5, swz = (r >> 1) & 7;
-    const int8_t* pa = lds + r8_slot(s0 + wr) * R8_SLOT_BYTES + r * BK8;
-    const int8_t* pb = lds + r8_slot(s0 + 2 + (wc >> 1)) * R8_SLOT_BYTES + ((wc & 1) * 64 + r) * BK8;
-#pragma unroll
-    for (int ks = 0; ks < 4; ks++) t8_kstep(acc, pa, pb, ((2 * ks + h) ^ swz) << 4);
-}
-
-__global__ __launch_bounds__(512, 2) void k_syrk_i8_ring(const int8_t* __restrict__ M8, long ld, const int* __restrict__ pairs,
-                                                         int npairs, int nblocks, long nstages, long stages_per_split,
-                                                         int32_t* __restrict__ C, long ldc) {
-    __shared__ __attribute__((aligned(1024))) int8_t lds[R8_SLOTS * R8_SLOT_BYTES];
-    const int cpx = (gridDim.x + 7) / 8;
-    const int lid = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
-    if (lid >= nblocks) return;
-    const int split = lid / npairs;
-    const int pr = pairs[lid - split * npairs];
-    const int ti = pr >> 16, tj = pr & 0xffff;
-    const long st0 = (long)split * stages_per_split;
-    long st1 = st0 + stages_per_split;
-    if (st1 > nstages) st1 = nstages;
-    if (st0 >= st1) return;
-    const int nst = (int)(st1 - st0), F = 4 * nst;
-    const int t = threadIdx.x, lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wr = w >> 2, wc = w & 3;
-    const int ldi = (int)ld;
-    const T8Lane ln = t8_lane(lane, ldi);
-    const __amdgpu_buffer_rsrc_t rsA = t8_rsrc(M8 + (long)ti * T8 * ld, ldi);
-    const __amdgpu_buffer_rsrc_t rsB = t8_rsrc(M8 + (long)tj * T8 * ld, ldi);
-    const int kbase = (int)(st0 * BK8);
-    i32x16 acc[4][2];
-    t8_zero(acc);
-    // fill f: stage f>>2, part f&3 (0,1: A halves; 2,3: B halves), slot f % 10
-#define R8_ISSUE(f, slot_)                                                                                    \
-    do {                                                                                                      \
-        const int part_ = (f) & 3;                                                                            \
-        r8_fill(part_ < 2 ? rsA : rsB, ln, ldi, part_ & 1, kbase + ((f) >> 2) * BK8, lds + (slot_) * R8_SLOT_BYTES, w); \
-    } while (0)
-#pragma unroll
-    for (int f = 0; f < 6; f++)
-        if (f < F) R8_ISSUE(f, f);
-    int s0 = 0;
-    for (int st = 0; st < nst; st++) {
-        const int rem = F - (4 * st + 4);
-        r8_wait(rem < 2 ? (rem < 0 ? 0 : rem) : 2);
-#pragma unroll
-        for (int i = 6; i < 10; i++) {
-            const int f = 4 * st + i;
-            if (f < F) R8_ISSUE(f, r8_slot(s0 + i));
-        }
-        r8_compute(acc, lds, s0, wr, wc, lane);
-        s0 = r8_slot(s0 + 4);
-    }
-#undef R8_ISSUE
-    const int col = lane & 31, rq = 4 * (lane >> 5);
-#pragma unroll
-    for (int m = 0; m < 4; m++)
-#pragma unroll
-        for (int n = 0; n < 2; n++)
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                long i = (long)ti * T8 + wr * 128 + m * 32 + (q & 3) + 8 * (q >> 2) + rq;
-                long j = (long)tj * T8 + wc * 64 + n * 32 + col;
-                int v = acc[m][n][q];
-                if (v) atomicAdd(&C[i * ldc + j], v);
-            }
-}
-
 // Upper-triangular tile pairs (ti<<16 | tj) in super-tile order, cached on the device per tile count.
 #include <map>
 #include <vector>
@@ -372,12 +225,8 @@ extern "C" int eagle_dev_mmt_accumulate(eagle_ctx* ctx, const int8_t* M8, long n
     dim3 grid((unsigned)((nblocks + 7) / 8 * 8));
 #define SYRK_LAUNCH(T) hipLaunchKernelGGL(k_syrk_i8<T>, grid, dim3(512), 0, (hipStream_t)stream, M8, ld, pairs, (int)npairs, (int)nblocks, nstages, per, C32, n_pad)
     switch (g_tune) {
-        case 1: SYRK_LAUNCH(1); break;
-        case 2: SYRK_LAUNCH(2); break;
         case 3: SYRK_LAUNCH(3); break;
         case 4: SYRK_LAUNCH(4); break;
-        case 5: SYRK_LAUNCH(5); break;
-        case 10: hipLaunchKernelGGL(k_syrk_i8_ring, grid, dim3(512), 0, (hipStream_t)stream, M8, ld, pairs, (int)npairs, (int)nblocks, nstages, per, C32, n_pad); break;
         default: SYRK_LAUNCH(0);
     }
 #undef SYRK_LAUNCH
@@ -637,18 +486,25 @@ extern "C" int64_t eagle_vara_i8_workspace_bytes(long n_pad, long L_pad, int nsl
     return (int64_t)(ws_bs_off(n_pad, L_pad, smax) + (size_t)smax * n_pad * n_pad);
 }
 
-extern "C" int eagle_dev_vara_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu,
-                                 int nslices, void* ws, double* vara_out, double* err_bound_dev, void* stream) {
+static int vara_i8_check(eagle_ctx* ctx, long L_pad, long n_pad, long ld, int nslices) {
     if (L_pad % T8 || n_pad % T8 || ld % 128 || n_pad > ld || nslices < 0 || nslices > 8 || (double)ld * T8 >= 2147483648.0)
         return eagle_fail(ctx, EAGLE_ERR_ARG, "vara_i8: layout contract violated (L_pad % 256, n_pad % 256, 0 <= nslices <= 8)");
     // int32 tile row-sum: 64 columns per wave x |T*m| <= 128*n_pad each (accumulation across tiles is int64)
     if (64.0 * 128.0 * (double)n_pad >= 2147483648.0)
         return eagle_fail(ctx, EAGLE_ERR_ARG, "vara_i8: n too large for the int32 per-slice partial sums; use the fp64 kernel");
+    return EAGLE_OK;
+}
+
+// Phase 1: max |off-diagonal|, slice count, diagonal vector, ONE fused pass over the genotypes for
+// vdiag_i = sum_k m_ik^2 W_kk (and a = Mt8 v if v != NULL), digit slices of the off-diagonal part.
+extern "C" int eagle_dev_vara_i8_prepare(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu,
+                                         int nslices, void* ws, const double* v, double* a_out, void* stream) {
+    int rc = vara_i8_check(ctx, L_pad, n_pad, ld, nslices);
+    if (rc) return rc;
     if (L_pad == 0) return EAGLE_OK;
     hipStream_t s = (hipStream_t)stream;
     const int smax = ws_smax(nslices);
     VaraHdr* hdr = (VaraHdr*)ws;
-    long long* q = (long long*)((char*)ws + ws_q_off());
     double* dW = (double*)((char*)ws + ws_dw_off(L_pad, smax));
     double* vdiag = (double*)((char*)ws + ws_vd_off(n_pad, L_pad, smax));
     int8_t* Bs = (int8_t*)((char*)ws + ws_bs_off(n_pad, L_pad, smax));
@@ -656,16 +512,41 @@ extern "C" int eagle_dev_vara_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, 
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "vara_i8 memset");
     hipLaunchKernelGGL(k_absmax_offdiag, dim3(1024), dim3(256), 0, s, Wu, n_pad, (unsigned long long*)&hdr->maxabs_off);
     hipLaunchKernelGGL(k_vara_prep, dim3(1), dim3(256), 0, s, Wu, n_pad, nslices, hdr, dW);
-    int rc = eagle_dev_gemv_i8_sq(ctx, Mt8, L_pad, n_pad, ld, dW, vdiag, stream);  // sum_k m_ik^2 W_kk in fp64
+    if (v) rc = eagle_dev_gemv2_i8(ctx, Mt8, L_pad, n_pad, ld, v, dW, 1.0, a_out, vdiag, stream);
+    else rc = eagle_dev_gemv_i8_sq(ctx, Mt8, L_pad, n_pad, ld, dW, vdiag, stream);
     if (rc) return rc;
     dim3 g2((unsigned)(n_pad / 32), (unsigned)(n_pad / 32));
     hipLaunchKernelGGL(k_slice_w, g2, dim3(256), 0, s, Wu, n_pad, hdr, Bs);
+    e = hipGetLastError();
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "vara_i8_prepare");
+    return EAGLE_OK;
+}
+
+// Phase 2: the int8 MFMA kernel over all (marker tile, slice) workers + the S-term finish.
+extern "C" int eagle_dev_vara_i8_mfma(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, int nslices, void* ws,
+                                      double* vara_out, double* err_bound_dev, void* stream) {
+    int rc = vara_i8_check(ctx, L_pad, n_pad, ld, nslices);
+    if (rc) return rc;
+    if (L_pad == 0) return EAGLE_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int smax = ws_smax(nslices);
+    VaraHdr* hdr = (VaraHdr*)ws;
+    long long* q = (long long*)((char*)ws + ws_q_off());
+    double* vdiag = (double*)((char*)ws + ws_vd_off(n_pad, L_pad, smax));
+    int8_t* Bs = (int8_t*)((char*)ws + ws_bs_off(n_pad, L_pad, smax));
     const int ntm = (int)(L_pad / T8);
     const int groups = (ntm + 7) / 8;
     hipLaunchKernelGGL(k_vara_i8, dim3((unsigned)(groups * 8 * smax)), dim3(512), 0, s, Mt8, ld, ntm, Bs, n_pad, hdr, q, L_pad);
     hipLaunchKernelGGL(k_vara_i8_finish, dim3((unsigned)((L_pad + 255) / 256)), dim3(256), 0, s, q, L_pad, hdr, vdiag, vara_out);
     if (err_bound_dev) hipLaunchKernelGGL(k_vara_i8_bound, dim3(1), dim3(1), 0, s, hdr, err_bound_dev, (int*)nullptr);
-    e = hipGetLastError();
-    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "vara_i8");
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "vara_i8_mfma");
     return EAGLE_OK;
+}
+
+extern "C" int eagle_dev_vara_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu,
+                                 int nslices, void* ws, double* vara_out, double* err_bound_dev, void* stream) {
+    int rc = eagle_dev_vara_i8_prepare(ctx, Mt8, L_pad, n_pad, ld, Wu, nslices, ws, nullptr, nullptr, stream);
+    if (rc) return rc;
+    return eagle_dev_vara_i8_mfma(ctx, Mt8, L_pad, n_pad, ld, nslices, ws, vara_out, err_bound_dev, stream);
 }

@@ -14,6 +14,10 @@ int eagle_fail_hip(eagle_ctx* ctx, hipError_t e, const char* where);
 int eagle_dev_gemm_f64(eagle_ctx* ctx, const double* A, const double* B, double* C, long np, void* stream);
 // out = A x where At is the row-major image of A^T (i.e. the column-major R matrix), n_pad % 64 == 0
 int eagle_dev_colgemv(eagle_ctx* ctx, const double* At, long n, long n_pad, const double* x, double* out, void* stream);
+// 4 KiB of ctx-owned device scratch (flags, small reductions); stream-ordered use only
+void* eagle_ctx_scratch(eagle_ctx* ctx);
+int eagle_dev_gemv2_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* v, const double* w,
+                       double scale, double* out_a, double* out_d, void* stream);
 // out_i = sum_j Mt8[i][j]^2 v[j]
 int eagle_dev_gemv_i8_sq(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* v, double* out,
                          void* stream);

@@ -232,8 +232,10 @@ __device__ __forceinline__ void gf_compute(f64x4 (&acc)[4][4], const double* lds
 template <int AMODE, int EPI>
 __global__ __launch_bounds__(256, 2) void k_gemm_f64(const void* __restrict__ A, long lda, const double* __restrict__ B,
                                                      long ldb, double* __restrict__ C, long ldc, int n_coltiles,
-                                                     long K) {
+                                                     long K, const int* __restrict__ upper_only) {
     __shared__ __attribute__((aligned(16))) double lds[2][GF_LDSA_DOUBLES + GF_LDSB_DOUBLES];
+    // EPI 0 with a symmetric product: tiles below the diagonal are not needed (k_fold_upper doubles the upper ones)
+    if (EPI == 0 && upper_only && *upper_only && blockIdx.x > blockIdx.y) return;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
     const int i16 = lane & 15, g = lane >> 4;
     const long row0 = (long)blockIdx.x * GF_T;
@@ -317,20 +319,55 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64(const void* __restrict__ A,
     }
 }
 
-// Wu[j][k] = Wt[j][k] + Wt[k][j] (j<k) ; Wt[k][k] (j==k) ; 0 (j>k).  Wt = row-major image of W^T.
-__global__ __launch_bounds__(256) void k_fold_upper(const double* __restrict__ Wt, long np, double* __restrict__ Wu) {
-    __shared__ double tile[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+// In-place fold  W -> Wu:  Wu[j][k] = W[j][k] + W[k][j] (j<k) ; W[k][k] (j==k) ; 0 (j>k).
+// One block per pair of mirrored 32x32 tiles.  If *sym (S and V symmetric, so W = S V S is, and only the 128-tiles on
+// or above the diagonal were computed) an off-diagonal 128-tile contributes 2 W[j][k] instead.
+__global__ __launch_bounds__(256) void k_fold_upper(double* __restrict__ W, long np, const int* __restrict__ sym) {
     const long bj = (long)blockIdx.y * 32, bk = (long)blockIdx.x * 32;
-    for (int r = ty; r < 32; r += 8) tile[r][tx] = Wt[(bk + r) * np + bj + tx];  // tile[kk][jj] = Wt[bk+kk][bj+jj]
+    if (bk < bj) return;
+    __shared__ double t1[32][33], t2[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const bool diag = (bk == bj);
+    const bool twice = (*sym != 0) && ((bj >> 7) != (bk >> 7));
+    for (int r = ty; r < 32; r += 8) {
+        t1[r][tx] = W[(bj + r) * np + bk + tx];
+        if (!diag && !twice) t2[r][tx] = W[(bk + r) * np + bj + tx];
+    }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
-        long j = bj + r, k = bk + tx;
-        double direct = Wt[j * np + k];
-        double v = (j < k) ? direct + tile[tx][r] : (j == k ? direct : 0.0);
-        Wu[j * np + k] = v;
+        const long j = bj + r, k = bk + tx;
+        double v;
+        if (diag) v = (j < k) ? t1[r][tx] + t1[tx][r] : (j == k ? t1[r][tx] : 0.0);
+        else v = twice ? 2.0 * t1[r][tx] : t1[r][tx] + t2[tx][r];
+        W[j * np + k] = v;
+        if (!diag) W[(bk + r) * np + bj + tx] = 0.0;
     }
 }
+
+// *sym = 1 iff both square matrices equal their transposes up to 1e-12 of the larger of the two diagonal entries
+// involved (they are MMt^-1/2 and a variance matrix in every Eagle run; an arbitrary caller may pass anything).
+__global__ __launch_bounds__(256) void k_sym_check(const double* __restrict__ A, const double* __restrict__ B, long np,
+                                                   int* __restrict__ sym) {
+    const long bj = (long)blockIdx.y * 32, bk = (long)blockIdx.x * 32;
+    if (bk <= bj) return;
+    __shared__ double t2[2][32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        t2[0][r][tx] = A[(bk + r) * np + bj + tx];
+        t2[1][r][tx] = B[(bk + r) * np + bj + tx];
+    }
+    __syncthreads();
+    bool bad = false;
+    for (int r = ty; r < 32; r += 8) {
+        const long j = bj + r, k = bk + tx;
+        const double a = A[j * np + k], at = t2[0][tx][r], b = B[j * np + k], bt = t2[1][tx][r];
+        const double sa = fmax(fmax(fabs(A[j * np + j]), fabs(A[k * np + k])), fmax(fabs(a), fabs(at)));
+        const double sb = fmax(fmax(fabs(B[j * np + j]), fabs(B[k * np + k])), fmax(fabs(b), fabs(bt)));
+        if (!(fabs(a - at) <= 1e-12 * sa) || !(fabs(b - bt) <= 1e-12 * sb)) bad = true;
+    }
+    if (bad) *sym = 0;
+}
+__global__ void k_set_int(int* p, int v) { *p = v; }
 
 // out[i] = sum_j At[j][i] * x[j]   (At row-major = column-major image of the R matrix: out = A x)
 // Block = 4 waves x 64 columns; wave w sums j = w, w+4, ... ; fixed-order LDS combine.
@@ -388,6 +425,82 @@ __global__ __launch_bounds__(256) void k_gemv_i8(const int8_t* __restrict__ Mt8,
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
             if (lane == 0) out[r0 + r] = scale * x;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused marker pass: a_i = scale * sum_j m_ij v_j  and (optionally)  d_i = sum_j m_ij^2 w_j  in ONE read of the
+// genotype bytes.  v (and w) live in LDS for the whole block, permuted so that lane l's 16-byte reads of iteration
+// `it` are consecutive across lanes (conflict-free ds_read_b128); a wave owns 8 marker rows at a time = 8 KiB of
+// coalesced 16-B-per-lane loads in flight; fixed summation order (lane-strided, then a shuffle tree): deterministic.
+// LDS: 8*n_pad bytes per vector, so both vectors fit up to n_pad = 10240, one vector up to 20480.
+// ------------------------------------------------------------------------------------------------
+template <bool SQ>
+__global__ __launch_bounds__(512) void k_gemv2_i8(const int8_t* __restrict__ Mt8, long L_pad, int n_pad, long ld,
+                                                  const double* __restrict__ v, const double* __restrict__ w, double scale,
+                                                  double* __restrict__ out_a, double* __restrict__ out_d) {
+    extern __shared__ __attribute__((aligned(16))) double lvec[];
+    const int nit = n_pad / 1024 + ((n_pad % 1024) ? 1 : 0);  // column strips of 1024
+    double* lv = lvec;
+    double* lw = lvec + (long)nit * 1024;
+    // LDS image: element (it, j, lane, e) = vec[it*1024 + lane*16 + 2*j + e]
+    for (int idx = threadIdx.x; idx < nit * 512; idx += 512) {
+        const int it = idx >> 9, rem = idx & 511, j = rem >> 6, lane = rem & 63;
+        const int c = it * 1024 + lane * 16 + 2 * j;
+        f64x2 x = {0.0, 0.0}, y = {0.0, 0.0};
+        if (c < n_pad) {
+            x = *(const f64x2*)(v + c);
+            if (SQ) y = *(const f64x2*)(w + c);
+        }
+        *(f64x2*)(lv + (long)idx * 2) = x;
+        if (SQ) *(f64x2*)(lw + (long)idx * 2) = y;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * 512 + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * 512) >> 6;
+    for (long r0 = wave * 8; r0 < L_pad; r0 += nwaves * 8) {
+        double sa[8], sd[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) { sa[r] = 0.0; sd[r] = 0.0; }
+        for (int it = 0; it < nit; it++) {
+            const int c = it * 1024 + lane * 16;
+            union { i32x4 q; int8_t b[16]; } m[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                m[r].q = (i32x4){0, 0, 0, 0};
+                if (c < n_pad) m[r].q = *(const i32x4*)(Mt8 + (r0 + r) * ld + c);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const f64x2 x = *(const f64x2*)(lv + ((long)(it * 8 + j) * 64 + lane) * 2);
+                f64x2 y = {0.0, 0.0};
+                if (SQ) y = *(const f64x2*)(lw + ((long)(it * 8 + j) * 64 + lane) * 2);
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const int g0 = m[r].b[2 * j], g1 = m[r].b[2 * j + 1];
+                    sa[r] += (double)g0 * x[0];
+                    sa[r] += (double)g1 * x[1];
+                    if (SQ) {
+                        sd[r] += (double)(g0 * g0) * y[0];
+                        sd[r] += (double)(g1 * g1) * y[1];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            double x = sa[r], y = sd[r];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                x += __shfl_down(x, o);
+                if (SQ) y += __shfl_down(y, o);
+            }
+            if (lane == 0) {
+                out_a[r0 + r] = scale * x;
+                if (SQ) out_d[r0 + r] = y;
+            }
         }
     }
 }
@@ -558,7 +671,14 @@ extern "C" int eagle_dev_gemm_f64(eagle_ctx* ctx, const double* A, const double*
     if (np % GF_T || np <= 0) return eagle_fail(ctx, EAGLE_ERR_ARG, "gemm_f64: size must be a multiple of 128");
     dim3 grid((unsigned)(np / GF_T), (unsigned)(np / GF_T));
     hipLaunchKernelGGL((k_gemm_f64<0, 0>), grid, dim3(256), 0, (hipStream_t)stream, (const void*)A, np, B, np, C, np,
-                       (int)(np / GF_T), np);
+                       (int)(np / GF_T), np, (const int*)nullptr);
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+static int gemm_f64_upper(eagle_ctx* ctx, const double* A, const double* B, double* C, long np, const int* flag, void* stream) {
+    dim3 grid((unsigned)(np / GF_T), (unsigned)(np / GF_T));
+    hipLaunchKernelGGL((k_gemm_f64<0, 0>), grid, dim3(256), 0, (hipStream_t)stream, (const void*)A, np, B, np, C, np,
+                       (int)(np / GF_T), np, flag);
     LAUNCH_CHECK(ctx);
     return EAGLE_OK;
 }
@@ -572,16 +692,18 @@ extern "C" int eagle_dev_scan_operands(eagle_ctx* ctx, const double* Sa, const d
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "scan_operands memset");
     hipLaunchKernelGGL(k_colgemv, dim3((unsigned)(n_pad / 64)), dim3(256), 0, s, Sa, n, n_pad, ahat, v_out);
     LAUNCH_CHECK(ctx);
+    // symmetric operands (every Eagle run): W = S V S is symmetric and only its upper 128-tiles are computed
+    int* sym = (int*)eagle_ctx_scratch(ctx);
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, sym, 1);
+    dim3 g32((unsigned)(n_pad / 32), (unsigned)(n_pad / 32));
+    hipLaunchKernelGGL(k_sym_check, g32, dim3(256), 0, s, Sa, Va, n_pad, sym);
+    LAUNCH_CHECK(ctx);
     // Xt = (V S)^T = S^T V^T = Sa * Va ; Wt = (S X)^T = X^T S^T = Xt * Sa        (row-major images)
     int rc = eagle_dev_gemm_f64(ctx, Sa, Va, tmp, n_pad, stream);
     if (rc) return rc;
-    rc = eagle_dev_gemm_f64(ctx, tmp, Sa, Wu_out, n_pad, stream);
+    rc = gemm_f64_upper(ctx, tmp, Sa, Wu_out, n_pad, sym, stream);
     if (rc) return rc;
-    // fold W into its upper triangle (in place is not possible: reads the transposed element) -> via tmp
-    e = hipMemcpyAsync(tmp, Wu_out, sizeof(double) * n_pad * n_pad, hipMemcpyDeviceToDevice, s);
-    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "scan_operands copy");
-    dim3 grid((unsigned)(n_pad / 32), (unsigned)(n_pad / 32));
-    hipLaunchKernelGGL(k_fold_upper, grid, dim3(256), 0, s, tmp, n_pad, Wu_out);
+    hipLaunchKernelGGL(k_fold_upper, g32, dim3(256), 0, s, Wu_out, n_pad, sym);
     LAUNCH_CHECK(ctx);
     return EAGLE_OK;
 }
@@ -594,10 +716,52 @@ extern "C" int eagle_dev_colgemv(eagle_ctx* ctx, const double* At, long n, long 
     return EAGLE_OK;
 }
 
+// LDS-resident-vector form; returns 1 if the vectors do not fit in LDS (caller falls back)
+static int gemv2_launch(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* v, const double* w,
+                        double scale, double* out_a, double* out_d, void* stream) {
+    if (L_pad % 8 || n_pad % 16 || ld % 16 || n_pad > ld) return 1;
+    const long nit = (n_pad + 1023) / 1024;
+    const size_t lds = (size_t)nit * 1024 * 8 * (w ? 2 : 1);
+    if (lds > 160 * 1024) return 1;
+    static bool attr_done[2] = {false, false};
+    if (!attr_done[w ? 1 : 0]) {
+        hipError_t e = w ? hipFuncSetAttribute((const void*)k_gemv2_i8<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                         : hipFuncSetAttribute((const void*)k_gemv2_i8<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return eagle_fail_hip(ctx, e, "hipFuncSetAttribute");
+        attr_done[w ? 1 : 0] = true;
+    }
+    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    long blocks = 256L * per_cu;
+    const long max_useful = (L_pad / 8 + 7) / 8;
+    if (blocks > max_useful) blocks = max_useful;
+    if (w) hipLaunchKernelGGL(k_gemv2_i8<true>, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, Mt8, L_pad, (int)n_pad, ld,
+                              v, w, scale, out_a, out_d);
+    else hipLaunchKernelGGL(k_gemv2_i8<false>, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, Mt8, L_pad, (int)n_pad, ld,
+                            v, w, scale, out_a, out_d);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "k_gemv2_i8");
+    return EAGLE_OK;
+}
+
+// a = scale * Mt8 v and d_i = sum_j Mt8[i][j]^2 w[j] in one pass over the genotypes (w may be NULL: a only).
+extern "C" int eagle_dev_gemv2_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* v,
+                                  const double* w, double scale, double* out_a, double* out_d, void* stream) {
+    if (L_pad == 0) return EAGLE_OK;
+    int rc = gemv2_launch(ctx, Mt8, L_pad, n_pad, ld, v, w, scale, out_a, out_d, stream);
+    if (rc != 1) return rc;
+    rc = eagle_dev_gemv_i8(ctx, Mt8, L_pad, n_pad, ld, v, scale, out_a, stream);
+    if (rc || !w) return rc;
+    return eagle_dev_gemv_i8_sq(ctx, Mt8, L_pad, n_pad, ld, w, out_d, stream);
+}
+
 extern "C" int eagle_dev_gemv_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* v,
                                  double scale, double* out, void* stream) {
     if (L_pad % 4 || n_pad % 16 || ld % 16 || n_pad > ld) return eagle_fail(ctx, EAGLE_ERR_ARG, "gemv_i8: layout contract violated");
     if (L_pad == 0) return EAGLE_OK;
+    {
+        int rc2 = gemv2_launch(ctx, Mt8, L_pad, n_pad, ld, v, nullptr, scale, out, nullptr, stream);
+        if (rc2 != 1) return rc2;
+    }
     long waves = L_pad / 4;
     long blocks = (waves + 3) / 4;
     if (blocks > 256 * 16) blocks = 256 * 16;
@@ -611,6 +775,7 @@ extern "C" int eagle_dev_gemv_i8_sq(eagle_ctx* ctx, const int8_t* Mt8, long L_pa
                                     double* out, void* stream) {
     if (L_pad % 4 || n_pad % 16 || ld % 16 || n_pad > ld) return eagle_fail(ctx, EAGLE_ERR_ARG, "gemv_i8_sq: layout contract violated");
     if (L_pad == 0) return EAGLE_OK;
+    // (the fused LDS kernel computes this as its second output; this entry is the large-n fallback)
     long blocks = (L_pad / 4 + 3) / 4;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(k_gemv_i8<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, Mt8, L_pad, n_pad, ld, v,
@@ -626,7 +791,7 @@ extern "C" int eagle_dev_vara_f64(eagle_ctx* ctx, const int8_t* Mt8, long L_pad,
     if (L_pad == 0) return EAGLE_OK;
     dim3 grid((unsigned)(L_pad / GF_T));
     hipLaunchKernelGGL((k_gemm_f64<1, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const void*)Mt8, ld, Wu, n_pad,
-                       vara_out, 0L, (int)(n_pad / GF_T), n_pad);
+                       vara_out, 0L, (int)(n_pad / GF_T), n_pad, (const int*)nullptr);
     LAUNCH_CHECK(ctx);
     return EAGLE_OK;
 }

@@ -193,17 +193,28 @@ class DeviceShard:
         self._check(self.L.eagle_dev_gemv_i8(self.ctx, self.Mt8.data_ptr(), self.Lp, self.np_, self.np_, self.v.data_ptr(),
                                              1.0, self.a.data_ptr(), self._stream()))
 
+    def _ws(self):
+        if self.ws is None:
+            nb = int(self.L.eagle_vara_i8_workspace_bytes(self.np_, self.Lp, self.nslices))
+            self.ws = self.torch.empty(nb, dtype=self.torch.uint8, device=self.dev)
+        return self.ws
+
+    def vara_prepare(self, with_a=True):
+        """int8 path, phase 1: slice W, and ONE pass over the genotypes for a = Mt v and the diagonal term of vara."""
+        ws = self._ws()
+        self._check(self.L.eagle_dev_vara_i8_prepare(self.ctx, self.Mt8.data_ptr(), self.Lp, self.np_, self.np_,
+                                                     self.Wu.data_ptr(), self.nslices, ws.data_ptr(),
+                                                     self.v.data_ptr() if with_a else None,
+                                                     self.a.data_ptr() if with_a else None, self._stream()))
+
     def vara_kernel(self):
+        """The dominant kernel alone: fp64 MFMA vara kernel (mode 0) or the int8 MFMA kernel + finish (mode 1)."""
         if self.mode == 0:
             self._check(self.L.eagle_dev_vara_f64(self.ctx, self.Mt8.data_ptr(), self.Lp, self.np_, self.np_,
                                                   self.Wu.data_ptr(), self.vara.data_ptr(), self._stream()))
         else:
-            if self.ws is None:
-                nb = int(self.L.eagle_vara_i8_workspace_bytes(self.np_, self.Lp, self.nslices))
-                self.ws = self.torch.empty(nb, dtype=self.torch.uint8, device=self.dev)
-            self._check(self.L.eagle_dev_vara_i8(self.ctx, self.Mt8.data_ptr(), self.Lp, self.np_, self.np_,
-                                                 self.Wu.data_ptr(), self.nslices, self.ws.data_ptr(), self.vara.data_ptr(),
-                                                 None, self._stream()))
+            self._check(self.L.eagle_dev_vara_i8_mfma(self.ctx, self.Mt8.data_ptr(), self.Lp, self.np_, self.np_, self.nslices,
+                                                      self._ws().data_ptr(), self.vara.data_ptr(), None, self._stream()))
 
     def vara_i8_info(self):
         """(slices used, absolute error bound, max |off-diagonal W|) of the last int8-slice vara launch (synchronises)."""
@@ -218,7 +229,10 @@ class DeviceShard:
     def scan(self):
         """calculate_a_and_vara_rcpp.cpp:90-112 + find_qtl.R:71-83 on this shard, all on the current stream."""
         self.scan_operands()
-        self.gemv_a()
+        if self.mode == 0:
+            self.gemv_a()
+        else:
+            self.vara_prepare()
         self.vara_kernel()
         self.argmax()
 

@@ -179,6 +179,14 @@ int eagle_dev_vara_f64(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad
  * device as { double max|offdiag|; int32 S_used; int32 pad; double bound; double sum|diag| }.
  * err_bound_dev (device double, may be NULL): the absolute error bound n_pad^2 * 2^(e+1-8S) of every vara_i. */
 int64_t eagle_vara_i8_workspace_bytes(long n_pad, long L_pad, int nslices);
+/* The same in two phases, so that one pass over the genotype bytes serves both a = Mt8 v (if v != NULL; written to
+ * a_out) and the diagonal term, and so that the MFMA kernel can be timed on its own:
+ *   prepare: max |off-diagonal|, slice count, diagonal vector, fused genotype pass, digit slices;
+ *   mfma   : k_vara_i8 over all (marker tile, slice) workers + the S-term finish into vara_out. */
+int eagle_dev_vara_i8_prepare(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu,
+                              int nslices, void* ws, const double* v, double* a_out, void* stream);
+int eagle_dev_vara_i8_mfma(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, int nslices, void* ws,
+                           double* vara_out, double* err_bound_dev, void* stream);
 int eagle_dev_vara_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu,
                       int nslices, void* ws, double* vara_out, double* err_bound_dev, void* stream);
 /* zero a[i], vara[i] at the listed rows (row masking of calculate_a_and_vara_rcpp.cpp:79-84: a zeroed

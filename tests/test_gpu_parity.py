@@ -250,6 +250,23 @@ def test_big_scan_int8_slices_match_fp64_kernel(big, api, oracle):
     assert idx1 == idx_ref
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_scan_nonsymmetric_operands(big, api, oracle, mode, request):
+    """S and V are symmetric in every Eagle run (the library then computes half of W = S V S); an arbitrary caller may
+    pass anything, and m^T S V S m must still match calculate_a_and_vara_rcpp.cpp:97-112."""
+    Mt8, geno, S, V, ahat = big
+    L, n = Mt8.shape
+    rng = np.random.default_rng(11)
+    S2 = S + 0.05 * rng.standard_normal((n, n)) / np.sqrt(n)
+    V2 = V + 0.05 * rng.standard_normal((n, n)) / np.sqrt(n)
+    request.addfinalizer(lambda: api.set_scan_mode(1))
+    api.set_scan_mode(mode)
+    a_ref, v_ref = oracle.scan_from_i8(Mt8[:4096], S2, V2, ahat)
+    res = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S2, V2, 8.0, (L, n), ahat)
+    _close(res["a"][:4096], a_ref)
+    np.testing.assert_allclose(res["vara"].ravel()[:4096], v_ref, rtol=1e-8)
+
+
 def test_dev_gemm_f64_layout(api):
     """The fp64 MFMA fragment maps, checked with asymmetric integer-valued data (exact in fp64)."""
     import torch

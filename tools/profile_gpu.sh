@@ -1,5 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): rocprofv3 kernel stats + separate PMC passes of bench.py.
+# PMC passes use --simple-operands: torch.linalg.eigh (rocSOLVER) segfaults under rocprofv3 counter collection.
 # Usage: tools/profile_gpu.sh <tag> [bench args...]      outputs under gpurun_out/prof_<tag>/
 set -o pipefail
 TAG=$1; shift
@@ -8,15 +9,18 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="$ROOT/bench.py --cpu-sample 0 --steps 3 --warmup 1 --simple-operands $@"
-KF="--kernel-include-regex k_vara_i8|k_syrk_i8|k_gemm_f64|k_gemv_i8|k_mmt_finish|k_slice_w"
+KF="--kernel-include-regex k_vara_i8|k_syrk_i8|k_gemm_f64|k_gemv|k_mmt_finish|k_slice_w"
 echo "== stats pass"; 
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $ARGS > $OUT/stats.log 2>&1 || { tail -5 $OUT/stats.log; exit 1; }
+# the stats pass profiles the default bench command itself (model-algebra operands; only the CPU sample is skipped)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $ROOT/bench.py --cpu-sample 0 "$@" > $OUT/stats.log 2>&1 || { tail -5 $OUT/stats.log; exit 1; }
 echo "== pmc FETCH_SIZE"
 rocprofv3 $KF --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1 || { tail -5 $OUT/pmc_fetch.log; exit 1; }
 echo "== pmc WRITE_SIZE"
 rocprofv3 $KF --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- python3 $ARGS > $OUT/pmc_write.log 2>&1 || { tail -5 $OUT/pmc_write.log; exit 1; }
 echo "== pmc SQ"
 rocprofv3 $KF --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq -o pmc -- python3 $ARGS > $OUT/pmc_sq.log 2>&1 || { tail -5 $OUT/pmc_sq.log; }
+echo "== pmc GRBM"
+rocprofv3 $KF --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT/pmc_tcc -o pmc -- python3 $ARGS > $OUT/pmc_tcc.log 2>&1 || { tail -5 $OUT/pmc_tcc.log; }
 echo "== pmc GRBM"
 rocprofv3 $KF --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_grbm -o pmc -- python3 $ARGS > $OUT/pmc_grbm.log 2>&1 || { tail -5 $OUT/pmc_grbm.log; }
 cd $ROOT && python3 tools/summarise_prof.py $OUT > $OUT/summary.txt 2>&1; cat $OUT/summary.txt
