@@ -1,0 +1,103 @@
+"""The non-R AM() loop driver (eagleeverything_amd/am.py).
+
+CPU: the loop with an oracle-backed backend finds planted QTL and follows the reference's stop/report rules.
+GPU (-m gpu): the HIP-backed loop selects exactly the same markers, with the same extBIC trace, as the
+oracle-backed loop on the reference's demo data.  parity unpinned (no recorded outputs in the reference)."""
+import numpy as np
+import pytest
+
+from eagleeverything_amd import am, host_model, synth
+
+NA = np.nan
+
+
+class OracleBackend:
+    """calcMMt / find_qtl / extract_geno through the CPU oracle (tests only)."""
+
+    def __init__(self, oracle):
+        self.o = oracle
+
+    def calcMMt(self, geno, availmemGb, ncpu, selected_loci, quiet):
+        n, L = geno["dim_of_ascii_M"]
+        sel = np.atleast_1d(np.asarray(selected_loci, dtype=np.float64))
+        if not np.any(np.isnan(sel)):
+            sel = sel - 1  # calculateMMt.R:24
+        return self.o.normalise_MMt(self.o.calculateMMt_rcpp(geno["asciifileM"], availmemGb, ncpu, sel, (n, L)))
+
+    def find_qtl(self, geno, availmemGb, selected_loci, MMt, invMMt, best_ve, best_vg, currentX, ncpu, quiet, trait):
+        n, L = geno["dim_of_ascii_M"]
+        H = host_model.calculateH(MMt, best_ve, best_vg)
+        P = host_model.calculateP(H, currentX)
+        sq = host_model.calculateMMt_sqrt_and_sqrtinv(MMt, checkres=False)
+        hat_a = host_model.calculate_reduced_a(best_vg, P, sq["sqrt_MMt"], trait)
+        var_hat_a = host_model.calculate_reduced_vara(currentX, best_ve, best_vg, invMMt, sq["sqrt_MMt"])
+        sel = np.atleast_1d(np.asarray(selected_loci, dtype=np.float64))
+        if not np.any(np.isnan(sel)):
+            sel = sel - 1  # calculate_a_and_vara.R:23
+        res = self.o.calculate_a_and_vara_rcpp(geno["asciifileMt"], sel, sq["inverse_sqrt_MMt"], var_hat_a, availmemGb, (L, n), hat_a)
+        return self.o.tsq_argmax(res["a"], res["vara"])[1]
+
+    def extract_geno(self, geno, colnum):
+        n = geno["dim_of_ascii_M"][0]
+        return self.o.ReadBlock(geno["asciifileMt"], colnum - 1, n, 1).ravel().astype(np.int64)
+
+
+def _planted(tmp_path, n=120, L=600, seed=4):
+    Mt8 = synth.genotypes_marker_major(n, L, seed=seed)
+    rng = np.random.default_rng(seed)
+    qtl = [50, 333]
+    y = 1.5 * Mt8[qtl[0]] - 1.2 * Mt8[qtl[1]] + 0.5 * rng.standard_normal(n)
+    geno = synth.write_geno_pair(str(tmp_path), Mt8)
+    return geno, y.astype(np.float64), np.ones((n, 1)), qtl
+
+
+def test_am_loop_finds_planted_qtl_cpu(oracle, tmp_path):
+    geno, y, X, qtl = _planted(tmp_path)
+    res = am.AM(y, X, geno, availmemGb=8, ncpu=2, maxit=10, backend=OracleBackend(oracle))
+    assert set(q + 1 for q in qtl) <= set(res["selected_loci"])   # 1-based columns
+    tr = res["extBIC_trace"]
+    assert len(res["all_picks"]) == len(res["selected_loci"]) + 1   # the pick that made extBIC worse is dropped
+    assert tr[-1] > min(tr) and np.argmin(tr) == len(tr) - 2         # stop rule AM.R:448
+    assert len(res["extBIC"]) == len(tr) - 1
+    assert res["vg"] >= 0 and res["ve"] > 0
+
+
+def test_am_maxit_reports_every_pick(oracle, tmp_path):
+    geno, y, X, _ = _planted(tmp_path)
+    res = am.AM(y, X, geno, maxit=2, backend=OracleBackend(oracle))
+    assert len(res["extBIC_trace"]) == 2 and res["selected_loci"] == res["all_picks"] and len(res["all_picks"]) == 2
+
+
+def test_emma_pieces_are_consistent():
+    rng = np.random.default_rng(0)
+    n = 60
+    A = rng.standard_normal((n, 200))
+    K = A @ A.T / 200 + 0.95 * np.eye(n)
+    X = np.column_stack([np.ones(n), rng.standard_normal(n)])
+    y = rng.multivariate_normal(X @ [1.0, 0.5], 0.7 * K + 1.3 * np.eye(n))
+    r = am.emma_REMLE(y, X, K)
+    m = am.emma_MLE(y, X, K, llim=-100, ulim=100)
+    assert r["ve"] > 0 and r["vg"] >= 0 and abs(r["delta"] - r["ve"] / r["vg"]) < 1e-9 * r["delta"]
+    # the REML optimum is a stationary point of the restricted likelihood (or sits on the grid boundary)
+    eig = am.emma_eigen_R_wo_Z(K, X)
+    etas = eig["vectors"].T @ y
+    ld = np.log(r["delta"])
+    if -10 < ld < 10:
+        assert abs(am._reml_dll(ld, eig["values"], etas)) < 1e-3
+    assert np.isfinite(m["ML"]) and m["ve"] > 0
+    # eigen R: n-q values, vectors orthogonal to X
+    assert eig["values"].size == n - 2 and np.abs(X.T @ eig["vectors"]).max() < 1e-8
+    # zeroin agrees with a bracketing reference root to its tolerance
+    root = am._zeroin(lambda x: x ** 3 - 2.0, 0.0, 3.0)
+    assert abs(root - 2.0 ** (1 / 3)) < 2e-4
+
+
+@pytest.mark.gpu
+def test_am_hip_selects_same_markers_as_oracle(oracle, golden, tmp_path):
+    g = golden("genoDemo_150x4998")
+    geno = synth.write_geno_pair(str(tmp_path), np.ascontiguousarray(g["M8"].T))
+    ref = am.AM(g["y"], g["X"], geno, maxit=6, backend=OracleBackend(oracle))
+    hip = am.AM(g["y"], g["X"], geno, maxit=6)
+    assert hip["all_picks"] == ref["all_picks"] and hip["selected_loci"] == ref["selected_loci"]
+    np.testing.assert_allclose(hip["extBIC_trace"], ref["extBIC_trace"], rtol=1e-9)
+    assert len(hip["all_picks"]) >= 2
