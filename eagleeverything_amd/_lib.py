@@ -35,6 +35,7 @@ SIGNATURES = {
                                              C.c_int, c_dp, c_dp]),
     "eagle_calculate_reduced_a": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double, c_dp, c_dp, C.c_double, c_lp, c_dp,
                                             C.c_long, C.c_int, c_dp]),
+    "eagle_extract_geno": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double, C.c_long, c_lp, C.POINTER(C.c_int)]),
     "eagle_last_scan_argmax": (C.c_int, [C.c_void_p, c_lp, c_dp, c_lp]),
     "eagle_last_mmt_normalised": (C.c_int, [C.c_void_p, c_dp, c_dp]),
     "eagle_pad": (C.c_long, [C.c_long]),

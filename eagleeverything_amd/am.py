@@ -201,10 +201,9 @@ class HipBackend:
         return self.r_api.find_qtl(device=self.device, **kw)
 
     def extract_geno(self, geno, colnum):
-        """Genotypes of marker `colnum` (1-based) as ints -1/0/1: row colnum-1 of Mt.ascii (extract_geno.R:8-12 reads
-        the same values as column colnum-1 of M.ascii)."""
-        n = geno["dim_of_ascii_M"][0]
-        return self.rcpp_api.ReadBlock(geno["asciifileMt"], colnum - 1, n, 1, device=self.device).ravel().astype(np.int64)
+        """extract_geno.R:8-12: column colnum (1-based) of M.ascii, served from the HBM-resident copy calcMMt left."""
+        return self.r_api.extract_geno(geno["asciifileM"], colnum, dim_of_ascii_M=geno["dim_of_ascii_M"],
+                                       device=self.device).astype(np.int64)
 
 
 def AM(trait, X, geno, availmemGb=8, ncpu=1, maxit=20, quiet=True, backend=None, message=None):

@@ -636,6 +636,58 @@ extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_asc
     return EAGLE_OK;
 }
 
+extern "C" int eagle_extract_geno(eagle_ctx* ctx, const char* f_name_ascii, double max_memory_in_Gbytes, long selected_locus,
+                                  const long dims[2], int* column_out) {
+    if (!ctx) return EAGLE_ERR_ARG;
+    const long n = dims[0], L = dims[1];
+    if (n <= 0 || L <= 0 || selected_locus < 0 || selected_locus >= L) return eagle_fail(ctx, EAGLE_ERR_ARG, "bad dims / locus");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    struct stat st;
+    if (stat(f_name_ascii, &st) != 0) return failf(ctx, EAGLE_ERR_OPEN, "ERROR: Could not open  %s", f_name_ascii);
+    const long mt = (long)st.st_mtim.tv_sec * 1000000000L + st.st_mtim.tv_nsec;
+    for (auto& g : ctx->cache)
+        if (g.path == f_name_ascii && g.size == st.st_size && g.mtime_ns == mt && g.rows == n && g.cols == L) {
+            DevBuf col;
+            HIPCHK(ctx, col.alloc(sizeof(int) * (size_t)n));
+            int rc = eagle_dev_extract_col(ctx, g.dev, n, g.ld, selected_locus, col.as<int>(), ctx->stream);
+            if (rc) return rc;
+            HIPCHK(ctx, hipMemcpyAsync(column_out, col.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            return EAGLE_OK;
+        }
+    // not resident: one character per line straight from the file (no n x L parse)
+    FileInfo fi;
+    int rc = open_file(ctx, f_name_ascii, fi);
+    if (rc) return rc;
+    if (fi.width >= 0) {
+        if (n > fi.nlines) return eagle_fail(ctx, EAGLE_ERR_FORMAT, "file has fewer lines than requested");
+        if (selected_locus >= fi.width) return eagle_fail(ctx, EAGLE_ERR_FORMAT, "line shorter than the requested columns");
+        for (long r = 0; r < n; r++) {
+            char c;
+            if (pread(fi.fd, &c, 1, (off_t)r * (fi.width + 1) + selected_locus) != 1) return eagle_fail(ctx, EAGLE_ERR_FORMAT, "short read");
+            if (c < '0' || c > '2') return eagle_fail(ctx, EAGLE_ERR_FORMAT, "character outside '0'..'2'");
+            column_out[r] = (c - '0') - 1;
+        }
+        return EAGLE_OK;
+    }
+    FILE* f = fdopen(dup(fi.fd), "r");
+    if (!f) return eagle_fail(ctx, EAGLE_ERR_OPEN, "fdopen failed");
+    rewind(f);
+    char* line = nullptr;
+    size_t cap = 0;
+    rc = EAGLE_OK;
+    for (long r = 0; r < n; r++) {
+        ssize_t len = getline(&line, &cap, f);
+        if (len <= selected_locus) { rc = eagle_fail(ctx, EAGLE_ERR_FORMAT, "file shorter than requested"); break; }
+        char c = line[selected_locus];
+        if (c < '0' || c > '2') { rc = eagle_fail(ctx, EAGLE_ERR_FORMAT, "character outside '0'..'2'"); break; }
+        column_out[r] = (c - '0') - 1;
+    }
+    free(line);
+    fclose(f);
+    return rc;
+}
+
 extern "C" int eagle_last_scan_argmax(eagle_ctx* ctx, long* index_out, double* tsqmax_out, long* n_near_ties) {
     if (!ctx || !ctx->d_a || ctx->scan_L <= 0) return eagle_fail(ctx, EAGLE_ERR_ARG, "no scan result held");
     HIPCHK(ctx, hipSetDevice(ctx->device));

@@ -505,6 +505,11 @@ __global__ __launch_bounds__(512) void k_gemv2_i8(const int8_t* __restrict__ Mt8
     }
 }
 
+__global__ __launch_bounds__(256) void k_extract_col(const int8_t* __restrict__ M8, long n, long ld, long col, int* __restrict__ out) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (int)M8[i * ld + col];
+}
+
 __global__ __launch_bounds__(256) void k_zero_rows(double* __restrict__ a, double* __restrict__ vara, long L,
                                                    const long* __restrict__ rows, long nrows, long row_offset) {
     long q = (long)blockIdx.x * 256 + threadIdx.x;
@@ -792,6 +797,13 @@ extern "C" int eagle_dev_vara_f64(eagle_ctx* ctx, const int8_t* Mt8, long L_pad,
     dim3 grid((unsigned)(L_pad / GF_T));
     hipLaunchKernelGGL((k_gemm_f64<1, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const void*)Mt8, ld, Wu, n_pad,
                        vara_out, 0L, (int)(n_pad / GF_T), n_pad, (const int*)nullptr);
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+
+extern "C" int eagle_dev_extract_col(eagle_ctx* ctx, const int8_t* M8, long n, long ld, long col, int* out, void* stream) {
+    if (n <= 0) return EAGLE_OK;
+    hipLaunchKernelGGL(k_extract_col, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M8, n, ld, col, out);
     LAUNCH_CHECK(ctx);
     return EAGLE_OK;
 }

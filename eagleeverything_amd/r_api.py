@@ -4,6 +4,7 @@
   calcMMt ................ E/R/calcMMt.R:1-15       (.calcMMt)
   calculate_a_and_vara ... E/R/calculate_a_and_vara.R:1-34
   find_qtl ............... E/R/find_qtl.R:1-84      (.find_qtl; host algebra from host_model)
+  extract_geno, constructX E/R/extract_geno.R:1-19, E/R/constructX.R:1-24
 
 `geno` is the reference's list {asciifileM, asciifileMt, dim_of_ascii_M = (n, L)} (E/R/ReadMarker.R:306-307).
 selected_loci follow R: 1-based, NA = numpy.nan.  The "-1 only if no NA anywhere" rule
@@ -53,6 +54,20 @@ def calculate_a_and_vara(geno, maxmemGb=8, selectedloci=np.nan, invMMtsqrt=None,
                                               inv_MMt_sqrt=invMMtsqrt, dim_reduced_vara=transformed_vara,
                                               max_memory_in_Gbytes=maxmemGb, dims=dimsMt, a=transformed_a, quiet=quiet,
                                               message=message, device=device)
+
+
+def extract_geno(fnameM, colnum, availmemGb=8, dim_of_ascii_M=None, device=0):
+    """E/R/extract_geno.R:1-19 (colnum is 1-based; the C++ side is 0-based)."""
+    return rcpp_api.extract_geno_rcpp(f_name_ascii=fnameM, max_memory_in_Gbytes=availmemGb, selected_locus=colnum - 1,
+                                      dims=dim_of_ascii_M, device=device)
+
+
+def constructX(fnameM, currentX, loci_indx, availmemGb=8, dim_of_ascii_M=None, device=0):
+    """E/R/constructX.R:1-24 (column names are the R caller's business)."""
+    if loci_indx is None or (isinstance(loci_indx, float) and np.isnan(loci_indx)):
+        return currentX
+    g = extract_geno(fnameM, int(loci_indx), availmemGb, dim_of_ascii_M, device=device)
+    return np.column_stack([currentX, g.astype(np.float64)])
 
 
 def find_qtl(geno, availmemGb, selected_loci, MMt, invMMt, best_ve, best_vg, currentX, ncpu, quiet, trait, ngpu=1,

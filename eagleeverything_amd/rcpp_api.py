@@ -9,6 +9,7 @@ call into the reference:
     calculate_a_and_vara_rcpp(f_name_ascii, selected_loci, inv_MMt_sqrt, dim_reduced_vara,
                               max_memory_in_Gbytes, dims, a, quiet, message)             :54
     calculate_reduced_a_rcpp(f_name_ascii, varG, P, y, max_memory_in_Gbytes, dims, selected_loci, quiet, message)  :73
+    extract_geno_rcpp(f_name_ascii, max_memory_in_Gbytes, selected_locus, dims)                                  :129
 
 R matrices are column-major; numpy arrays are converted to Fortran order on the way in and come back so.
 NA is numpy.nan.  Every call runs on the GPU; nothing here computes.
@@ -165,6 +166,17 @@ def calculate_reduced_a_rcpp(f_name_ascii, varG, P, y, max_memory_in_Gbytes, dim
     if rc == 1:  # 1 x 1 zero matrix, calculate_reduced_a_rcpp.cpp:94-103
         return np.zeros((1, 1))
     return out.reshape(Lm, 1)
+
+
+def extract_geno_rcpp(f_name_ascii, max_memory_in_Gbytes, selected_locus, dims, device=0):
+    """E/src/extract_geno_rcpp.cpp:16-89: column selected_locus (0-based) of M.ascii as int32 -1/0/1."""
+    L = _lib.load()
+    ctx = context(device)
+    n = int(dims[0])
+    out = np.zeros(n, dtype=np.int32)
+    _check(ctx, L.eagle_extract_geno(ctx, os.fsencode(f_name_ascii), float(max_memory_in_Gbytes), int(selected_locus),
+                                     _dims(dims), out.ctypes.data_as(C.POINTER(C.c_int))))
+    return out
 
 
 def last_scan_argmax(device=0):

@@ -108,6 +108,15 @@ int eagle_calculate_reduced_a(eagle_ctx* ctx, const char* f_name_ascii, double v
                               const double* y, double max_memory_in_Gbytes, const long dims[2],
                               const double* selected_loci, long n_selected, int quiet, double* ar_out);
 
+/* Replaces  Eigen::VectorXi extract_geno_rcpp(CharacterVector f_name_ascii, double max_memory_in_Gbytes,
+ *           long selected_locus, std::vector<long> dims)   E/src/extract_geno_rcpp.cpp:16-89, RcppExports.cpp:128-141
+ * Column `selected_locus` (0-based) of M.ascii as ints -1/0/1 (constructX appends it to the design matrix,
+ * E/R/constructX.R:16-19).  dims = (n, L).  Served from the HBM-resident copy of the file when eagle_calculateMMt
+ * has loaded it (always the case inside AM(), AM.R:403 vs :414-417); otherwise one character per line is read from
+ * the file -- the reference parses the whole n x L file into doubles for this. */
+int eagle_extract_geno(eagle_ctx* ctx, const char* f_name_ascii, double max_memory_in_Gbytes, long selected_locus,
+                       const long dims[2], int* column_out);
+
 /* Replaces the R tail of .find_qtl:  tsq <- a^2/vara ; which(tsq == max(tsq, na.rm=TRUE))[1]
  *                                                E/R/find_qtl.R:71-83
  * Evaluated on the device on the a / vara of the LAST eagle_calculate_a_and_vara call of this ctx (still in

@@ -526,6 +526,26 @@ long eo_tsq_argmax(const double* a, const double* vara, long L, double* tsq_out,
     return idx;
 }
 
+/* E/src/extract_geno_rcpp.cpp:16-89: column `selected_locus` (0-based) of M.ascii as ints; both of its branches
+ * (whole file / row blocks) yield genoMat(i, selected_locus) for every line i. */
+int eo_extract_geno(const char* path, long selected_locus, long n, long L, int* out) {
+    if (selected_locus < 0 || selected_locus >= L) return eo_fail(EO_ERR_ARG, "bad locus%s", NULL);
+    double* row = (double*)malloc(sizeof(double) * (size_t)L);
+    if (!row) return eo_fail(EO_ERR_NOMEM, "out of memory%s", NULL);
+    FILE* f = fopen(path, "r");
+    if (!f) { free(row); return eo_fail(EO_ERR_OPEN, "ERROR: Could not open  %s", path); }
+    char* line = NULL;
+    size_t cap = 0;
+    int rc = EO_OK;
+    for (long r = 0; r < n; r++) {
+        ssize_t len = getline(&line, &cap, f);
+        if (len < 0 || len <= selected_locus) { rc = eo_fail(EO_ERR_SHORT, "file %s shorter than requested", path); break; }
+        out[r] = (int)((double)(line[selected_locus] - '0') - 1);
+    }
+    free(line); free(row); fclose(f);
+    return rc;
+}
+
 int eo_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

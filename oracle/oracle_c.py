@@ -45,6 +45,7 @@ def lib():
         L.eo_tsq_argmax.argtypes = [c_dp, c_dp, C.c_long, c_dp, c_dp]
         L.eo_tsq_argmax.restype = C.c_long
         L.eo_num_threads.restype = C.c_int
+        L.eo_extract_geno.argtypes = [C.c_char_p, C.c_long, C.c_long, C.c_long, C.POINTER(C.c_int)]
         L.eo_set_num_threads.argtypes = [C.c_int]
         L.eo_set_num_threads.restype = None
         _lib = L
@@ -134,6 +135,14 @@ def calculate_reduced_a_rcpp(f_name_ascii, varG, P, y, max_memory_in_Gbytes, dim
     if rc == 1:
         return np.zeros((1, 1))
     return out.reshape(L, 1)
+
+
+def extract_geno_rcpp(f_name_ascii, max_memory_in_Gbytes, selected_locus, dims):
+    """E/src/extract_geno_rcpp.cpp:16-89."""
+    n, L = int(dims[0]), int(dims[1])
+    out = np.zeros(n, dtype=np.int32)
+    _check(lib().eo_extract_geno(os.fsencode(f_name_ascii), int(selected_locus), n, L, out.ctypes.data_as(C.POINTER(C.c_int))))
+    return out
 
 
 def tsq_argmax(a, vara):

@@ -160,6 +160,21 @@ def test_reduced_a(files, api, oracle):
     _close(np.delete(arm.ravel(), [5, 9]), np.delete(ref.ravel(), [5, 9]), scale=np.abs(ref).max())
 
 
+def test_extract_geno_resident_and_from_file(files, api, oracle):
+    g, geno = files["synth_203x1531"]
+    n, L = g["M8"].shape
+    api.drop_cache()
+    for c in (0, 17, L - 1):  # not resident: one character per line from the file
+        np.testing.assert_array_equal(api.extract_geno_rcpp(geno["asciifileM"], 8.0, c, (n, L)),
+                                      oracle.extract_geno_rcpp(geno["asciifileM"], 8.0, c, (n, L)))
+    api.calculateMMt_rcpp(geno["asciifileM"], 8.0, 2, NA, (n, L))  # makes M.ascii resident in HBM
+    for c in (0, 17, L - 1):
+        np.testing.assert_array_equal(api.extract_geno_rcpp(geno["asciifileM"], 8.0, c, (n, L)), g["M8"][:, c].astype(np.int32))
+    from eagleeverything_amd._lib import EagleError
+    with pytest.raises(EagleError):
+        api.extract_geno_rcpp(geno["asciifileM"], 8.0, L, (n, L))
+
+
 def test_find_qtl_mirror_selects_same_marker(files, api, oracle):
     from eagleeverything_amd import host_model, r_api
     g, geno = files["genoDemo_150x4998"]

@@ -179,3 +179,11 @@ def test_scan_real_blocked_branch(oracle, tmp_path):
     a_np = Mt8.astype(np.float64) @ (S @ ah)
     a_np[sel.astype(int)] = 0.0
     np.testing.assert_allclose(blk["a"].ravel(), a_np, rtol=1e-11, atol=1e-12)
+
+
+def test_extract_geno(golden, oracle, tmp_path):
+    g = golden("synth_203x1531")
+    geno = _files(tmp_path, g)
+    n, L = g["M8"].shape
+    for c in (0, 17, L - 1):
+        np.testing.assert_array_equal(oracle.extract_geno_rcpp(geno["asciifileM"], 8.0, c, (n, L)), g["M8"][:, c].astype(np.int32))
