@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--mode", choices=["f64", "i8"], default=os.environ.get("EAGLE_SCAN_MODE", "i8"))
     ap.add_argument("--slices", type=int, default=0, help="int8 digit slices of W in i8 mode (0 = chosen from the error bound)")
     ap.add_argument("--mmt-reps", type=int, default=2)
-    ap.add_argument("--cpu-sample", type=int, default=32768, help="markers in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=131072, help="markers in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--simple-operands", action="store_true", help="seeded random SPD S / V instead of the model algebra")
     args = ap.parse_args()
 
@@ -250,7 +250,7 @@ def main():
         parity = {"a_max_rel": rel(a_g, a_ref), "vara_max_rel": float(np.max(np.abs(v_g - vara_ref) / np.abs(vara_ref))),
                   "sample_argmax_equal": bool(np.argmax(a_g ** 2 / v_g) == np.argmax(a_ref ** 2 / vara_ref))}
         # MM^T baseline on a marker subsample, scaled linearly in L
-        nm = min(4096, Lloc)
+        nm = min(16384, Lloc)
         M_s = np.ascontiguousarray(sh.Mt8[:nm, :n].cpu().numpy().T)
         tc = time.perf_counter()
         mm_ref = oracle_c.mmt_from_i8(M_s)

@@ -93,7 +93,13 @@ __device__ __forceinline__ void t8_compute(i32x16 (&acc)[4][2], const int8_t* ld
 // the DMA pieces over the k-steps (+-2 %), software-pipelined fragment reads pinned with sched_group_barrier (-3 %),
 // a 10-slot 160 KiB LDS ring with 96 KiB in flight and counted vmcnt (-3 %; DMA-only 2.55 ms), a 4-deep ring of 64-byte
 // K stages (-9 %), tile-major pre-swizzled operand copies so that every DMA instruction reads 1 KiB of consecutive
-// bytes (+-1 %), odd leading dimensions against channel aliasing (+-1 %).
+// bytes (+-1 %), odd leading dimensions against channel aliasing (+-1 %), a descending K order for every second tile so
+// that each sweep of the genotype panel starts on the lines the previous sweep left in L2 (0 %), and L2 prefetch of the
+// stage wanted 3 stages ahead by one designated leader per sharing group (-10 %: the leader's in-order vmcnt wait now
+// includes its own HBM-latency loads and it becomes the straggler of its group).
+// tools/ubench/fill_rate.hip measures what bounds it: filling 64 KiB of LDS takes 1.15-1.2 us per CU when every line
+// is an L2 hit and 3.1 us when every line comes from HBM, by LDS-DMA and by register staging alike; at the 72-82 %
+// hit rate of these kernels (rocprofv3 TCC_HIT/TCC_REQ) that is 1.5-1.7 us per stage against 0.9-1.1 us of MFMA work.
 template <int TUNE>
 __device__ __forceinline__ void t8_stage_compute(i32x16 (&acc)[4][2], const int8_t* ldsA, const int8_t* ldsB, const T8Read& rd,
                                                  bool more, __amdgpu_buffer_rsrc_t rsA, const T8Lane& lnA, int ldA, int kA,

@@ -101,21 +101,35 @@ __global__ __launch_bounds__(256) void k_mmt_downdate(const int8_t* __restrict__
     if ((i >> 8) <= (j >> 8)) C[i * ldc + j] -= s;
 }
 
+// One block per 32x32 tile on or above the diagonal: coalesced read of the int32 tile, coalesced write of the fp64
+// tile and (through LDS) of its mirror image; block max -> atomicMax on the raw bits (the maximum is non-negative).
 __global__ __launch_bounds__(256) void k_mmt_finish(const int32_t* __restrict__ C, long n, long ldc,
                                                     double* __restrict__ out, long ld_out,
                                                     unsigned long long* __restrict__ maxbits) {
-    long j = (long)blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
-    double v = 0.0;
-    if (j < n) {
-        int c = ((i >> 8) <= (j >> 8)) ? C[i * ldc + j] : C[j * ldc + i];
-        v = (double)c;
-        out[i * ld_out + j] = v;
+    const long bi = (long)blockIdx.y * 32, bj = (long)blockIdx.x * 32;
+    if (bj < bi) return;
+    __shared__ double t[32][33];
+    __shared__ double sm[4];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    double m = 0.0;
+    for (int r = ty; r < 32; r += 8) {
+        const long i = bi + r, j = bj + tx;
+        double v = 0.0;
+        if (i < n && j < n) {
+            v = (double)C[i * ldc + j];
+            out[i * ld_out + j] = v;
+            m = v > m ? v : m;
+        }
+        t[r][tx] = v;
     }
-    // block max (values >= 0 on the diagonal, so the maximum is non-negative: ordered as raw bits)
-    double m = v > 0.0 ? v : 0.0;
+    __syncthreads();
+    if (bj > bi)
+        for (int r = ty; r < 32; r += 8) {
+            const long j = bj + r, i = bi + tx;  // out[j][i] = C[i][j]
+            if (i < n && j < n) out[j * ld_out + i] = t[tx][r];
+        }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { double x = __shfl_down(m, o); m = x > m ? x : m; }
-    __shared__ double sm[4];
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -657,7 +671,7 @@ extern "C" int eagle_dev_mmt_finish(eagle_ctx* ctx, const int32_t* C32, long n, 
     if (n > 65535) return eagle_fail(ctx, EAGLE_ERR_ARG, "mmt_finish: n too large");
     hipError_t e = hipMemsetAsync(max_dev, 0, sizeof(double), (hipStream_t)stream);
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "mmt_finish memset");
-    dim3 grid((unsigned)((n + 255) / 256), (unsigned)n);
+    dim3 grid((unsigned)((n + 31) / 32), (unsigned)((n + 31) / 32));
     hipLaunchKernelGGL(k_mmt_finish, grid, dim3(256), 0, (hipStream_t)stream, C32, n, n_pad, MMt, ld_out,
                        (unsigned long long*)max_dev);
     LAUNCH_CHECK(ctx);
