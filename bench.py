@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--mmt-reps", type=int, default=2)
     ap.add_argument("--cpu-sample", type=int, default=131072, help="markers in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--simple-operands", action="store_true", help="seeded random SPD S / V instead of the model algebra")
+    ap.add_argument("--save-operands", default=None, help="write S, V, a_hat (torch.save) after computing them")
+    ap.add_argument("--load-operands", default=None, help="read S, V, a_hat written by --save-operands (used by the PMC passes of\n                    tools/profile_gpu.sh: rocSOLVER's eigh crashes under rocprofv3 counter collection)")
     args = ap.parse_args()
 
     import torch
@@ -144,7 +146,9 @@ def main():
         qtl = torch.linspace(0, Lloc - 1, 12, device=dev).long()[1:-1]
         y = 0.5 * sh.Mt8[qtl, :n].double().sum(0) + torch.randn(n, generator=gen, device=dev, dtype=torch.float64)
         X = torch.ones((n, 1), dtype=torch.float64, device=dev)
-        if args.simple_operands:
+        if args.load_operands:
+            S, V, ahat = [t.to(dev) for t in torch.load(args.load_operands, weights_only=True)]
+        elif args.simple_operands:
             A = torch.randn((n, 64), generator=gen, device=dev, dtype=torch.float64) / 8.0
             S = torch.eye(n, dtype=torch.float64, device=dev) + A @ A.T
             V = 0.5 * torch.eye(n, dtype=torch.float64, device=dev) - 0.01 * (A[:, :8] @ A[:, :8].T)
@@ -156,6 +160,8 @@ def main():
         V = torch.empty((n, n), dtype=torch.float64, device=dev)
         ahat = torch.empty(n, dtype=torch.float64, device=dev)
     S, V, ahat = S.contiguous(), V.contiguous(), ahat.contiguous()
+    if args.save_operands and rank == 0:
+        torch.save([S.cpu(), V.cpu(), ahat.cpu()], args.save_operands)
     coll.broadcast_(S); coll.broadcast_(V); coll.broadcast_(ahat)
     sh.set_operands(S, V, ahat)
     torch.cuda.synchronize(dev)
@@ -212,7 +218,18 @@ def main():
         roof = {"bound": "mfma", "kernel": "k_vara_i8 (v_mfma_i32_32x32x32_i8, %d digit slices)" % S_used, "dtype": "i8",
                 "achieved": ops / kern_s / 1e12, "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s"}
     roof["frac"] = roof["achieved"] / roof["peak"]
-    roof["traffic"] = None  # HBM bytes per launch from the PMC pass: see profiles/ and DESIGN.md
+    # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command (tools/profile_gpu.sh);
+    # they cannot be collected in-process, so the committed figure is attached when the configuration matches.
+    roof["traffic"] = None
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["k_vara_i8"]
+        if sh.mode == 1 and tr["config"] == {"n": n, "markers": Lloc, "slices": S_used}:
+            roof["traffic"] = tr["hbm_side_bytes"]
+            roof["traffic_unit"] = "bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r01_rocprof_final"
+            roof["algorithmic_bytes"] = float(Lp) * np_ + float(S_used) * np_ * np_ / 2
+            roof["l2_hit_rate"] = tr["TCC_hit_rate"]
+    except Exception:
+        pass
     roof["kernel_ms"] = kern_s * 1e3
     roof["reference_flops_per_launch"] = 2.0 * Lloc * n * n + 2.0 * Lloc * n
     roof["fp64_equiv_tflops"] = roof["reference_flops_per_launch"] / kern_s / 1e12
@@ -267,7 +284,7 @@ def main():
             "config": {"workload": "synthetic %d individuals x %d SNPs per GPU (HWE genotypes, int8 resident in HBM), "
                                    "single trait, full calculate_a_and_vara pass + tsq arg-max" % (n, Lloc),
                        "n": n, "markers_per_gpu": Lloc, "markers_total": Ltot, "parallelism": "marker-shard x%d" % world,
-                       "scan_mode": args.mode, "slices": S_used, "vara_abs_error_bound": vara_bound, "operands": "simple" if args.simple_operands else "model algebra on MM^T"},
+                       "scan_mode": args.mode, "slices": S_used, "vara_abs_error_bound": vara_bound, "operands": "simple" if args.simple_operands else "model algebra on MM^T" + (" (reloaded)" if args.load_operands else "")},
             "mmt_build_s": mmt_build_s, "selected_marker": int(sel[0]), "tsqmax": sel[1],
             "roofline": roof, "roofline_secondary": secondary, "cpu_baseline": cpu, "parity": parity,
             "device": info, "setup_s": {"genotypes": t_gen, "operands": t_ops},

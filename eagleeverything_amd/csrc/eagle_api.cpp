@@ -21,6 +21,8 @@
 #include <stdio.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <time.h>
+#include <stdlib.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -53,6 +55,7 @@ struct eagle_ctx {
     double* d_mmt = nullptr; long mmt_n = 0; double* d_mmt_max = nullptr;
     double* d_a = nullptr; double* d_vara = nullptr; long scan_L = 0; long scan_cap = 0;
     void* d_scratch = nullptr;
+    void* arena = nullptr; size_t arena_cap = 0, arena_off = 0;  // grow-only device workspace reused across calls
     char arch[64] = {0};
     int cu_count = 0;
     int64_t hbm_bytes = 0;
@@ -104,6 +107,30 @@ struct PinBuf {
     ~PinBuf() { if (p) (void)hipHostFree(p); }
     hipError_t alloc(size_t bytes) { return hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault); }
 };
+
+// Grow-only device arena: the n x n operand images and kernel workspaces of a call are carved from one allocation that
+// survives between calls (a find_qtl iteration would otherwise pay ~10 hipMalloc/hipFree pairs of 100s of MB each).
+static int arena_reserve(eagle_ctx* ctx, size_t total) {
+    ctx->arena_off = 0;
+    if (total <= ctx->arena_cap) return EAGLE_OK;
+    if (ctx->arena) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->arena); ctx->arena = nullptr; ctx->arena_cap = 0; }
+    hipError_t e = hipMalloc(&ctx->arena, total);
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "arena hipMalloc");
+    ctx->arena_cap = total;
+    return EAGLE_OK;
+}
+static size_t arena_round(size_t b) { return (b + 255) / 256 * 256; }
+template <class T> static T* arena_take(eagle_ctx* ctx, size_t bytes) {
+    T* p = (T*)((char*)ctx->arena + ctx->arena_off);
+    ctx->arena_off += arena_round(bytes);
+    return p;
+}
+static double now_s() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+static bool timing_on() { static int v = -1; if (v < 0) v = getenv("EAGLE_HIP_TIMING") ? 1 : 0; return v == 1; }
 
 // ------------------------------------------------------------------------------------------------
 extern "C" const char* eagle_open_error(void) { return g_open_err; }
@@ -169,6 +196,7 @@ extern "C" void eagle_close(eagle_ctx* ctx) {
     if (ctx->d_a) (void)hipFree(ctx->d_a);
     if (ctx->d_vara) (void)hipFree(ctx->d_vara);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->arena) (void)hipFree(ctx->arena);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -598,29 +626,42 @@ extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_asc
     rc = get_resident(ctx, f_name_ascii, L, n, max_memory_in_Gbytes, host_threads(), &g);
     if (rc) return rc;
     const long np = g->ld, Lp = g->rows_pad;
-    DevBuf Sa, Va, tmp, Wu, ah, v, dsel, ws;
+    DevBuf dsel;
     const size_t sq = sizeof(double) * (size_t)np * np;
-    HIPCHK(ctx, Sa.alloc(sq)); HIPCHK(ctx, Va.alloc(sq)); HIPCHK(ctx, tmp.alloc(sq)); HIPCHK(ctx, Wu.alloc(sq));
-    HIPCHK(ctx, ah.alloc(sizeof(double) * np)); HIPCHK(ctx, v.alloc(sizeof(double) * np));
-    if ((rc = upload_square(ctx, inv_MMt_sqrt, n, np, Sa.as<double>()))) return rc;
-    if ((rc = upload_square(ctx, dim_reduced_vara, n, np, Va.as<double>()))) return rc;
-    if ((rc = upload_vec(ctx, a, n, np, ah.as<double>()))) return rc;
+    const bool use_i8 = ctx->scan_mode == 1 && 64.0 * 128.0 * (double)np < 2147483648.0;
+    const int nslices = ctx->scan_slices;
+    const size_t wsb = use_i8 ? (size_t)eagle_vara_i8_workspace_bytes(np, Lp, nslices) : 0;
+    const double t0 = now_s();
+    if ((rc = arena_reserve(ctx, 4 * arena_round(sq) + 2 * arena_round(sizeof(double) * np) + arena_round(wsb)))) return rc;
+    double* Sa = arena_take<double>(ctx, sq);
+    double* Va = arena_take<double>(ctx, sq);
+    double* tmp = arena_take<double>(ctx, sq);
+    double* Wu = arena_take<double>(ctx, sq);
+    double* ah = arena_take<double>(ctx, sizeof(double) * np);
+    double* v = arena_take<double>(ctx, sizeof(double) * np);
+    void* ws = arena_take<char>(ctx, wsb);
+    if ((rc = upload_square(ctx, inv_MMt_sqrt, n, np, Sa))) return rc;
+    if ((rc = upload_square(ctx, dim_reduced_vara, n, np, Va))) return rc;
+    if ((rc = upload_vec(ctx, a, n, np, ah))) return rc;
     if ((rc = ensure_scan_out(ctx, Lp))) return rc;
-    rc = eagle_dev_scan_operands(ctx, Sa.as<double>(), Va.as<double>(), ah.as<double>(), n, np, v.as<double>(), Wu.as<double>(),
-                                 tmp.as<double>(), ctx->stream);
+    double t1 = 0;
+    if (timing_on()) { (void)hipStreamSynchronize(ctx->stream); t1 = now_s(); }
+    rc = eagle_dev_scan_operands(ctx, Sa, Va, ah, n, np, v, Wu, tmp, ctx->stream);
     if (rc) return rc;
-    if (ctx->scan_mode == 1 && 64.0 * 128.0 * (double)np < 2147483648.0) {
-        const int nslices = ctx->scan_slices;
-        HIPCHK(ctx, ws.alloc((size_t)eagle_vara_i8_workspace_bytes(np, Lp, nslices)));
+    if (use_i8) {
         // one pass over the genotypes gives a = Mt v and the diagonal term of vara; then the int8 MFMA kernel
-        rc = eagle_dev_vara_i8_prepare(ctx, g->dev, Lp, np, g->ld, Wu.as<double>(), nslices, ws.p, v.as<double>(), ctx->d_a,
-                                       ctx->stream);
+        rc = eagle_dev_vara_i8_prepare(ctx, g->dev, Lp, np, g->ld, Wu, nslices, ws, v, ctx->d_a, ctx->stream);
         if (rc) return rc;
-        rc = eagle_dev_vara_i8_mfma(ctx, g->dev, Lp, np, g->ld, nslices, ws.p, ctx->d_vara, nullptr, ctx->stream);
+        rc = eagle_dev_vara_i8_mfma(ctx, g->dev, Lp, np, g->ld, nslices, ws, ctx->d_vara, nullptr, ctx->stream);
     } else {
-        rc = eagle_dev_gemv_i8(ctx, g->dev, Lp, np, g->ld, v.as<double>(), 1.0, ctx->d_a, ctx->stream);
+        rc = eagle_dev_gemv_i8(ctx, g->dev, Lp, np, g->ld, v, 1.0, ctx->d_a, ctx->stream);
         if (rc) return rc;
-        rc = eagle_dev_vara_f64(ctx, g->dev, Lp, np, g->ld, Wu.as<double>(), ctx->d_vara, ctx->stream);
+        rc = eagle_dev_vara_f64(ctx, g->dev, Lp, np, g->ld, Wu, ctx->d_vara, ctx->stream);
+    }
+    if (timing_on()) {
+        (void)hipStreamSynchronize(ctx->stream);
+        fprintf(stderr, "[eaglehip] scan n=%ld L=%ld: alloc+upload %.1f ms, device compute %.1f ms\n", n, L, (t1 - t0) * 1e3,
+                (now_s() - t1) * 1e3);
     }
     if (rc) return rc;
     if (!sel.empty()) {  // :79-84: a zeroed marker row gives a = 0 and vara = 0 exactly

@@ -282,6 +282,42 @@ def test_scan_nonsymmetric_operands(big, api, oracle, mode, request):
     np.testing.assert_allclose(res["vara"].ravel()[:4096], v_ref, rtol=1e-8)
 
 
+def test_large_n_device_path(api, oracle):
+    """n = 12000 (47 column tiles: odd count, vectors too large for the LDS-resident genotype pass), device-resident
+    entry points only, checked against the oracle on a marker sample and through exact properties of MM^T."""
+    import torch
+    from eagleeverything_amd.sharded import DeviceShard
+    n, L = 12000, 4096
+    sh = DeviceShard(n, L)
+    sh.fill_synthetic(seed=99)
+    gen = torch.Generator(device=sh.dev)
+    gen.manual_seed(5)
+    A = torch.randn((n, 32), generator=gen, device=sh.dev, dtype=torch.float64) / 32.0
+    S = 0.4 * torch.eye(n, dtype=torch.float64, device=sh.dev) + A @ A.T
+    V = 0.5 * torch.eye(n, dtype=torch.float64, device=sh.dev) - 0.02 * (A[:, :4] @ A[:, :4].T)
+    ahat = torch.randn(n, generator=gen, device=sh.dev, dtype=torch.float64)
+    sh.set_operands(S, V, ahat)
+    Mt_s = sh.Mt8[:384, :n].cpu().numpy()
+    a_ref, v_ref = oracle.scan_from_i8(Mt_s, S.cpu().numpy(), V.cpu().numpy(), ahat.cpu().numpy())
+    for mode in (1, 0):
+        sh.mode = mode
+        sh.scan()
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(sh.a[:384].cpu().numpy(), a_ref, rtol=1e-9, atol=1e-12 * np.abs(a_ref).max())
+        np.testing.assert_allclose(sh.vara[:384].cpu().numpy(), v_ref, rtol=1e-9)
+    # MM^T: exact trace (sum of squares) and symmetry at this size
+    c32 = sh.mmt_partial()
+    MMt, mx = sh.mmt_finish(c32)
+    Mt = sh.Mt8[:L, :n]
+    diag_ref = (Mt.to(torch.int32) ** 2).sum(dim=0).double()
+    assert torch.equal(torch.diagonal(MMt), diag_ref)
+    assert torch.equal(MMt, MMt.T)
+    cols = torch.tensor([0, 1, 255, 256, 6000, n - 1], device=sh.dev)
+    ref_cols = Mt.double().T @ Mt[:, cols].double()
+    assert torch.equal(MMt[:, cols], ref_cols)
+    assert float(mx) == float(MMt.max())
+
+
 def test_dev_gemm_f64_layout(api):
     """The fp64 MFMA fragment maps, checked with asymmetric integer-valued data (exact in fp64)."""
     import torch

@@ -29,6 +29,7 @@ def main():
     S = np.eye(n) + A @ A.T
     V = 0.5 * np.eye(n) - 0.01 * (A[:, :8] @ A[:, :8].T)
     ahat = rng.standard_normal(n)
+    S, V = np.asfortranarray(S), np.asfortranarray(V)  # R hands column-major matrices: no host-side re-layout
     out = {"n": n, "L": L}
     with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
         t = time.perf_counter()

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): rocprofv3 kernel stats + separate PMC passes of bench.py.
-# PMC passes use --simple-operands: torch.linalg.eigh (rocSOLVER) segfaults under rocprofv3 counter collection.
+# PMC passes reload the operands the stats pass computed: torch.linalg.eigh (rocSOLVER) segfaults under rocprofv3
+# counter collection, and the workload must be the same in every pass.
 # Usage: tools/profile_gpu.sh <tag> [bench args...]      outputs under gpurun_out/prof_<tag>/
 set -o pipefail
 TAG=$1; shift
@@ -8,11 +9,12 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$ROOT/bench.py --cpu-sample 0 --steps 3 --warmup 1 --simple-operands $@"
+OPS=/tmp/eagle_bench_operands.pt
+ARGS="$ROOT/bench.py --cpu-sample 0 --steps 3 --warmup 1 --load-operands $OPS $@"
 KF="--kernel-include-regex k_vara_i8|k_syrk_i8|k_gemm_f64|k_gemv|k_mmt_finish|k_slice_w"
 echo "== stats pass"; 
 # the stats pass profiles the default bench command itself (model-algebra operands; only the CPU sample is skipped)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $ROOT/bench.py --cpu-sample 0 "$@" > $OUT/stats.log 2>&1 || { tail -5 $OUT/stats.log; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $ROOT/bench.py --cpu-sample 0 --save-operands $OPS "$@" > $OUT/stats.log 2>&1 || { tail -5 $OUT/stats.log; exit 1; }
 echo "== pmc FETCH_SIZE"
 rocprofv3 $KF --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1 || { tail -5 $OUT/pmc_fetch.log; exit 1; }
 echo "== pmc WRITE_SIZE"
