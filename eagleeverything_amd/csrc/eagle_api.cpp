@@ -450,10 +450,21 @@ extern "C" int eagle_dev_load_ascii(eagle_ctx* ctx, const char* path, long row0,
     return load_tile_general(ctx, fi, row0, nrows, col0, ncols, dst, ld);
 }
 
+// How many bytes of genotypes may stay resident per file: EAGLE_HIP_MAX_RESIDENT_GB (tests force the streamed path
+// with it), otherwise whatever HBM has free.  Files above it are streamed through HBM in marker chunks.
+#define EAGLE_STREAM 2
+static size_t resident_budget() {
+    const char* e = getenv("EAGLE_HIP_MAX_RESIDENT_GB");
+    if (e && *e) return (size_t)(atof(e) * 1e9);
+    return (size_t)-1;
+}
+
 // Resident genotype tile of a whole file: `rows` lines x first `cols` characters, zero padded to
 // [pad128(rows)][pad128(cols)].
+// Returns EAGLE_OK (*out set), EAGLE_STREAM (too large: the caller streams marker chunks) or an error.
+// reserve_bytes: HBM the caller still needs for operands and workspaces.
 static int get_resident(eagle_ctx* ctx, const char* path, long rows, long cols, double max_mem_gb, int threads,
-                        GenoEntry** out) {
+                        GenoEntry** out, size_t reserve_bytes = (size_t)1 << 30) {
     struct stat st;
     if (stat(path, &st) != 0) return failf(ctx, EAGLE_ERR_OPEN, "ERROR: Could not open  %s", path);
     long mt = (long)st.st_mtim.tv_sec * 1000000000L + st.st_mtim.tv_nsec;
@@ -466,13 +477,13 @@ static int get_resident(eagle_ctx* ctx, const char* path, long rows, long cols, 
     g.path = path; g.size = st.st_size; g.mtime_ns = mt; g.rows = rows; g.cols = cols;
     g.rows_pad = eagle_pad(rows); g.ld = eagle_pad(cols);
     size_t bytes = (size_t)g.rows_pad * (size_t)g.ld;
+    if (bytes > resident_budget()) return EAGLE_STREAM;
     size_t freeb = 0, totalb = 0;
     HIPCHK(ctx, hipMemGetInfo(&freeb, &totalb));
-    if (bytes + ((size_t)1 << 30) > freeb) {
+    if (bytes + reserve_bytes > freeb) {
         eagle_drop_cache(ctx);
         HIPCHK(ctx, hipMemGetInfo(&freeb, &totalb));
-        if (bytes + ((size_t)1 << 30) > freeb)
-            return failf(ctx, EAGLE_ERR_NOMEM, "genotype tile of %zu bytes does not fit in HBM (%zu free): shard the markers", bytes, freeb);
+        if (bytes + reserve_bytes > freeb) return EAGLE_STREAM;  // does not fit beside the operands: stream it
     }
     HIPCHK(ctx, hipMalloc((void**)&g.dev, bytes));
     hipError_t e = hipMemsetAsync(g.dev, 0, bytes, ctx->stream);
@@ -482,6 +493,15 @@ static int get_resident(eagle_ctx* ctx, const char* path, long rows, long cols, 
     ctx->cache.push_back(g);
     *out = &ctx->cache.back();
     return EAGLE_OK;
+}
+
+// Rows (multiple of 256) of a streamed chunk whose padded row length is `row_bytes`.
+static long stream_chunk_rows(long row_bytes, long total_rows_pad) {
+    size_t budget = resident_budget();
+    if (budget == (size_t)-1) budget = (size_t)8 << 30;  // 8 GiB chunks when streaming because HBM is full
+    long rows = (long)(budget / (size_t)row_bytes) / 256 * 256;
+    if (rows < 256) rows = 256;
+    return rows < total_rows_pad ? rows : total_rows_pad;
 }
 
 // column-major n x n host matrix -> zero padded np x np device image (row-major image of the transpose)
@@ -540,20 +560,49 @@ extern "C" int eagle_calculateMMt(eagle_ctx* ctx, const char* f_name_ascii, doub
         if (rows_in_block <= 0) return eagle_fail(ctx, EAGLE_ERR_ARG, "availmemGb too small: zero rows per block");
         if (!quiet) say(ctx, "number of rows in block is %ld", rows_in_block);  // :107
     }
+    const int threads = num_cores > 0 ? num_cores : 1;
+    const long np = eagle_pad(n);
     GenoEntry* g = nullptr;
-    rc = get_resident(ctx, f_name_ascii, n, L, max_memory_in_Gbytes, num_cores > 0 ? num_cores : 1, &g);
-    if (rc) return rc;
-    const long np = g->rows_pad;
-    DevBuf c32, dsel;
+    rc = get_resident(ctx, f_name_ascii, n, L, max_memory_in_Gbytes, threads, &g, sizeof(int32_t) * (size_t)np * np * 2);
+    if (rc < 0) return rc;
+    DevBuf c32, dsel, win;
     HIPCHK(ctx, c32.alloc(sizeof(int32_t) * (size_t)np * np));
     HIPCHK(ctx, hipMemsetAsync(c32.p, 0, sizeof(int32_t) * (size_t)np * np, ctx->stream));
-    rc = eagle_dev_mmt_accumulate(ctx, g->dev, np, g->ld, g->ld, c32.as<int32_t>(), ctx->stream);
-    if (rc) return rc;
-    if (!sel.empty()) {  // :88-92 as an exact rank-k downdate
-        HIPCHK(ctx, dsel.alloc(sizeof(long) * sel.size()));
-        HIPCHK(ctx, hipMemcpyAsync(dsel.p, sel.data(), sizeof(long) * sel.size(), hipMemcpyHostToDevice, ctx->stream));
-        rc = eagle_dev_mmt_downdate(ctx, g->dev, np, g->ld, dsel.as<long>(), (long)sel.size(), c32.as<int32_t>(), ctx->stream);
+    if (rc == EAGLE_OK) {
+        rc = eagle_dev_mmt_accumulate(ctx, g->dev, np, g->ld, g->ld, c32.as<int32_t>(), ctx->stream);
         if (rc) return rc;
+        if (!sel.empty()) {  // :88-92 as an exact rank-k downdate
+            HIPCHK(ctx, dsel.alloc(sizeof(long) * sel.size()));
+            HIPCHK(ctx, hipMemcpyAsync(dsel.p, sel.data(), sizeof(long) * sel.size(), hipMemcpyHostToDevice, ctx->stream));
+            rc = eagle_dev_mmt_downdate(ctx, g->dev, np, g->ld, dsel.as<long>(), (long)sel.size(), c32.as<int32_t>(), ctx->stream);
+            if (rc) return rc;
+        }
+    } else {
+        // M.ascii does not fit (or may not stay) in HBM: stream column windows of every line (= marker chunks) and
+        // accumulate the exact integer partial products, MMt = sum_w M_w M_w^T.
+        const long Lw = stream_chunk_rows(np, eagle_pad(L));  // window width in markers; rows of the window = np
+        HIPCHK(ctx, win.alloc((size_t)np * Lw));
+        if (!quiet) say(ctx, " M.ascii streamed through HBM in windows of %ld markers", Lw);
+        for (long c0 = 0; c0 < L; c0 += Lw) {
+            const long nc = std::min(Lw, L - c0);
+            HIPCHK(ctx, hipMemsetAsync(win.p, 0, (size_t)np * Lw, ctx->stream));
+            rc = eagle_dev_load_ascii(ctx, f_name_ascii, 0, n, c0, nc, win.as<int8_t>(), Lw, max_memory_in_Gbytes, threads);
+            if (rc) return rc;
+            rc = eagle_dev_mmt_accumulate(ctx, win.as<int8_t>(), np, Lw, Lw, c32.as<int32_t>(), ctx->stream);
+            if (rc) return rc;
+            std::vector<long> in_win;
+            for (long c : sel) if (c >= c0 && c < c0 + nc) in_win.push_back(c - c0);
+            if (!in_win.empty()) {
+                DevBuf dw;
+                HIPCHK(ctx, dw.alloc(sizeof(long) * in_win.size()));
+                HIPCHK(ctx, hipMemcpyAsync(dw.p, in_win.data(), sizeof(long) * in_win.size(), hipMemcpyHostToDevice, ctx->stream));
+                // duplicates of one column must be dropped across the whole list, which k_mmt_downdate does per call:
+                // selected_loci entries are distinct columns in any sane call; duplicates inside one window are handled
+                rc = eagle_dev_mmt_downdate(ctx, win.as<int8_t>(), np, Lw, dw.as<long>(), (long)in_win.size(), c32.as<int32_t>(), ctx->stream);
+                if (rc) return rc;
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            }
+        }
     }
     if (ctx->mmt_n != n) {
         if (ctx->d_mmt) { (void)hipFree(ctx->d_mmt); ctx->d_mmt = nullptr; }
@@ -622,17 +671,22 @@ extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_asc
         }
         if (rows_in_block == 0) return eagle_fail(ctx, EAGLE_ERR_ARG, "availmemGb too small: zero rows per block");
     }
-    GenoEntry* g = nullptr;
-    rc = get_resident(ctx, f_name_ascii, L, n, max_memory_in_Gbytes, host_threads(), &g);
-    if (rc) return rc;
-    const long np = g->ld, Lp = g->rows_pad;
-    DevBuf dsel;
+    const long np = eagle_pad(n), Lp = eagle_pad(L);
     const size_t sq = sizeof(double) * (size_t)np * np;
     const bool use_i8 = ctx->scan_mode == 1 && 64.0 * 128.0 * (double)np < 2147483648.0;
     const int nslices = ctx->scan_slices;
-    const size_t wsb = use_i8 ? (size_t)eagle_vara_i8_workspace_bytes(np, Lp, nslices) : 0;
+    GenoEntry* g = nullptr;
+    rc = get_resident(ctx, f_name_ascii, L, n, max_memory_in_Gbytes, host_threads(), &g,
+                      4 * sq + (use_i8 ? (size_t)eagle_vara_i8_workspace_bytes(np, Lp, nslices) : 0) + ((size_t)1 << 30));
+    if (rc < 0) return rc;
+    const bool streamed = (rc == EAGLE_STREAM);
+    const long Lc = streamed ? stream_chunk_rows(np, Lp) : Lp;  // marker rows per pass
+    DevBuf dsel;
+    const size_t wsb = use_i8 ? (size_t)eagle_vara_i8_workspace_bytes(np, Lc, nslices) : 0;
     const double t0 = now_s();
-    if ((rc = arena_reserve(ctx, 4 * arena_round(sq) + 2 * arena_round(sizeof(double) * np) + arena_round(wsb)))) return rc;
+    if ((rc = arena_reserve(ctx, 4 * arena_round(sq) + 2 * arena_round(sizeof(double) * np) + arena_round(wsb) +
+                                     (streamed ? arena_round((size_t)Lc * np) : 0))))
+        return rc;
     double* Sa = arena_take<double>(ctx, sq);
     double* Va = arena_take<double>(ctx, sq);
     double* tmp = arena_take<double>(ctx, sq);
@@ -640,6 +694,7 @@ extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_asc
     double* ah = arena_take<double>(ctx, sizeof(double) * np);
     double* v = arena_take<double>(ctx, sizeof(double) * np);
     void* ws = arena_take<char>(ctx, wsb);
+    int8_t* chunk = streamed ? arena_take<int8_t>(ctx, (size_t)Lc * np) : nullptr;
     if ((rc = upload_square(ctx, inv_MMt_sqrt, n, np, Sa))) return rc;
     if ((rc = upload_square(ctx, dim_reduced_vara, n, np, Va))) return rc;
     if ((rc = upload_vec(ctx, a, n, np, ah))) return rc;
@@ -648,20 +703,34 @@ extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_asc
     if (timing_on()) { (void)hipStreamSynchronize(ctx->stream); t1 = now_s(); }
     rc = eagle_dev_scan_operands(ctx, Sa, Va, ah, n, np, v, Wu, tmp, ctx->stream);
     if (rc) return rc;
-    if (use_i8) {
-        // one pass over the genotypes gives a = Mt v and the diagonal term of vara; then the int8 MFMA kernel
-        rc = eagle_dev_vara_i8_prepare(ctx, g->dev, Lp, np, g->ld, Wu, nslices, ws, v, ctx->d_a, ctx->stream);
+    if (streamed && !quiet) say(ctx, " Mt.ascii streamed through HBM in blocks of %ld markers", Lc);
+    // one pass per marker block: the whole file when it is resident, else chunks read back from the file
+    for (long r0 = 0; r0 < L; r0 += Lc) {
+        const long nr = std::min(Lc, L - r0), nrp = eagle_pad(nr);
+        const int8_t* Mt8 = streamed ? chunk : g->dev;
+        const long ldm = streamed ? np : g->ld;
+        if (streamed) {
+            HIPCHK(ctx, hipMemsetAsync(chunk, 0, (size_t)nrp * np, ctx->stream));
+            rc = eagle_dev_load_ascii(ctx, f_name_ascii, r0, nr, 0, n, chunk, np, max_memory_in_Gbytes, host_threads());
+            if (rc) return rc;
+        }
+        if (use_i8) {
+            // one pass over the genotypes gives a = Mt v and the diagonal term of vara; then the int8 MFMA kernel
+            rc = eagle_dev_vara_i8_prepare(ctx, Mt8, nrp, np, ldm, Wu, nslices, ws, v, ctx->d_a + r0, ctx->stream);
+            if (rc) return rc;
+            rc = eagle_dev_vara_i8_mfma(ctx, Mt8, nrp, np, ldm, nslices, ws, ctx->d_vara + r0, nullptr, ctx->stream);
+        } else {
+            rc = eagle_dev_gemv_i8(ctx, Mt8, nrp, np, ldm, v, 1.0, ctx->d_a + r0, ctx->stream);
+            if (rc) return rc;
+            rc = eagle_dev_vara_f64(ctx, Mt8, nrp, np, ldm, Wu, ctx->d_vara + r0, ctx->stream);
+        }
         if (rc) return rc;
-        rc = eagle_dev_vara_i8_mfma(ctx, g->dev, Lp, np, g->ld, nslices, ws, ctx->d_vara, nullptr, ctx->stream);
-    } else {
-        rc = eagle_dev_gemv_i8(ctx, g->dev, Lp, np, g->ld, v, 1.0, ctx->d_a, ctx->stream);
-        if (rc) return rc;
-        rc = eagle_dev_vara_f64(ctx, g->dev, Lp, np, g->ld, Wu, ctx->d_vara, ctx->stream);
+        if (streamed) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the chunk buffer is reused
     }
     if (timing_on()) {
         (void)hipStreamSynchronize(ctx->stream);
-        fprintf(stderr, "[eaglehip] scan n=%ld L=%ld: alloc+upload %.1f ms, device compute %.1f ms\n", n, L, (t1 - t0) * 1e3,
-                (now_s() - t1) * 1e3);
+        fprintf(stderr, "[eaglehip] scan n=%ld L=%ld%s: alloc+upload %.1f ms, device compute %.1f ms\n", n, L,
+                streamed ? " (streamed)" : "", (t1 - t0) * 1e3, (now_s() - t1) * 1e3);
     }
     if (rc) return rc;
     if (!sel.empty()) {  // :79-84: a zeroed marker row gives a = 0 and vara = 0 exactly
@@ -770,20 +839,34 @@ extern "C" int eagle_calculate_reduced_a(eagle_ctx* ctx, const char* f_name_asci
         eagle_fail(ctx, EAGLE_SOFT_SENTINEL, "availmemGb: cannot even read in a single row of data into memory");
         return EAGLE_SOFT_SENTINEL;
     }
+    const long np = eagle_pad(n), Lp = eagle_pad(L);
     GenoEntry* g = nullptr;
-    rc = get_resident(ctx, f_name_ascii, L, n, max_memory_in_Gbytes, host_threads(), &g);
-    if (rc) return rc;
-    const long np = g->ld, Lp = g->rows_pad;
-    DevBuf Pa, yv, py, out, dsel;
+    rc = get_resident(ctx, f_name_ascii, L, n, max_memory_in_Gbytes, host_threads(), &g,
+                      sizeof(double) * (size_t)np * np + ((size_t)1 << 30));
+    if (rc < 0) return rc;
+    const bool streamed = (rc == EAGLE_STREAM);
+    const long Lc = streamed ? stream_chunk_rows(np, Lp) : Lp;
+    DevBuf Pa, yv, py, out, dsel, chunk;
     HIPCHK(ctx, Pa.alloc(sizeof(double) * (size_t)np * np));
     HIPCHK(ctx, yv.alloc(sizeof(double) * np)); HIPCHK(ctx, py.alloc(sizeof(double) * np));
     HIPCHK(ctx, out.alloc(sizeof(double) * Lp));
+    if (streamed) HIPCHK(ctx, chunk.alloc((size_t)Lc * np));
     if ((rc = upload_square(ctx, P, n, np, Pa.as<double>()))) return rc;
     if ((rc = upload_vec(ctx, y, n, np, yv.as<double>()))) return rc;
     rc = eagle_dev_colgemv(ctx, Pa.as<double>(), n, np, yv.as<double>(), py.as<double>(), ctx->stream);  // :82
     if (rc) return rc;
-    rc = eagle_dev_gemv_i8(ctx, g->dev, Lp, np, g->ld, py.as<double>(), varG, out.as<double>(), ctx->stream);  // :83-84
-    if (rc) return rc;
+    for (long r0 = 0; r0 < L; r0 += Lc) {  // :83-84, one pass per marker block (the whole file when resident)
+        const long nr = std::min(Lc, L - r0), nrp = eagle_pad(nr);
+        if (streamed) {
+            HIPCHK(ctx, hipMemsetAsync(chunk.p, 0, (size_t)nrp * np, ctx->stream));
+            rc = eagle_dev_load_ascii(ctx, f_name_ascii, r0, nr, 0, n, chunk.as<int8_t>(), np, max_memory_in_Gbytes, host_threads());
+            if (rc) return rc;
+        }
+        rc = eagle_dev_gemv_i8(ctx, streamed ? chunk.as<int8_t>() : g->dev, nrp, np, streamed ? np : g->ld, py.as<double>(), varG,
+                               out.as<double>() + r0, ctx->stream);
+        if (rc) return rc;
+        if (streamed) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     if (!sel.empty()) {  // :74-78
         HIPCHK(ctx, dsel.alloc(sizeof(long) * sel.size()));
         HIPCHK(ctx, hipMemcpyAsync(dsel.p, sel.data(), sizeof(long) * sel.size(), hipMemcpyHostToDevice, ctx->stream));

@@ -80,7 +80,9 @@ int eagle_read_block(eagle_ctx* ctx, const char* asciifname, long start_row, lon
  *           int num_cores, NumericVector selected_loci, std::vector<long> dims, bool quiet,
  *           Function message)                    E/src/calculateMMt_rcpp.cpp:19-185, RcppExports.cpp:37-52
  * dims = (n, L) of M.ascii.  MMt_out: n x n column-major.  max_memory_in_Gbytes bounds HOST staging
- * (the genotype tiles are streamed through pinned memory); num_cores bounds host reader threads. */
+ * (the genotype tiles are streamed through pinned memory); num_cores bounds host reader threads.
+ * A file that does not fit in HBM (or exceeds the environment variable EAGLE_HIP_MAX_RESIDENT_GB) is streamed in
+ * marker windows and the exact integer partial products are accumulated; the same holds for the two scans below. */
 int eagle_calculateMMt(eagle_ctx* ctx, const char* f_name_ascii, double max_memory_in_Gbytes, int num_cores,
                        const double* selected_loci, long n_selected, const long dims[2], int quiet,
                        double* MMt_out);

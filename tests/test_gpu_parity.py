@@ -282,6 +282,41 @@ def test_scan_nonsymmetric_operands(big, api, oracle, mode, request):
     np.testing.assert_allclose(res["vara"].ravel()[:4096], v_ref, rtol=1e-8)
 
 
+def test_streamed_paths_match_resident(big, api, oracle, monkeypatch):
+    """Files larger than the resident budget are streamed through HBM in marker chunks (the out-of-core case, BASELINE
+    config 4); forced here with a 5 MB budget.  Results must equal the resident path bit for bit (same kernels, same
+    per-marker order; MM^T is an exact integer sum over windows)."""
+    Mt8, geno, S, V, ahat = big
+    L, n = Mt8.shape
+    rng = np.random.default_rng(2)
+    P = rng.standard_normal((n, n)) / n
+    y = rng.standard_normal(n)
+    sel = np.array([7.0, 5000.0, float(L - 1)])
+    api.drop_cache()
+    res = {}
+    for tag, budget in (("resident", None), ("streamed", "0.005")):
+        if budget:
+            monkeypatch.setenv("EAGLE_HIP_MAX_RESIDENT_GB", budget)
+        api.drop_cache()
+        msgs = []
+        res[tag] = dict(
+            mmt=api.calculateMMt_rcpp(geno["asciifileM"], 8.0, 4, NA, (n, L), quiet=False, message=msgs.append),
+            mmt_m=api.calculateMMt_rcpp(geno["asciifileM"], 8.0, 4, sel, (n, L)),
+            scan=api.calculate_a_and_vara_rcpp(geno["asciifileMt"], sel, S, V, 8.0, (L, n), ahat, quiet=False, message=msgs.append),
+            idx=api.last_scan_argmax(),
+            ar=api.calculate_reduced_a_rcpp(geno["asciifileMt"], 0.7, P, y, 8.0, (n, L), NA))
+        assert any("streamed" in m for m in msgs) == (budget is not None)
+    monkeypatch.delenv("EAGLE_HIP_MAX_RESIDENT_GB")
+    api.drop_cache()
+    for k in ("mmt", "mmt_m", "ar"):
+        np.testing.assert_array_equal(res["streamed"][k], res["resident"][k])
+    np.testing.assert_array_equal(res["streamed"]["scan"]["a"], res["resident"]["scan"]["a"])
+    np.testing.assert_array_equal(res["streamed"]["scan"]["vara"], res["resident"]["scan"]["vara"])
+    assert res["streamed"]["idx"] == res["resident"]["idx"]
+    G = Mt8.astype(np.float64)
+    np.testing.assert_array_equal(res["streamed"]["mmt"], G.T @ G)
+
+
 def test_large_n_device_path(api, oracle):
     """n = 12000 (47 column tiles: odd count, vectors too large for the LDS-resident genotype pass), device-resident
     entry points only, checked against the oracle on a marker sample and through exact properties of MM^T."""
