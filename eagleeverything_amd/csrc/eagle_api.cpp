@@ -56,6 +56,7 @@ struct eagle_ctx {
     double* d_a = nullptr; double* d_vara = nullptr; long scan_L = 0; long scan_cap = 0;
     void* d_scratch = nullptr;
     void* arena = nullptr; size_t arena_cap = 0, arena_off = 0;  // grow-only device workspace reused across calls
+    void* stage_pin[2] = {nullptr, nullptr}; void* stage_raw[2] = {nullptr, nullptr}; size_t stage_cap = 0;  // tile streamer
     char arch[64] = {0};
     int cu_count = 0;
     int64_t hbm_bytes = 0;
@@ -197,6 +198,7 @@ extern "C" void eagle_close(eagle_ctx* ctx) {
     if (ctx->d_vara) (void)hipFree(ctx->d_vara);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->arena) (void)hipFree(ctx->arena);
+    for (int b = 0; b < 2; b++) { if (ctx->stage_pin[b]) (void)hipHostFree(ctx->stage_pin[b]); if (ctx->stage_raw[b]) (void)hipFree(ctx->stage_raw[b]); }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -332,20 +334,31 @@ static int load_tile_fixed(eagle_ctx* ctx, FileInfo& fi, long row0, long nrows, 
     const bool at_end = (col0 + ncols == fi.width);
     const long src_bytes = at_end ? ncols + 1 : ncols;
     const long stride = src_bytes;
-    // staging budget: a quarter of availmemGb per buffer, within [one row, 256 MiB]
+    // staging budget: a quarter of availmemGb per buffer, within [one row, 64 MiB]; the two pinned / device staging
+    // buffers live in the ctx (page-locking 100s of MB per call costs more than the copy it feeds)
     double budget = max_mem_gb > 0 ? max_mem_gb * 1e9 / 4.0 : 64e6;
-    long chunk_rows = (long)std::max(1.0, std::min(budget, 268435456.0) / (double)stride);
+    long chunk_rows = (long)std::max(1.0, std::min(budget, 67108864.0) / (double)stride);
     chunk_rows = std::min(chunk_rows, nrows);
-    PinBuf pin[2];
-    DevBuf raw[2], bad;
+    const size_t need = (size_t)chunk_rows * stride;
+    if (need > ctx->stage_cap) {
+        for (int b = 0; b < 2; b++) {
+            if (ctx->stage_pin[b]) { (void)hipHostFree(ctx->stage_pin[b]); ctx->stage_pin[b] = nullptr; }
+            if (ctx->stage_raw[b]) { (void)hipFree(ctx->stage_raw[b]); ctx->stage_raw[b] = nullptr; }
+        }
+        ctx->stage_cap = 0;
+        for (int b = 0; b < 2; b++) {
+            HIPCHK(ctx, hipHostMalloc(&ctx->stage_pin[b], need, hipHostMallocDefault));
+            HIPCHK(ctx, hipMalloc(&ctx->stage_raw[b], need));
+        }
+        ctx->stage_cap = need;
+    }
+    char* pin[2] = {(char*)ctx->stage_pin[0], (char*)ctx->stage_pin[1]};
+    uint8_t* raw[2] = {(uint8_t*)ctx->stage_raw[0], (uint8_t*)ctx->stage_raw[1]};
+    DevBuf bad;
     hipEvent_t done[2] = {nullptr, nullptr};
     HIPCHK(ctx, bad.alloc(sizeof(int)));
     HIPCHK(ctx, hipMemsetAsync(bad.p, 0, sizeof(int), ctx->stream));
-    for (int b = 0; b < 2; b++) {
-        HIPCHK(ctx, pin[b].alloc((size_t)chunk_rows * stride));
-        HIPCHK(ctx, raw[b].alloc((size_t)chunk_rows * stride));
-        HIPCHK(ctx, hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
-    }
+    for (int b = 0; b < 2; b++) HIPCHK(ctx, hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
     int rc = EAGLE_OK;
     volatile int io_err = 0;
     long k = 0;
@@ -356,14 +369,14 @@ static int load_tile_fixed(eagle_ctx* ctx, FileInfo& fi, long row0, long nrows, 
             hipError_t e = hipEventSynchronize(done[b]);  // the copy out of pin[b] two chunks ago has finished
             if (e != hipSuccess) { rc = eagle_fail_hip(ctx, e, "hipEventSynchronize"); break; }
         }
-        parallel_pread(fi.fd, (uint8_t*)pin[b].p, stride, nr, src_bytes, (off_t)(row0 + r) * line + col0, line, threads,
+        parallel_pread(fi.fd, (uint8_t*)pin[b], stride, nr, src_bytes, (off_t)(row0 + r) * line + col0, line, threads,
                        &io_err);
         if (io_err) { rc = eagle_fail(ctx, EAGLE_ERR_FORMAT, "short read: file has fewer lines than requested"); break; }
-        hipError_t e = hipMemcpyAsync(raw[b].p, pin[b].p, (size_t)nr * stride, hipMemcpyHostToDevice, ctx->stream);
+        hipError_t e = hipMemcpyAsync(raw[b], pin[b], (size_t)nr * stride, hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) { rc = eagle_fail_hip(ctx, e, "hipMemcpyAsync H2D"); break; }
         e = hipEventRecord(done[b], ctx->stream);
         if (e != hipSuccess) { rc = eagle_fail_hip(ctx, e, "hipEventRecord"); break; }
-        rc = eagle_dev_decode_ascii(ctx, raw[b].as<uint8_t>(), nr, ncols, stride, dst + r * ld, ld, bad.as<int>(), ctx->stream);
+        rc = eagle_dev_decode_ascii(ctx, raw[b], nr, ncols, stride, dst + r * ld, ld, bad.as<int>(), ctx->stream);
     }
     int nbad = 0;
     if (rc == EAGLE_OK) {
