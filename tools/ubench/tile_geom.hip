@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
+#include <algorithm>
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
@@ -92,13 +93,72 @@ __global__ __launch_bounds__(G::NW * 64) void k_tile(const int8_t* __restrict__ 
             }
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN>
+
+// Same engine on v_mfma_i32_16x16x64_i8: wave tile (WM*16) x (WN*16), two K=64 steps per 128-byte stage.
+template <class G, int WM, int WN>
+__global__ __launch_bounds__(G::NW * 64) void k_tile16(const int8_t* __restrict__ A, const int8_t* __restrict__ B, long ld, int nstages,
+                                                         int* __restrict__ C, long ldc, int wavesN) {
+    extern __shared__ __attribute__((aligned(1024))) int8_t lds[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = w / wavesN, wc = w % wavesN;
+    const int ldi = (int)ld;
+    const int voffE = (lane >> 3) * ldi + (((lane & 7) ^ (lane >> 4)) << 4);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (long)blockIdx.y * G::TM * ld), 0, G::TM * ldi, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(B + (long)blockIdx.x * G::TN * ld), 0, G::TN * ldi, 0x00020000);
+    i32x4 acc[WM][WN];
+#pragma unroll
+    for (int m = 0; m < WM; m++)
+#pragma unroll
+        for (int n = 0; n < WN; n++) acc[m][n] = (i32x4){0, 0, 0, 0};
+    const int r = lane & 15, q = lane >> 4, swz = (r >> 1) & 7;
+    stage_tile<G>(rsA, voffE, ldi, 0, lds, G::TM, w);
+    stage_tile<G>(rsB, voffE, ldi, 0, lds + G::A_BYTES, G::TN, w);
+    __syncthreads();
+    int cur = 0;
+    for (int st = 0; st < nstages; st++) {
+        int8_t* nb = lds + (cur ^ 1) * G::STAGE;
+        if (st + 1 < nstages) {
+            stage_tile<G>(rsA, voffE, ldi, (st + 1) * BK, nb, G::TM, w);
+            stage_tile<G>(rsB, voffE, ldi, (st + 1) * BK, nb + G::A_BYTES, G::TN, w);
+        }
+        const int8_t* pa = lds + cur * G::STAGE + (wr * WM * 16 + r) * BK;
+        const int8_t* pb = lds + cur * G::STAGE + G::A_BYTES + (wc * WN * 16 + r) * BK;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const int ch = ((4 * ks + q) ^ swz) << 4;
+            i32x4 a[WM], b[WN];
+#pragma unroll
+            for (int m = 0; m < WM; m++) a[m] = *(const i32x4*)(pa + m * 16 * BK + ch);
+#pragma unroll
+            for (int n = 0; n < WN; n++) b[n] = *(const i32x4*)(pb + n * 16 * BK + ch);
+#pragma unroll
+            for (int m = 0; m < WM; m++)
+#pragma unroll
+                for (int n = 0; n < WN; n++) acc[m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[m], b[n], acc[m][n], 0, 0, 0);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int m = 0; m < WM; m++)
+#pragma unroll
+        for (int n = 0; n < WN; n++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                long i = (long)blockIdx.y * G::TM + (wr * WM + m) * 16 + 4 * q + e;
+                long j = (long)blockIdx.x * G::TN + (wc * WN + n) * 16 + r;
+                C[i * ldc + j] = acc[m][n][e];
+            }
+}
+
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool SH16 = false>
 static void run(const char* name, const int8_t* dA, const int8_t* dB, long ld, int K, int Mrows, int Nrows, int* dC, const std::vector<int8_t>& hA,
                 const std::vector<int8_t>& hB) {
     using G = Geo<WAVES_M, WAVES_N, WM, WN>;
     const int gx = Nrows / G::TN, gy = Mrows / G::TM;
     const size_t ldsb = 2 * (size_t)G::STAGE;
-    auto kern = k_tile<G, WM, WN>;
+    auto kern = SH16 ? k_tile16<G, WM * 2, WN * 2> : k_tile<G, WM, WN>;
     CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -143,9 +203,15 @@ int main() {
     CHECK(hipMemcpy(dB, hB.data(), hB.size(), hipMemcpyHostToDevice));
     for (int round = 0; round < 2; round++) {
         run<2, 4, 4, 2>("G0", dA, dB, ld, K, Mrows, Nrows, dC, hA, hB);
+        run<2, 4, 4, 2, true>("G0/16x16x64", dA, dB, ld, K, Mrows, Nrows, dC, hA, hB);
         run<2, 2, 4, 4>("G1", dA, dB, ld, K, Mrows, Nrows, dC, hA, hB);
         run<2, 2, 4, 5>("G2b", dA, dB, ld, K, Mrows, 320 * 48, dC, hA, hB);
         run<2, 2, 4, 6>("G2", dA, dB, ld, K, Mrows, Nrows, dC, hA, hB);
     }
+    // the same two on all-zero operands: the gap to the random-data time is clock the chip gives back under load
+    CHECK(hipMemset(dA, 0, hA.size())); CHECK(hipMemset(dB, 0, hB.size()));
+    std::fill(hA.begin(), hA.end(), 0); std::fill(hB.begin(), hB.end(), 0);
+    run<2, 4, 4, 2>("G0 zeros", dA, dB, ld, K, Mrows, Nrows, dC, hA, hB);
+    run<2, 4, 4, 2, true>("G0/16x16x64 zeros", dA, dB, ld, K, Mrows, Nrows, dC, hA, hB);
     return 0;
 }
