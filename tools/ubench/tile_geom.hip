@@ -208,6 +208,15 @@ int main() {
         run<2, 2, 4, 5>("G2b", dA, dB, ld, K, Mrows, 320 * 48, dC, hA, hB);
         run<2, 2, 4, 6>("G2", dA, dB, ld, K, Mrows, Nrows, dC, hA, hB);
     }
+    // genotype coding: HWE-like genotype frequencies (g=0: 55 %, g=1: 35 %, g=2: 10 %) as m = g-1 (0xFF common) vs as g (0x00 common)
+    for (int coding = 0; coding < 2; coding++) {
+        for (auto& x : hA) { int u = rand() % 100; int g = u < 55 ? 0 : (u < 90 ? 1 : 2); x = (int8_t)(coding ? g : g - 1); }
+        CHECK(hipMemcpy(dA, hA.data(), hA.size(), hipMemcpyHostToDevice));
+        for (int rep = 0; rep < 2; rep++) {
+            run<2, 4, 4, 2>(coding ? "G0 A=g in {0,1,2}" : "G0 A=g-1 in {-1,0,1}", dA, dB, ld, K, Mrows, Nrows, dC, hA, hB);
+            run<2, 4, 4, 2, true>(coding ? "G0/16 A=g" : "G0/16 A=g-1", dA, dB, ld, K, Mrows, Nrows, dC, hA, hB);
+        }
+    }
     // the same two on all-zero operands: the gap to the random-data time is clock the chip gives back under load
     CHECK(hipMemset(dA, 0, hA.size())); CHECK(hipMemset(dB, 0, hB.size()));
     std::fill(hA.begin(), hA.end(), 0); std::fill(hB.begin(), hB.end(), 0);
