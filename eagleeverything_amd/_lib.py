@@ -29,6 +29,10 @@ SIGNATURES = {
     "eagle_device_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "eagle_set_scan_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "eagle_set_scan_slices": (C.c_int, [C.c_void_p, C.c_int]),
+    "eagle_get_row_column": (C.c_int, [C.c_void_p, C.c_char_p, c_lp]),
+    "eagle_create_M_ascii": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
+                                       C.c_double, c_lp, C.c_int, C.c_char_p]),
+    "eagle_create_Mt_ascii": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_double, c_lp, C.c_int]),
     "eagle_read_block": (C.c_int, [C.c_void_p, C.c_char_p, C.c_long, C.c_long, C.c_long, c_dp]),
     "eagle_calculateMMt": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double, C.c_int, c_dp, C.c_long, c_lp, C.c_int, c_dp]),
     "eagle_calculate_a_and_vara": (C.c_int, [C.c_void_p, C.c_char_p, c_dp, C.c_long, c_dp, c_dp, C.c_double, c_lp, c_dp,

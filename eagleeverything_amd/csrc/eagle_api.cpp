@@ -30,41 +30,9 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/eagle_hip.h"
-#include "eagle_internal.h"
+#include "eagle_ctx.h"
 
-struct GenoEntry {
-    std::string path;
-    off_t size = 0;
-    long mtime_ns = 0;
-    long rows = 0, cols = 0;          // logical tile held: all `rows` lines, first `cols` characters
-    long rows_pad = 0, ld = 0;
-    int8_t* dev = nullptr;
-};
-
-struct eagle_ctx {
-    int device = -1;
-    hipStream_t stream = nullptr;
-    char err[1024] = {0};
-    eagle_message_fn msg_fn = nullptr;
-    void* msg_user = nullptr;
-    int scan_mode = 1;   // 1 = int8 digit slices on the int8 MFMA (default), 0 = fp64 MFMA
-    int scan_slices = 0; // 0 = chosen per call from the error bound (3..7), 1..8 = fixed
-    std::vector<GenoEntry> cache;
-    // results of the last calls, kept in HBM
-    double* d_mmt = nullptr; long mmt_n = 0; double* d_mmt_max = nullptr;
-    double* d_a = nullptr; double* d_vara = nullptr; long scan_L = 0; long scan_cap = 0;
-    void* d_scratch = nullptr;
-    void* arena = nullptr; size_t arena_cap = 0, arena_off = 0;  // grow-only device workspace reused across calls
-    void* stage_pin[2] = {nullptr, nullptr}; void* stage_raw[2] = {nullptr, nullptr}; size_t stage_cap = 0;  // tile streamer
-    char arch[64] = {0};
-    int cu_count = 0;
-    int64_t hbm_bytes = 0;
-};
-
-static thread_local char g_open_err[512];
-static int host_threads() { unsigned h = std::thread::hardware_concurrency(); return h == 0 ? 1 : (h > 16 ? 16 : (int)h); }
-
+thread_local char g_open_err[512];
 extern "C" int eagle_fail(eagle_ctx* ctx, int code, const char* msg) {
     if (ctx) snprintf(ctx->err, sizeof ctx->err, "%s", msg);
     return code;
@@ -73,41 +41,6 @@ extern "C" int eagle_fail_hip(eagle_ctx* ctx, hipError_t e, const char* where) {
     if (ctx) snprintf(ctx->err, sizeof ctx->err, "HIP error in %s: %s", where, hipGetErrorString(e));
     return EAGLE_ERR_HIP;
 }
-static int failf(eagle_ctx* ctx, int code, const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    if (ctx) vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
-    va_end(ap);
-    return code;
-}
-static void say(eagle_ctx* ctx, const char* fmt, ...) {
-    if (!ctx->msg_fn) return;
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    ctx->msg_fn(buf, ctx->msg_user);
-}
-
-#define HIPCHK(ctx, call)                                              \
-    do {                                                               \
-        hipError_t e__ = (call);                                       \
-        if (e__ != hipSuccess) return eagle_fail_hip(ctx, e__, #call); \
-    } while (0)
-
-// RAII device / pinned buffers so every error path frees what it took
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
-    template <class T> T* as() { return (T*)p; }
-};
-struct PinBuf {
-    void* p = nullptr;
-    ~PinBuf() { if (p) (void)hipHostFree(p); }
-    hipError_t alloc(size_t bytes) { return hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault); }
-};
 
 // Grow-only device arena: the n x n operand images and kernel workspaces of a call are carved from one allocation that
 // survives between calls (a find_qtl iteration would otherwise pay ~10 hipMalloc/hipFree pairs of 100s of MB each).
@@ -326,6 +259,23 @@ static void parallel_pread(int fd, uint8_t* dst, long dst_stride, long nrows, lo
     for (auto& th : pool) th.join();
 }
 
+// Two pinned host buffers + two device buffers of at least `need` bytes each, owned by the ctx (grow-only).
+int eagle_stage_ensure(eagle_ctx* ctx, size_t need) {
+    if (need <= ctx->stage_cap) return EAGLE_OK;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int b = 0; b < 2; b++) {
+        if (ctx->stage_pin[b]) { (void)hipHostFree(ctx->stage_pin[b]); ctx->stage_pin[b] = nullptr; }
+        if (ctx->stage_raw[b]) { (void)hipFree(ctx->stage_raw[b]); ctx->stage_raw[b] = nullptr; }
+    }
+    ctx->stage_cap = 0;
+    for (int b = 0; b < 2; b++) {
+        HIPCHK(ctx, hipHostMalloc(&ctx->stage_pin[b], need, hipHostMallocDefault));
+        HIPCHK(ctx, hipMalloc(&ctx->stage_raw[b], need));
+    }
+    ctx->stage_cap = need;
+    return EAGLE_OK;
+}
+
 static int load_tile_fixed(eagle_ctx* ctx, FileInfo& fi, long row0, long nrows, long col0, long ncols, int8_t* dst,
                            long ld, double max_mem_gb, int threads) {
     const long line = fi.width + 1;
@@ -339,19 +289,8 @@ static int load_tile_fixed(eagle_ctx* ctx, FileInfo& fi, long row0, long nrows, 
     double budget = max_mem_gb > 0 ? max_mem_gb * 1e9 / 4.0 : 64e6;
     long chunk_rows = (long)std::max(1.0, std::min(budget, 67108864.0) / (double)stride);
     chunk_rows = std::min(chunk_rows, nrows);
-    const size_t need = (size_t)chunk_rows * stride;
-    if (need > ctx->stage_cap) {
-        for (int b = 0; b < 2; b++) {
-            if (ctx->stage_pin[b]) { (void)hipHostFree(ctx->stage_pin[b]); ctx->stage_pin[b] = nullptr; }
-            if (ctx->stage_raw[b]) { (void)hipFree(ctx->stage_raw[b]); ctx->stage_raw[b] = nullptr; }
-        }
-        ctx->stage_cap = 0;
-        for (int b = 0; b < 2; b++) {
-            HIPCHK(ctx, hipHostMalloc(&ctx->stage_pin[b], need, hipHostMallocDefault));
-            HIPCHK(ctx, hipMalloc(&ctx->stage_raw[b], need));
-        }
-        ctx->stage_cap = need;
-    }
+    int rcs = eagle_stage_ensure(ctx, (size_t)chunk_rows * stride);
+    if (rcs) return rcs;
     char* pin[2] = {(char*)ctx->stage_pin[0], (char*)ctx->stage_pin[1]};
     uint8_t* raw[2] = {(uint8_t*)ctx->stage_raw[0], (uint8_t*)ctx->stage_raw[1]};
     DevBuf bad;
@@ -476,18 +415,41 @@ static size_t resident_budget() {
 // [pad128(rows)][pad128(cols)].
 // Returns EAGLE_OK (*out set), EAGLE_STREAM (too large: the caller streams marker chunks) or an error.
 // reserve_bytes: HBM the caller still needs for operands and workspaces.
-static int get_resident(eagle_ctx* ctx, const char* path, long rows, long cols, double max_mem_gb, int threads,
-                        GenoEntry** out, size_t reserve_bytes = (size_t)1 << 30) {
+static bool file_key(const char* path, off_t* size, long* mtime_ns) {
     struct stat st;
-    if (stat(path, &st) != 0) return failf(ctx, EAGLE_ERR_OPEN, "ERROR: Could not open  %s", path);
-    long mt = (long)st.st_mtim.tv_sec * 1000000000L + st.st_mtim.tv_nsec;
+    if (stat(path, &st) != 0) return false;
+    *size = st.st_size;
+    *mtime_ns = (long)st.st_mtim.tv_sec * 1000000000L + st.st_mtim.tv_nsec;
+    return true;
+}
+const GenoEntry* eagle_cache_find(eagle_ctx* ctx, const char* path, long rows, long cols) {
+    off_t size; long mt;
+    if (!file_key(path, &size, &mt)) return nullptr;
     for (auto& g : ctx->cache)
-        if (g.path == path && g.size == st.st_size && g.mtime_ns == mt && g.rows == rows && g.cols == cols) { *out = &g; return EAGLE_OK; }
-    // stale entries of the same path are dropped
+        if (g.path == path && g.size == size && g.mtime_ns == mt && g.rows == rows && g.cols == cols) return &g;
+    return nullptr;
+}
+static void cache_drop_path(eagle_ctx* ctx, const char* path) {
     for (size_t i = 0; i < ctx->cache.size();)
         if (ctx->cache[i].path == path) { (void)hipFree(ctx->cache[i].dev); ctx->cache.erase(ctx->cache.begin() + i); } else i++;
+}
+int eagle_cache_adopt(eagle_ctx* ctx, const char* path, long rows, long cols, long rows_pad, long ld, int8_t* dev) {
+    cache_drop_path(ctx, path);
     GenoEntry g;
-    g.path = path; g.size = st.st_size; g.mtime_ns = mt; g.rows = rows; g.cols = cols;
+    if (!file_key(path, &g.size, &g.mtime_ns)) { (void)hipFree(dev); return failf(ctx, EAGLE_ERR_OPEN, "ERROR: Could not open  %s", path); }
+    g.path = path; g.rows = rows; g.cols = cols; g.rows_pad = rows_pad; g.ld = ld; g.dev = dev;
+    ctx->cache.push_back(g);
+    return EAGLE_OK;
+}
+
+static int get_resident(eagle_ctx* ctx, const char* path, long rows, long cols, double max_mem_gb, int threads,
+                        GenoEntry** out, size_t reserve_bytes = (size_t)1 << 30) {
+    off_t fsize; long mt;
+    if (!file_key(path, &fsize, &mt)) return failf(ctx, EAGLE_ERR_OPEN, "ERROR: Could not open  %s", path);
+    if (const GenoEntry* hit = eagle_cache_find(ctx, path, rows, cols)) { *out = const_cast<GenoEntry*>(hit); return EAGLE_OK; }
+    cache_drop_path(ctx, path);  // stale entries of the same path
+    GenoEntry g;
+    g.path = path; g.size = fsize; g.mtime_ns = mt; g.rows = rows; g.cols = cols;
     g.rows_pad = eagle_pad(rows); g.ld = eagle_pad(cols);
     size_t bytes = (size_t)g.rows_pad * (size_t)g.ld;
     if (bytes > resident_budget()) return EAGLE_STREAM;
@@ -507,6 +469,14 @@ static int get_resident(eagle_ctx* ctx, const char* path, long rows, long cols, 
     *out = &ctx->cache.back();
     return EAGLE_OK;
 }
+
+int eagle_get_resident(eagle_ctx* ctx, const char* path, long rows, long cols, double max_mem_gb, int threads, const GenoEntry** out) {
+    GenoEntry* g = nullptr;
+    int rc = get_resident(ctx, path, rows, cols, max_mem_gb, threads, &g);
+    *out = g;
+    return rc;
+}
+size_t eagle_resident_budget() { return resident_budget(); }
 
 // Rows (multiple of 256) of a streamed chunk whose padded row length is `row_bytes`.
 static long stream_chunk_rows(long row_bytes, long total_rows_pad) {

@@ -846,3 +846,83 @@ extern "C" int eagle_dev_tsq_argmax(eagle_ctx* ctx, const double* a, const doubl
     return EAGLE_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Marker-file ingestion.
+//   k_encode_ascii : int8 {-1,0,1} rows -> text lines '0','1','2' + '\n'   (what CreateASCIInospace.cpp:132-135 and
+//                    createMt_ASCII_rcpp.cpp:104-118 write)
+//   k_plink_code   : PLINK allele characters -> genotype codes, one thread per locus walking the individuals in file
+//                    order, because the reference's allele table evolves row by row
+//                    (E/src/CreateASCIInospace_PLINK.cpp:95-187)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_encode_ascii(const int8_t* __restrict__ in, long rows, long cols, long ld_in,
+                                                      uint8_t* __restrict__ out) {
+    const long row = blockIdx.y;
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c > cols) return;
+    out[row * (cols + 1) + c] = c == cols ? (uint8_t)'\n' : (uint8_t)('0' + 1 + in[row * ld_in + c]);
+}
+
+extern "C" int eagle_dev_encode_ascii(eagle_ctx* ctx, const int8_t* in, long rows, long cols, long ld_in, uint8_t* out, void* stream) {
+    if (rows <= 0) return EAGLE_OK;
+    for (long r0 = 0; r0 < rows; r0 += 65535) {
+        long nr = rows - r0 < 65535 ? rows - r0 : 65535;
+        dim3 grid((unsigned)((cols + 1 + 255) / 256), (unsigned)nr);
+        hipLaunchKernelGGL(k_encode_ascii, grid, dim3(256), 0, (hipStream_t)stream, in + r0 * ld_in, nr, cols, ld_in, out + r0 * (cols + 1));
+    }
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+
+// chars: rows x 2L allele characters (one per allele, in file order) of individuals row0 .. row0+rows-1.
+// alleles0/alleles1: the per-locus allele table, carried across calls.  out: int8 genotype - 1 at out[r*ld + i].
+// first_err / first_missing: smallest row-major position (row*L + locus) of a third allele / of a missing allele.
+__global__ __launch_bounds__(256) void k_plink_code(const uint8_t* __restrict__ chars, long rows, long L, long row0,
+                                                    uint8_t* __restrict__ alleles0, uint8_t* __restrict__ alleles1,
+                                                    int8_t* __restrict__ out, long ld, unsigned long long* __restrict__ first_err,
+                                                    unsigned long long* __restrict__ first_missing) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= L) return;
+    uint8_t a0 = alleles0[i], a1 = alleles1[i];
+    bool dead = false;  // a third allele was met: the reference has returned, later rows are never coded
+    for (long r = 0; r < rows; r++) {
+        uint8_t c0 = chars[r * 2 * L + 2 * i], c1 = chars[r * 2 * L + 2 * i + 1];
+        const bool miss = c0 == '0' || c1 == '0' || c0 == '-' || c1 == '-';
+        if (row0 + r == 0) {                                   // :95-106
+            if (miss) { a0 = 'I'; a1 = 'I'; } else { a0 = c0; a1 = c1; }
+        }
+        int8_t code = 0;                                       // het / missing -> '1' -> 0
+        if (!dead) {
+            if (miss) {                                        // :110-123
+                atomicMin(first_missing, (unsigned long long)((row0 + r) * L + i));
+                c0 = 'I';
+                c1 = 'I';
+            }
+#pragma unroll
+            for (int j = 1; j >= 0; --j) {                     // :127-165
+                const uint8_t c = j ? c1 : c0;
+                if (c != a0 && c != a1 && c != 'I') {
+                    if (a0 == 'I') a0 = c;
+                    else if (a1 == 'I') a1 = c;
+                    else if (a0 == a1) a1 = c;
+                    else if (!dead) { dead = true; atomicMin(first_err, (unsigned long long)((row0 + r) * L + i)); }
+                }
+            }
+            if (c0 == 'I' || c1 == 'I' || c0 != c1) code = 0;  // :170-184
+            else code = c0 == a0 ? -1 : 1;
+        }
+        out[r * ld + i] = code;
+    }
+    alleles0[i] = a0;
+    alleles1[i] = a1;
+}
+
+extern "C" int eagle_dev_plink_code(eagle_ctx* ctx, const uint8_t* chars, long rows, long L, long row0, uint8_t* alleles0,
+                                    uint8_t* alleles1, int8_t* out, long ld, unsigned long long* first_err,
+                                    unsigned long long* first_missing, void* stream) {
+    if (rows <= 0 || L <= 0) return EAGLE_OK;
+    hipLaunchKernelGGL(k_plink_code, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, (hipStream_t)stream, chars, rows, L, row0, alleles0,
+                       alleles1, out, ld, first_err, first_missing);
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}

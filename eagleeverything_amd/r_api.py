@@ -86,3 +86,62 @@ def find_qtl(geno, availmemGb, selected_loci, MMt, invMMt, best_ve, best_vg, cur
     if return_stats:
         return indx, {"tsqmax": tsqmax, "near_ties": near, "a": a_and_vara["a"], "vara": a_and_vara["vara"]}
     return indx
+
+
+def create_ascii(file_genotype, type="text", AA=None, AB=None, BB=None, availmemGb=8, dim_of_ascii_M=None, quiet=True,
+                 missing=None, outdir=None, message=None, device=0):
+    """E/R/create_ascii.R:1-62 -> True / False; writes <outdir>/M.ascii and <outdir>/Mt.ascii (R: tempdir())."""
+    outdir = outdir or os.path.dirname(os.path.abspath(file_genotype))
+    asciiMfile, asciiMtfile = os.path.join(outdir, "M.ascii"), os.path.join(outdir, "Mt.ascii")
+    dims = [int(dim_of_ascii_M[0]), int(dim_of_ascii_M[1])]
+    if type == "text":
+        missing = "NA" if missing is None else str(missing)                       # :30-34
+        if not rcpp_api.createM_ASCII_rcpp(file_genotype, asciiMfile, type, AA, AB, BB, availmemGb, dims, quiet, message, missing,
+                                           device=device):
+            return False
+        rcpp_api.createMt_ASCII_rcpp(asciiMfile, asciiMtfile, type, availmemGb, dims, quiet, message, device=device)
+    else:
+        ncol = dims[1]
+        dims[1] = 2 * dims[1] + 6                                                   # :46-47 columns of a PLINK ped file
+        if not rcpp_api.createM_ASCII_rcpp(file_genotype, asciiMfile, type, "-9", "-9", "-9", availmemGb, dims, quiet, message, "NA",
+                                           device=device):
+            return False
+        dims[1] = ncol                                                              # :54
+        rcpp_api.createMt_ASCII_rcpp(asciiMfile, asciiMtfile, type, availmemGb, dims, quiet, message, device=device)
+    return True
+
+
+def ReadMarker(filename=None, type="text", missing=None, AA=None, AB=None, BB=None, availmemGb=16, quiet=True, outdir=None,
+               message=None, device=0):
+    """E/R/ReadMarker.R:194-318 -> geno dict {asciifileM, asciifileMt, dim_of_ascii_M} or None (the R list / NULL)."""
+    say = message or (lambda s: None)
+    if type not in ("text", "PLINK"):                                               # :206-215
+        say(' type must be set to "text" or "PLINK". \n')
+        say(" ReadMarker has terminated with errors")
+        return None
+    if filename is None or not os.path.exists(filename):                            # :222-231, check_inputs.R
+        say(" The %s file %s could not be found. " % ("PLINK ped" if type == "PLINK" else "marker", filename))
+        say(" ReadMarker has terminated with errors ")
+        return None
+    genofile = os.path.abspath(filename)
+    outdir = outdir or os.path.dirname(genofile)
+    if type == "PLINK":
+        dims = rcpp_api.getRowColumn(genofile, device=device)                       # :234-235
+        dims[1] = (dims[1] - 6) // 2
+        ok = create_ascii(genofile, type=type, availmemGb=availmemGb, dim_of_ascii_M=dims, quiet=quiet, outdir=outdir,
+                          message=message, device=device)
+    else:
+        if AA is None or BB is None:                                                # :262-268
+            say("Error: The function parameters AA and BB must be assigned a numeric or character value since a text file is being assumed. \n")
+            say(" ReadMarker has terminated with errors")
+            return None
+        if AB is None:
+            AB = "NA"                                                               # :271-272 no hets
+        say(" Getting number of individuals and snp from file ... ")
+        dims = rcpp_api.getRowColumn(genofile, device=device)                       # :283
+        say(" Beginning creation of reformatted file ... ")
+        ok = create_ascii(genofile, type=type, AA=str(AA), AB=str(AB), BB=str(BB), availmemGb=availmemGb, dim_of_ascii_M=dims,
+                          quiet=quiet, missing=missing, outdir=outdir, message=message, device=device)
+    if not ok:
+        return None
+    return {"asciifileM": os.path.join(outdir, "M.ascii"), "asciifileMt": os.path.join(outdir, "Mt.ascii"), "dim_of_ascii_M": dims}

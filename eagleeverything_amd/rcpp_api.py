@@ -198,3 +198,37 @@ def last_mmt_normalised(n, device=0):
     mx = C.c_double()
     _check(ctx, L.eagle_last_mmt_normalised(ctx, _dp(out), C.byref(mx)))
     return out, mx.value
+
+
+# ---- marker-file ingestion (E/src/RcppExports.cpp:92-151): same argument order as the reference's exports ----
+def getRowColumn(fname, device=0):
+    L = _lib.load()
+    ctx = context(device)
+    d = (C.c_long * 2)()
+    _check(ctx, L.eagle_get_row_column(ctx, os.fsencode(fname), d))
+    return [int(d[0]), int(d[1])]
+
+
+def createM_ASCII_rcpp(f_name, f_name_ascii, type, AA, AB, BB, max_memory_in_Gbytes, dims, quiet=True, message=None,
+                       missing="NA", device=0):
+    """-> bool it_worked (createM_ASCII_rcpp.cpp:18-106).  last_error() describes a False."""
+    L = _lib.load()
+    ctx = context(device)
+    _set_message(ctx, message)
+    enc = lambda v: str(v).encode()  # R passes AA=0, AB=1, BB=2 through as.character
+    rc = _check(ctx, L.eagle_create_M_ascii(ctx, os.fsencode(f_name), os.fsencode(f_name_ascii), enc(type), enc(AA), enc(AB),
+                                            enc(BB), float(max_memory_in_Gbytes), _dims(dims), int(bool(quiet)), enc(missing)),
+                soft_ok=True)
+    return rc == 0
+
+
+def createMt_ASCII_rcpp(f_name, f_name_ascii, type, max_memory_in_Gbytes, dims, quiet=True, message=None, device=0):
+    L = _lib.load()
+    ctx = context(device)
+    _set_message(ctx, message)
+    _check(ctx, L.eagle_create_Mt_ascii(ctx, os.fsencode(f_name), os.fsencode(f_name_ascii), str(type).encode(),
+                                        float(max_memory_in_Gbytes), _dims(dims), int(bool(quiet))))
+
+
+def last_error(device=0):
+    return _lib.load().eagle_last_error(context(device)).decode()

@@ -119,6 +119,39 @@ int eagle_calculate_reduced_a(eagle_ctx* ctx, const char* f_name_ascii, double v
 int eagle_extract_geno(eagle_ctx* ctx, const char* f_name_ascii, double max_memory_in_Gbytes, long selected_locus,
                        const long dims[2], int* column_out);
 
+/* ---------------------------------------------------------------------------------------------
+ * 1b. Marker-file ingestion (the producers of M.ascii / Mt.ascii that ReadMarker() calls, E/R/create_ascii.R:27-58).
+ *     Same results byte for byte; additionally the int8 images of both files stay resident in HBM under the OUTPUT
+ *     paths, so the eagle_calculateMMt / eagle_calculate_a_and_vara calls that follow never parse text.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Replaces  std::vector<long> getRowColumn(std::string fname)      E/src/getRowColumn.cpp:20-72, RcppExports.cpp:143-151
+ * dims_out = (lines, whitespace-separated tokens of the first line). */
+int eagle_get_row_column(eagle_ctx* ctx, const char* fname, long dims_out[2]);
+
+/* Replaces  bool createM_ASCII_rcpp(CharacterVector f_name, CharacterVector f_name_ascii, CharacterVector type,
+ *           std::string AA, std::string AB, std::string BB, double max_memory_in_Gbytes, std::vector<long> dims,
+ *           bool quiet, Function message, std::string missing)
+ *                                                E/src/createM_ASCII_rcpp.cpp:18-106, RcppExports.cpp:92-111
+ * type "PLINK": f_name is a ped file, dims = (individuals, 6 + 2*loci), AA/AB/BB/missing unused
+ *               (E/src/CreateASCIInospace_PLINK.cpp:16-249: first-seen allele order, 0 / - = missing -> het);
+ * otherwise   : a whitespace-separated genotype table, dims = (individuals, loci), tokens BB -> '2', AB -> '1',
+ *               AA -> '0', missing -> '1'  (E/src/CreateASCIInospace.cpp:84-105).
+ * Returns EAGLE_OK where the reference returns true, EAGLE_SOFT_SENTINEL where it prints its messages and returns
+ * false (unknown token, unequal number of columns, third allele; eagle_last_error holds a one-line summary and the
+ * output file keeps the rows converted before the failure, like the reference's). */
+int eagle_create_M_ascii(eagle_ctx* ctx, const char* f_name, const char* f_name_ascii, const char* type, const char* AA,
+                         const char* AB, const char* BB, double max_memory_in_Gbytes, const long dims[2], int quiet,
+                         const char* missing);
+
+/* Replaces  void createMt_ASCII_rcpp(CharacterVector f_name, CharacterVector f_name_ascii, CharacterVector type,
+ *           double max_memory_in_Gbytes, std::vector<long> dims, bool quiet, Function message)
+ *                                                E/src/createMt_ASCII_rcpp.cpp:14-247, RcppExports.cpp:113-126
+ * f_name = M.ascii (dims = (n, L)), f_name_ascii = Mt.ascii to write (L lines of n characters).  The transpose runs on
+ * the device from the resident image of M.ascii (loaded if it is not there; column windows if it does not fit). */
+int eagle_create_Mt_ascii(eagle_ctx* ctx, const char* f_name, const char* f_name_ascii, const char* type,
+                          double max_memory_in_Gbytes, const long dims[2], int quiet);
+
 /* Replaces the R tail of .find_qtl:  tsq <- a^2/vara ; which(tsq == max(tsq, na.rm=TRUE))[1]
  *                                                E/R/find_qtl.R:71-83
  * Evaluated on the device on the a / vara of the LAST eagle_calculate_a_and_vara call of this ctx (still in

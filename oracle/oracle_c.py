@@ -19,7 +19,8 @@ c_lp = C.POINTER(C.c_long)
 
 
 def build(force=False):
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "eagle_oracle.c")):
+    srcs = [os.path.join(_HERE, f) for f in ("eagle_oracle.c", "eagle_oracle_ingest.c")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "libeagle_oracle.so"])
 
 
@@ -48,6 +49,11 @@ def lib():
         L.eo_extract_geno.argtypes = [C.c_char_p, C.c_long, C.c_long, C.c_long, C.POINTER(C.c_int)]
         L.eo_set_num_threads.argtypes = [C.c_int]
         L.eo_set_num_threads.restype = None
+        L.eo_getRowColumn.argtypes = [C.c_char_p, c_lp]
+        L.eo_create_ascii_text.argtypes = [C.c_char_p, C.c_char_p, C.c_long, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
+                                           c_lp, c_lp, C.c_char_p, C.c_long]
+        L.eo_create_ascii_plink.argtypes = [C.c_char_p, C.c_char_p, C.c_long, c_lp, c_lp, c_lp, C.POINTER(C.c_int)]
+        L.eo_createMt_ascii.argtypes = [C.c_char_p, C.c_char_p, C.c_long, C.c_long]
         _lib = L
     return _lib
 
@@ -198,3 +204,39 @@ def num_threads():
 
 def set_num_threads(t):
     lib().eo_set_num_threads(int(t))
+
+
+# ---- marker-file ingestion (eagle_oracle_ingest.c); argument order of E/src/RcppExports.cpp:92,113,143 ----
+def getRowColumn(fname):
+    d = (C.c_long * 2)()
+    rc = lib().eo_getRowColumn(os.fsencode(fname), d)
+    if rc:
+        raise OracleError("ERROR: Could not open  %s" % fname)
+    return [int(d[0]), int(d[1])]
+
+
+def createM_ASCII_rcpp(f_name, f_name_ascii, type, AA, AB, BB, max_memory_in_Gbytes, dims, quiet=True, message=None,
+                       missing="NA"):
+    """Returns (it_worked, info): info = dict(kind, row, token/columns/locus, missing_seen)."""
+    er, ec, el = C.c_long(0), C.c_long(0), C.c_long(0)
+    info = {}
+    if type == "PLINK":
+        ms = C.c_int(0)
+        rc = lib().eo_create_ascii_plink(os.fsencode(f_name), os.fsencode(f_name_ascii), int(dims[1]), C.byref(er), C.byref(el),
+                                         C.byref(ec), C.byref(ms))
+        info["missing_seen"] = bool(ms.value)
+    else:
+        tok = C.create_string_buffer(64)
+        rc = lib().eo_create_ascii_text(os.fsencode(f_name), os.fsencode(f_name_ascii), int(dims[1]), str(AA).encode(),
+                                        str(AB).encode(), str(BB).encode(), str(missing).encode(), C.byref(er), C.byref(ec), tok, 64)
+        info["token"] = tok.value.decode()
+    if rc < 0:
+        return False, {"kind": "open"}
+    info.update(kind={0: "ok", 1: "token", 2: "columns", 3: "alleles"}[rc], row=er.value, columns=ec.value, locus=el.value)
+    return rc == 0, info
+
+
+def createMt_ASCII_rcpp(f_name, f_name_ascii, type, max_memory_in_Gbytes, dims, quiet=True, message=None):
+    rc = lib().eo_createMt_ascii(os.fsencode(f_name), os.fsencode(f_name_ascii), int(dims[0]), int(dims[1]))
+    if rc:
+        raise OracleError("createMt_ASCII_rcpp failed (%d)" % rc)

@@ -87,6 +87,12 @@ def main():
     X = np.ones((203, 1))
     make_case("synth_203x1531", np.ascontiguousarray(Mt8.T), y, X, 1.0, 0.7)
 
+    # ingestion fixtures: the reference's own data pair, the same 150 x 100 genotypes as a PLINK ped file and as a
+    # 0/1/2 text table (DATA files, copied byte for byte)
+    import shutil
+    shutil.copyfile(os.path.join(REF, "geno.ped"), os.path.join(OUT, "geno_150x100.ped"))
+    shutil.copyfile(os.path.join(REF, "geno.txt"), os.path.join(OUT, "geno_150x100.txt"))
+
 
 if __name__ == "__main__":
     main()
