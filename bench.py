@@ -79,9 +79,17 @@ def main():
         if rank == 0:
             print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
+    # EAGLE_BENCH_BACKEND=gloo rehearses the N > 1 rank logic with several ranks on ONE card (collectives through the
+    # host); the measured configuration is always one rank per GPU over RCCL.
+    backend = os.environ.get("EAGLE_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "gloo":
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from eagleeverything_amd import rcpp_api
     from eagleeverything_amd.sharded import Collectives, DeviceShard
@@ -101,7 +109,7 @@ def main():
     def max_over_ranks(x):
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device=None if backend == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -283,7 +291,8 @@ def main():
             "dtype": "f64" if sh.mode == 0 else "i8 (int32/int64 exact sums, f64 finish)", "data": "synthetic",
             "config": {"workload": "synthetic %d individuals x %d SNPs per GPU (HWE genotypes, int8 resident in HBM), "
                                    "single trait, full calculate_a_and_vara pass + tsq arg-max" % (n, Lloc),
-                       "n": n, "markers_per_gpu": Lloc, "markers_total": Ltot, "parallelism": "marker-shard x%d" % world,
+                       "n": n, "markers_per_gpu": Lloc, "markers_total": Ltot,
+                       "parallelism": "marker-shard x%d" % world + (" (REHEARSAL: gloo, ranks share one card)" if backend == "gloo" and world > 1 else ""),
                        "scan_mode": args.mode, "slices": S_used, "vara_abs_error_bound": vara_bound, "operands": "simple" if args.simple_operands else "model algebra on MM^T" + (" (reloaded)" if args.load_operands else "")},
             "mmt_build_s": mmt_build_s, "selected_marker": int(sel[0]), "tsqmax": sel[1],
             "roofline": roof, "roofline_secondary": secondary, "cpu_baseline": cpu, "parity": parity,

@@ -34,23 +34,35 @@ class Collectives:
         self.dist = dist
         self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
+        # gloo (CPU tests, and the 2-ranks-on-one-GPU rehearsal of bench.py) moves device tensors through the host
+        self.via_host = self.world > 1 and dist.get_backend() == "gloo"
+
+    def _staged(self, t, fn):
+        if self.via_host and t.is_cuda:
+            h = t.cpu()
+            fn(h)
+            t.copy_(h)
+        else:
+            fn(t)
+        return t
 
     def sum_partial_mmt(self, c32):
         """In-place sum of the int32 partial MM^T tensors of all ranks (exact)."""
         if self.world > 1:
-            self.dist.all_reduce(c32, op=self.dist.ReduceOp.SUM)
+            self._staged(c32, lambda x: self.dist.all_reduce(x, op=self.dist.ReduceOp.SUM))
         return c32
 
     def broadcast_(self, t, src=0):
         if self.world > 1:
-            self.dist.broadcast(t, src=src)
+            self._staged(t, lambda x: self.dist.broadcast(x, src=src))
         return t
 
     def best_marker(self, local_tsqmax, local_index0_global, device=None):
         """All-gather (tsqmax, global 0-based index or -1) and pick find_qtl.R:76-80's marker.
         Returns (1-based global index or 0, tsqmax)."""
         import torch
-        mine = torch.tensor([float(local_tsqmax), float(local_index0_global)], dtype=torch.float64, device=device)
+        mine = torch.tensor([float(local_tsqmax), float(local_index0_global)], dtype=torch.float64,
+                            device=None if self.via_host else device)
         if self.world > 1:
             allv = [torch.empty_like(mine) for _ in range(self.world)]
             self.dist.all_gather(allv, mine)
