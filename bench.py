@@ -210,6 +210,16 @@ def main():
     value = Ltot * args.steps / elapsed
     kern_s = float(np.mean([a.elapsed_time(b) for a, b in ev])) / 1e3
     gemv_s = float(np.mean([a.elapsed_time(b) for a, b in ev_gemv])) / 1e3
+    # the HBM-bound kernel of the scan on its own (a = Mt v: L*n genotype bytes, read once), outside the timed steps
+    gp = []
+    for _ in range(4):
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g0.record()
+        sh.gemv_a()
+        g1.record()
+        torch.cuda.synchronize(dev)
+        gp.append(g0.elapsed_time(g1))
+    gpass_s = float(np.median(gp[1:])) / 1e3
 
     # ---- roofline of the dominant kernel (vara) ---------------------------------------------------
     np_, Lp = sh.np_, sh.Lp
@@ -242,8 +252,10 @@ def main():
     roof["reference_flops_per_launch"] = 2.0 * Lloc * n * n + 2.0 * Lloc * n
     roof["fp64_equiv_tflops"] = roof["reference_flops_per_launch"] / kern_s / 1e12
     secondary = {
-        "genotype_pass (a = Mt v%s)" % ("" if sh.mode == 0 else " + diagonal term + slicing of W"): {"bound": "hbm", "achieved": Lp * np_ / gemv_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": Lp * np_ / gemv_s / 1e9 / HBM_PEAK_GBS, "kernel_ms": gemv_s * 1e3},
+        "genotype_pass": {"bound": "hbm", "kernel": "k_slice_vec + k_gemv_mfma (a = Mt v; algorithmic bytes = L_pad*n_pad genotype bytes)",
+                          "achieved": Lp * np_ / gpass_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": Lp * np_ / gpass_s / 1e9 / HBM_PEAK_GBS, "kernel_ms": gpass_s * 1e3},
+        "scan_prepare_ms": gemv_s * 1e3,  # inside a step: the same pass fused with the diagonal term of vara, + slicing of W (i8 mode)
         "syrk_i8": {"bound": "mfma", "achieved": (np_ * (np_ + 128.0)) * Lp / syrk_s / 1e12, "peak": I8_MFMA_PEAK_TOPS,
                     "unit": "TFLOP/s", "frac": (np_ * (np_ + 128.0)) * Lp / syrk_s / 1e12 / I8_MFMA_PEAK_TOPS,
                     "kernel_ms": syrk_s * 1e3},

@@ -131,6 +131,7 @@ extern "C" void eagle_close(eagle_ctx* ctx) {
     if (ctx->d_vara) (void)hipFree(ctx->d_vara);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->gemv_ws) (void)hipFree(ctx->gemv_ws);
     for (int b = 0; b < 2; b++) { if (ctx->stage_pin[b]) (void)hipHostFree(ctx->stage_pin[b]); if (ctx->stage_raw[b]) (void)hipFree(ctx->stage_raw[b]); }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;

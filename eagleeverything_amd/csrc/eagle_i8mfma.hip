@@ -524,8 +524,8 @@ extern "C" int eagle_dev_vara_i8_prepare(eagle_ctx* ctx, const int8_t* Mt8, long
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "vara_i8 memset");
     hipLaunchKernelGGL(k_absmax_offdiag, dim3(1024), dim3(256), 0, s, Wu, n_pad, (unsigned long long*)&hdr->maxabs_off);
     hipLaunchKernelGGL(k_vara_prep, dim3(1), dim3(256), 0, s, Wu, n_pad, nslices, hdr, dW);
-    if (v) rc = eagle_dev_gemv2_i8(ctx, Mt8, L_pad, n_pad, ld, v, dW, 1.0, a_out, vdiag, stream);
-    else rc = eagle_dev_gemv_i8_sq(ctx, Mt8, L_pad, n_pad, ld, dW, vdiag, stream);
+    // one pass over the genotypes: a = Mt8 v (if asked for) and the diagonal term (a NULL a_out drops the a half)
+    rc = eagle_dev_gemv2_i8(ctx, Mt8, L_pad, n_pad, ld, v ? v : dW, dW, 1.0, v ? a_out : nullptr, vdiag, stream);
     if (rc) return rc;
     dim3 g2((unsigned)(n_pad / 32), (unsigned)(n_pad / 32));
     hipLaunchKernelGGL(k_slice_w, g2, dim3(256), 0, s, Wu, n_pad, hdr, Bs);

@@ -19,9 +19,6 @@ void* eagle_ctx_scratch(eagle_ctx* ctx);
 int eagle_dev_gemv2_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* v, const double* w,
                        double scale, double* out_a, double* out_d, void* stream);
 int eagle_dev_extract_col(eagle_ctx* ctx, const int8_t* M8, long n, long ld, long col, int* out, void* stream);
-// out_i = sum_j Mt8[i][j]^2 v[j]
-int eagle_dev_gemv_i8_sq(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* v, double* out,
-                         void* stream);
 #ifdef __cplusplus
 }
 #endif

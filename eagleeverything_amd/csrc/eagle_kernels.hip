@@ -6,13 +6,14 @@
 //   k_gemm_f64<..> ........ fp64 MFMA GEMM core (v_mfma_f64_16x16x4_f64):
 //                             A = f64 : W = S (V S)                     (calculate_a_and_vara_rcpp.cpp:97-98)
 //                             A = int8: T = Mt W fused with the row-dot (calculate_a_and_vara_rcpp.cpp:103-112)
-//   k_gemv_i8 ............. a = Mt v                                    (calculate_a_and_vara_rcpp.cpp:91,
+//   k_gemv_mfma ........... a = Mt v (+ diagonal term of vara)          (calculate_a_and_vara_rcpp.cpp:91,
 //                                                                        calculate_reduced_a_rcpp.cpp:83-84)
 //   k_tsq_* ............... tsq = a^2/vara, first arg-max ignoring NaN  (E/R/find_qtl.R:71-83)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/eagle_hip.h"
+#include "eagle_ctx.h"
 #include "eagle_internal.h"
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -404,121 +405,6 @@ __global__ __launch_bounds__(256) void k_colgemv(const double* __restrict__ At, 
     if (w == 0) out[i] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
-// ------------------------------------------------------------------------------------------------
-// a_i = scale * sum_j Mt8[i][j] v[j].  One wave owns 4 marker rows at a time; every lane streams 16
-// genotype bytes per row per step (coalesced 1 KiB per wave-instruction) and the 16 matching v values,
-// then a wavefront shuffle reduction.  HBM-bound on the genotype bytes.
-// ------------------------------------------------------------------------------------------------
-template <bool SQ>  // SQ: sum_j Mt8[i][j]^2 v[j] (the diagonal term of the quadratic form)
-__global__ __launch_bounds__(256) void k_gemv_i8(const int8_t* __restrict__ Mt8, long L_pad, long n_pad, long ld,
-                                                 const double* __restrict__ v, double scale, double* __restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const long wave = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
-    const long nwaves = ((long)gridDim.x * 256) >> 6;
-    for (long r0 = wave * 4; r0 < L_pad; r0 += nwaves * 4) {
-        double s[4] = {0, 0, 0, 0};
-        for (long c = (long)lane * 16; c < n_pad; c += 1024) {
-            union { i32x4 q; int8_t b[16]; } m[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) m[r].q = *(const i32x4*)(Mt8 + (r0 + r) * ld + c);
-            double vv[16];
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                f64x2 x = *(const f64x2*)(v + c + 2 * q);
-                vv[2 * q] = x[0];
-                vv[2 * q + 1] = x[1];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-#pragma unroll
-                for (int q = 0; q < 16; q++) s[r] += (double)(SQ ? m[r].b[q] * m[r].b[q] : (int)m[r].b[q]) * vv[q];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            double x = s[r];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
-            if (lane == 0) out[r0 + r] = scale * x;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Fused marker pass: a_i = scale * sum_j m_ij v_j  and (optionally)  d_i = sum_j m_ij^2 w_j  in ONE read of the
-// genotype bytes.  v (and w) live in LDS for the whole block, permuted so that lane l's 16-byte reads of iteration
-// `it` are consecutive across lanes (conflict-free ds_read_b128); a wave owns 8 marker rows at a time = 8 KiB of
-// coalesced 16-B-per-lane loads in flight; fixed summation order (lane-strided, then a shuffle tree): deterministic.
-// LDS: 8*n_pad bytes per vector, so both vectors fit up to n_pad = 10240, one vector up to 20480.
-// ------------------------------------------------------------------------------------------------
-template <bool SQ>
-__global__ __launch_bounds__(512) void k_gemv2_i8(const int8_t* __restrict__ Mt8, long L_pad, int n_pad, long ld,
-                                                  const double* __restrict__ v, const double* __restrict__ w, double scale,
-                                                  double* __restrict__ out_a, double* __restrict__ out_d) {
-    extern __shared__ __attribute__((aligned(16))) double lvec[];
-    const int nit = n_pad / 1024 + ((n_pad % 1024) ? 1 : 0);  // column strips of 1024
-    double* lv = lvec;
-    double* lw = lvec + (long)nit * 1024;
-    // LDS image: element (it, j, lane, e) = vec[it*1024 + lane*16 + 2*j + e]
-    for (int idx = threadIdx.x; idx < nit * 512; idx += 512) {
-        const int it = idx >> 9, rem = idx & 511, j = rem >> 6, lane = rem & 63;
-        const int c = it * 1024 + lane * 16 + 2 * j;
-        f64x2 x = {0.0, 0.0}, y = {0.0, 0.0};
-        if (c < n_pad) {
-            x = *(const f64x2*)(v + c);
-            if (SQ) y = *(const f64x2*)(w + c);
-        }
-        *(f64x2*)(lv + (long)idx * 2) = x;
-        if (SQ) *(f64x2*)(lw + (long)idx * 2) = y;
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const long wave = ((long)blockIdx.x * 512 + threadIdx.x) >> 6;
-    const long nwaves = ((long)gridDim.x * 512) >> 6;
-    for (long r0 = wave * 8; r0 < L_pad; r0 += nwaves * 8) {
-        double sa[8], sd[8];
-#pragma unroll
-        for (int r = 0; r < 8; r++) { sa[r] = 0.0; sd[r] = 0.0; }
-        for (int it = 0; it < nit; it++) {
-            const int c = it * 1024 + lane * 16;
-            union { i32x4 q; int8_t b[16]; } m[8];
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                m[r].q = (i32x4){0, 0, 0, 0};
-                if (c < n_pad) m[r].q = *(const i32x4*)(Mt8 + (r0 + r) * ld + c);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const f64x2 x = *(const f64x2*)(lv + ((long)(it * 8 + j) * 64 + lane) * 2);
-                f64x2 y = {0.0, 0.0};
-                if (SQ) y = *(const f64x2*)(lw + ((long)(it * 8 + j) * 64 + lane) * 2);
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    const int g0 = m[r].b[2 * j], g1 = m[r].b[2 * j + 1];
-                    sa[r] += (double)g0 * x[0];
-                    sa[r] += (double)g1 * x[1];
-                    if (SQ) {
-                        sd[r] += (double)(g0 * g0) * y[0];
-                        sd[r] += (double)(g1 * g1) * y[1];
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            double x = sa[r], y = sd[r];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                x += __shfl_down(x, o);
-                if (SQ) y += __shfl_down(y, o);
-            }
-            if (lane == 0) {
-                out_a[r0 + r] = scale * x;
-                if (SQ) out_d[r0 + r] = y;
-            }
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void k_extract_col(const int8_t* __restrict__ M8, long n, long ld, long col, int* __restrict__ out) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = (int)M8[i * ld + col];
@@ -735,72 +621,156 @@ extern "C" int eagle_dev_colgemv(eagle_ctx* ctx, const double* At, long n, long 
     return EAGLE_OK;
 }
 
-// LDS-resident-vector form; returns 1 if the vectors do not fit in LDS (caller falls back)
-static int gemv2_launch(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* v, const double* w,
-                        double scale, double* out_a, double* out_d, void* stream) {
-    if (L_pad % 8 || n_pad % 16 || ld % 16 || n_pad > ld) return 1;
-    const long nit = (n_pad + 1023) / 1024;
-    const size_t lds = (size_t)nit * 1024 * 8 * (w ? 2 : 1);
-    if (lds > 160 * 1024) return 1;
-    static bool attr_done[2] = {false, false};
-    if (!attr_done[w ? 1 : 0]) {
-        hipError_t e = w ? hipFuncSetAttribute((const void*)k_gemv2_i8<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-                         : hipFuncSetAttribute((const void*)k_gemv2_i8<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return eagle_fail_hip(ctx, e, "hipFuncSetAttribute");
-        attr_done[w ? 1 : 0] = true;
+
+// ------------------------------------------------------------------------------------------------
+// Genotype pass on the int8 MFMA:  a_i = scale * sum_k m_ik v_k   and   d_i = sum_k m_ik^2 w_k   in one sweep over the
+// genotype bytes (E/src/calculate_a_and_vara_rcpp.cpp:90-91, calculate_reduced_a_rcpp.cpp:83-84; d is the diagonal term
+// of the int8 vara path).  HBM-bound: L*n genotype bytes, read once.
+//
+// The fp64 vectors are turned into exact fixed point first (k_slice_vec): Q_k = rint(v_k * 2^(62-e)), max|v| < 2^e, as 8
+// balanced base-256 digits (peeled least significant first), so v_k = 2^(e-62) sum_s 256^s D_s[k] up to 2^(e-63) for
+// elements more than 10 binades below the largest and exactly otherwise.  B = [D_0..D_7 of v ; D_0..D_7 of w] is a
+// 16 x n_pad int8 matrix; v_mfma_i32_16x16x64_i8 gives P[i][s] = sum_k m_ik D_s[k] exactly (|P| <= 128 n), and
+// a_i = 2^(e-62) sum_s 256^s P[i][s] is assembled in int64 halves and rounded once.  m^2 = m & 1 for m in {-1,0,1}.
+// Two MFMAs (32 matrix cycles) per KiB of genotypes leave the kernel on the HBM stream: 0.478 ms for a and d at C2 (5.35 TB/s;
+// a alone 0.464 ms, 5.5 TB/s), where the fp64 VALU form it replaced (int8 -> fp64 convert + FMA per genotype, vectors in
+// LDS) took 0.62 ms for the pair (tools/bench_gemv.py history in DESIGN.md 3.4).  Nontemporal loads cost 12 %.
+// Wave = 16 markers x all k; lane (r = l&15, q = l>>4) loads the 16 bytes k = 64 step + 16 q .. of marker r and the same
+// k range of digit row r from LDS (16-byte chunks XOR-swizzled with r: conflict-free without padding, so that
+// n_pad = 10240 fits the 160 KiB exactly).
+// ------------------------------------------------------------------------------------------------
+#define GV_MAXN 10240
+__global__ __launch_bounds__(1024) void k_slice_vec(const double* __restrict__ v, const double* __restrict__ w, int n_pad,
+                                                    int8_t* __restrict__ B, int* __restrict__ exps) {
+    __shared__ double red[2][16];
+    __shared__ int ex[2];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    double mv = 0.0, mw = 0.0;
+    for (int k = t; k < n_pad; k += 1024) {
+        mv = fmax(mv, fabs(v[k]));
+        if (w) mw = fmax(mw, fabs(w[k]));
     }
-    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
-    long blocks = 256L * per_cu;
-    const long max_useful = (L_pad / 8 + 7) / 8;
-    if (blocks > max_useful) blocks = max_useful;
-    if (w) hipLaunchKernelGGL(k_gemv2_i8<true>, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, Mt8, L_pad, (int)n_pad, ld,
-                              v, w, scale, out_a, out_d);
-    else hipLaunchKernelGGL(k_gemv2_i8<false>, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, Mt8, L_pad, (int)n_pad, ld,
-                            v, w, scale, out_a, out_d);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "k_gemv2_i8");
-    return EAGLE_OK;
+    for (int o = 32; o > 0; o >>= 1) { mv = fmax(mv, __shfl_xor(mv, o)); mw = fmax(mw, __shfl_xor(mw, o)); }
+    if (lane == 0) { red[0][wv] = mv; red[1][wv] = mw; }
+    __syncthreads();
+    if (t < 2) {
+        double m = 0.0;
+        for (int i = 0; i < 16; i++) m = fmax(m, red[t][i]);
+        int e = 0;
+        if (m > 0.0 && m < INFINITY) (void)frexp(m, &e);  // m = f 2^e, f in [0.5,1)
+        ex[t] = e;
+        exps[t] = e;
+    }
+    __syncthreads();
+    for (int idx = t; idx < 2 * n_pad; idx += 1024) {
+        const int which = idx >= n_pad, k = idx - which * n_pad;
+        long long Q = 0;
+        if (!which) Q = llrint(ldexp(v[k], 62 - ex[0]));
+        else if (w) Q = llrint(ldexp(w[k], 62 - ex[1]));
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const long long d = ((Q + 128) & 255) - 128;
+            Q = (Q - d) >> 8;
+            B[(long)(8 * which + s) * n_pad + k] = (int8_t)d;
+        }
+    }
 }
 
-// a = scale * Mt8 v and d_i = sum_j Mt8[i][j]^2 w[j] in one pass over the genotypes (w may be NULL: a only).
+typedef int gv_i32x4 __attribute__((ext_vector_type(4)));
+#define GV_U 8  /* 16-byte loads per lane in flight: 8 KiB per wave, 128 KiB per CU */
+template <bool SQ>
+__global__ __launch_bounds__(1024) void k_gemv_mfma(const int8_t* __restrict__ Mt8, long L_pad, int n_pad, long ld,
+                                                    const int8_t* __restrict__ B, const int* __restrict__ exps, double scale,
+                                                    double* __restrict__ out_a, double* __restrict__ out_d, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) int8_t lB[];  // [16][n_pad], chunk c of row r stored at chunk c ^ r
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int nchunk = n_pad >> 4;
+    for (int idx = t; idx < 16 * nchunk; idx += 1024) {
+        const int r = idx / nchunk, c = idx - r * nchunk;
+        *(gv_i32x4*)(lB + (long)r * n_pad + ((c ^ r) << 4)) = *(const gv_i32x4*)(B + (long)r * n_pad + (c << 4));
+    }
+    __syncthreads();
+    const int r = lane & 15, q = lane >> 4;
+    const int8_t* brow = lB + (long)r * n_pad;
+    const double sa = scale * ldexp(1.0, exps[0] - 62), sd = ldexp(1.0, exps[1] - 62);
+    const long ngroups = L_pad >> 4;
+    for (long g = (long)blockIdx.x * 16 + wv; g < ngroups; g += (long)gridDim.x * 16) {
+        const int8_t* ap = Mt8 + (g * 16 + r) * ld + (q << 4);
+        gv_i32x4 accA = {0, 0, 0, 0}, accD = {0, 0, 0, 0};
+        const int nsteps = n_pad >> 6;  // n_pad % 256 == 0 in every caller: a multiple of 4
+        for (int st = 0; st < nsteps; st += GV_U) {
+            gv_i32x4 a[GV_U], b[GV_U];
+#pragma unroll
+            for (int u = 0; u < GV_U; u++)
+                a[u] = st + u < nsteps ? *(const gv_i32x4*)(ap + ((st + u) << 6)) : (gv_i32x4){0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < GV_U; u++)
+                b[u] = st + u < nsteps ? *(const gv_i32x4*)(brow + (((4 * (st + u) + q) ^ r) << 4)) : (gv_i32x4){0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < GV_U; u++) {
+                accA = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[u], b[u], accA, 0, 0, 0);
+                if (SQ) {
+                    const gv_i32x4 a2 = a[u] & (gv_i32x4){0x01010101, 0x01010101, 0x01010101, 0x01010101};
+                    accD = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b[u], accD, 0, 0, 0);
+                }
+            }
+        }
+        // lane holds P[row = 4q + e][col = r]: cols 0..7 of accA are the digits of v, cols 8..15 of accD those of w
+        const int s = r & 7;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const long long val = (r < 8) ? (long long)accA[e] : (long long)(SQ ? accD[e] : 0);
+            long long hi = s >= 4 ? val << (8 * (s - 4)) : 0, lo = s < 4 ? val << (8 * s) : 0;
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) { hi += __shfl_xor(hi, o); lo += __shfl_xor(lo, o); }
+            if (s == 0) {
+                const long row = g * 16 + 4 * q + e;
+                const double x = (double)hi * 4294967296.0 + (double)lo;
+                if (r == 0) { if (out_a) out_a[row] = accumulate ? out_a[row] + sa * x : sa * x; }
+                else if (SQ) out_d[row] = accumulate ? out_d[row] + sd * x : sd * x;
+            }
+        }
+    }
+}
+
+// a = scale * Mt8 v and d_i = sum_j Mt8[i][j]^2 w[j] in one pass over the genotypes (w may be NULL: a only; out_a may be
+// NULL: d only).
+// Individuals beyond GV_MAXN columns are taken in further sweeps of GV_MAXN columns that add into the outputs.
 extern "C" int eagle_dev_gemv2_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* v,
                                   const double* w, double scale, double* out_a, double* out_d, void* stream) {
-    if (L_pad == 0) return EAGLE_OK;
-    int rc = gemv2_launch(ctx, Mt8, L_pad, n_pad, ld, v, w, scale, out_a, out_d, stream);
-    if (rc != 1) return rc;
-    rc = eagle_dev_gemv_i8(ctx, Mt8, L_pad, n_pad, ld, v, scale, out_a, stream);
-    if (rc || !w) return rc;
-    return eagle_dev_gemv_i8_sq(ctx, Mt8, L_pad, n_pad, ld, w, out_d, stream);
+    if (L_pad % 16 || n_pad % 256 || ld % 16 || n_pad > ld) return eagle_fail(ctx, EAGLE_ERR_ARG, "gemv_i8: layout contract violated (L_pad % 16, n_pad % 256, ld % 16)");
+    if (L_pad == 0 || n_pad == 0) return EAGLE_OK;
+    if (!ctx->gemv_ws) {
+        hipError_t e = hipMalloc(&ctx->gemv_ws, 16 * GV_MAXN + 256);
+        if (e != hipSuccess) return eagle_fail_hip(ctx, e, "gemv workspace");
+    }
+    int8_t* B = (int8_t*)ctx->gemv_ws;
+    int* exps = (int*)(B + 16 * GV_MAXN);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemv_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemv_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return eagle_fail_hip(ctx, e, "hipFuncSetAttribute");
+        attr_done = true;
+    }
+    long blocks = 256;
+    const long groups = L_pad / 16;
+    if (blocks > (groups + 15) / 16) blocks = (groups + 15) / 16;
+    for (long k0 = 0; k0 < n_pad; k0 += GV_MAXN) {
+        const int nk = (int)(n_pad - k0 < GV_MAXN ? n_pad - k0 : GV_MAXN);
+        hipLaunchKernelGGL(k_slice_vec, dim3(1), dim3(1024), 0, (hipStream_t)stream, v + k0, w ? w + k0 : nullptr, nk, B, exps);
+        if (w) hipLaunchKernelGGL(k_gemv_mfma<true>, dim3((unsigned)blocks), dim3(1024), (size_t)16 * nk, (hipStream_t)stream, Mt8 + k0, L_pad, nk, ld,
+                                  B, exps, scale, out_a, out_d, k0 > 0);
+        else hipLaunchKernelGGL(k_gemv_mfma<false>, dim3((unsigned)blocks), dim3(1024), (size_t)16 * nk, (hipStream_t)stream, Mt8 + k0, L_pad, nk, ld,
+                                B, exps, scale, out_a, out_d, k0 > 0);
+    }
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
 }
 
 extern "C" int eagle_dev_gemv_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* v,
                                  double scale, double* out, void* stream) {
-    if (L_pad % 4 || n_pad % 16 || ld % 16 || n_pad > ld) return eagle_fail(ctx, EAGLE_ERR_ARG, "gemv_i8: layout contract violated");
-    if (L_pad == 0) return EAGLE_OK;
-    {
-        int rc2 = gemv2_launch(ctx, Mt8, L_pad, n_pad, ld, v, nullptr, scale, out, nullptr, stream);
-        if (rc2 != 1) return rc2;
-    }
-    long waves = L_pad / 4;
-    long blocks = (waves + 3) / 4;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(k_gemv_i8<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, Mt8, L_pad, n_pad, ld, v,
-                       scale, out);
-    LAUNCH_CHECK(ctx);
-    return EAGLE_OK;
-}
-
-extern "C" int eagle_dev_gemv_i8_sq(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* v,
-                                    double* out, void* stream) {
-    if (L_pad % 4 || n_pad % 16 || ld % 16 || n_pad > ld) return eagle_fail(ctx, EAGLE_ERR_ARG, "gemv_i8_sq: layout contract violated");
-    if (L_pad == 0) return EAGLE_OK;
-    // (the fused LDS kernel computes this as its second output; this entry is the large-n fallback)
-    long blocks = (L_pad / 4 + 3) / 4;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(k_gemv_i8<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, Mt8, L_pad, n_pad, ld, v,
-                       1.0, out);
-    LAUNCH_CHECK(ctx);
-    return EAGLE_OK;
+    return eagle_dev_gemv2_i8(ctx, Mt8, L_pad, n_pad, ld, v, nullptr, scale, out, nullptr, stream);
 }
 
 extern "C" int eagle_dev_vara_f64(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu,

@@ -210,8 +210,9 @@ int eagle_dev_mmt_normalise(eagle_ctx* ctx, double* MMt, long n, long ld, const 
  * tmp: n_pad*n_pad doubles of scratch. */
 int eagle_dev_scan_operands(eagle_ctx* ctx, const double* Sa, const double* Va, const double* ahat, long n,
                             long n_pad, double* v_out, double* Wu_out, double* tmp, void* stream);
-/* a_i = sum_j Mt8[i][j] v[j]  (scale * ...) for L_pad rows: calculate_a_and_vara_rcpp.cpp:91,
- * calculate_reduced_a_rcpp.cpp:83-84. */
+/* a_i = scale * sum_j Mt8[i][j] v[j] for L_pad rows: calculate_a_and_vara_rcpp.cpp:91, calculate_reduced_a_rcpp.cpp:83-84.
+ * HBM-bound pass on the int8 MFMA (v as 8 exact base-256 digit rows, int32 sums, one rounding per output).
+ * L_pad % 16 == 0, n_pad % 256 == 0, ld % 16 == 0. */
 int eagle_dev_gemv_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* v,
                       double scale, double* out, void* stream);
 /* vara_i = m_i^T W m_i for L_pad rows (calculate_a_and_vara_rcpp.cpp:103-112), fp64 MFMA kernel. */
