@@ -332,6 +332,55 @@ static int load_tile_fixed(eagle_ctx* ctx, FileInfo& fi, long row0, long nrows, 
     return rc;
 }
 
+// Tile from the 2-bit sidecar "<path>.e2b" when there is a valid one (made from this very text file: same size and
+// mtime): a quarter of the bytes to read.  Returns 1 when there is none (the caller parses the text), else a status.
+static int load_tile_sidecar(eagle_ctx* ctx, const char* path, const FileInfo& fi, long row0, long nrows, long col0, long ncols,
+                             int8_t* dst, long ld, int threads) {
+    if (!eagle_sidecar_enabled()) return 1;
+    std::string sp = std::string(path) + ".e2b";
+    int fd = open(sp.c_str(), O_RDONLY);
+    if (fd < 0) return 1;
+    struct Closer { int fd; ~Closer() { close(fd); } } closer{fd};
+    E2bHeader h;
+    if (pread(fd, &h, sizeof h, 0) != (ssize_t)sizeof h || memcmp(h.magic, "EAGLE2B", 8) != 0 || h.version != 1) return 1;
+    if ((off_t)h.src_size != fi.size || h.src_mtime_ns != fi.mtime_ns) return 1;  // stale: the text file changed
+    if ((uint64_t)(row0 + nrows) > h.rows || (uint64_t)(col0 + ncols) > h.cols) return 1;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || (uint64_t)st.st_size < sizeof h + h.rows * h.row_bytes) return 1;
+    const long b0 = col0 / 4, b1 = (col0 + ncols + 3) / 4;
+    const bool whole_rows = col0 == 0 && (uint64_t)ncols == h.cols;  // then the rows are one contiguous byte range
+    const long nb = whole_rows ? (long)h.row_bytes : b1 - b0;
+    const long stride = (nb + 15) / 16 * 16;
+    long chunk_rows = std::max(1L, std::min(nrows, (long)(67108864 / stride)));
+    int rc = eagle_stage_ensure(ctx, (size_t)chunk_rows * stride);
+    if (rc) return rc;
+    DevBuf bad;
+    HIPCHK(ctx, bad.alloc(sizeof(int)));
+    HIPCHK(ctx, hipMemsetAsync(bad.p, 0, sizeof(int), ctx->stream));
+    hipEvent_t done[2] = {nullptr, nullptr};
+    for (int b = 0; b < 2; b++) HIPCHK(ctx, hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
+    struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int b = 0; b < 2; b++) if (e[b]) (void)hipEventDestroy(e[b]); } } evg{done};
+    volatile int io_err = 0;
+    long k = 0;
+    for (long r = 0; r < nrows; r += chunk_rows, k++) {
+        const int b = (int)(k & 1);
+        const long nr = std::min(chunk_rows, nrows - r);
+        if (k >= 2) HIPCHK(ctx, hipEventSynchronize(done[b]));
+        parallel_pread(fd, (uint8_t*)ctx->stage_pin[b], stride, nr, nb, (off_t)sizeof h + (off_t)(row0 + r) * (off_t)h.row_bytes + b0,
+                       (long)h.row_bytes, threads, &io_err);
+        if (io_err) { (void)hipStreamSynchronize(ctx->stream); return eagle_fail(ctx, EAGLE_ERR_FORMAT, "short read from the 2-bit sidecar"); }
+        HIPCHK(ctx, hipMemcpyAsync(ctx->stage_raw[b], ctx->stage_pin[b], (size_t)nr * stride, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipEventRecord(done[b], ctx->stream));
+        rc = eagle_dev_unpack2b(ctx, (const uint8_t*)ctx->stage_raw[b], nr, ncols, stride, (int)(col0 % 4), dst + r * ld, ld, bad.as<int>(), ctx->stream);
+        if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    }
+    int nbad = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&nbad, bad.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (nbad) return failf(ctx, EAGLE_ERR_FORMAT, "%d invalid genotype codes in %s", nbad, sp.c_str());
+    return EAGLE_OK;
+}
+
 // General path: arbitrary line lengths.  Lines are located on the host; the first `col0+ncols` characters of
 // each wanted line are required to exist (the reference indexes past the end of a short line: undefined).
 static int load_tile_general(eagle_ctx* ctx, FileInfo& fi, long row0, long nrows, long col0, long ncols, int8_t* dst,
@@ -393,6 +442,8 @@ extern "C" int eagle_dev_load_ascii(eagle_ctx* ctx, const char* path, long row0,
     int rc = open_file(ctx, path, fi);
     if (rc) return rc;
     if (nrows == 0 || ncols == 0) return EAGLE_OK;
+    rc = load_tile_sidecar(ctx, path, fi, row0, nrows, col0, ncols, dst, ld, threads);
+    if (rc != 1) return rc;
     if (fi.width >= 0) {
         if (row0 + nrows > fi.nlines) return eagle_fail(ctx, EAGLE_ERR_FORMAT, "file has fewer lines than requested");
         if (col0 + ncols > fi.width) return eagle_fail(ctx, EAGLE_ERR_FORMAT, "line shorter than the requested columns");

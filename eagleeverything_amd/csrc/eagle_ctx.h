@@ -4,7 +4,9 @@
 #define EAGLE_CTX_H
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
+#include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <sys/types.h>
 
 #include <string>
@@ -90,6 +92,23 @@ int eagle_cache_adopt(eagle_ctx* ctx, const char* path, long rows, long cols, lo
 // Resident copy of a file if the cache holds one that matches the file's current size and mtime, else nullptr.
 const GenoEntry* eagle_cache_find(eagle_ctx* ctx, const char* path, long rows, long cols);
 int eagle_stage_ensure(eagle_ctx* ctx, size_t need);
+
+// 2-bit sidecar "<text file>.e2b": 64-byte header + rows x row_bytes packed genotype codes.  It is only trusted while
+// the text file it was made from still has the recorded size and mtime.
+struct E2bHeader {
+    char magic[8];        // "EAGLE2B\0"
+    uint32_t version;     // 1
+    uint32_t reserved;
+    uint64_t rows, cols, row_bytes;
+    uint64_t src_size;
+    int64_t src_mtime_ns;
+    uint64_t pad;
+};
+static_assert(sizeof(E2bHeader) == 64, "E2bHeader is the 64-byte file header");
+extern "C" int eagle_dev_pack2b(eagle_ctx* ctx, const int8_t* in, long rows, long cols, long ld_in, uint8_t* out, long row_bytes, void* stream);
+extern "C" int eagle_dev_unpack2b(eagle_ctx* ctx, const uint8_t* raw, long rows, long cols, long stride, int shift, int8_t* out,
+                                  long ld_out, int* bad_dev, void* stream);
+inline bool eagle_sidecar_enabled() { const char* e = getenv("EAGLE_HIP_SIDECAR"); return !(e && e[0] == '0'); }
 // Whole-file resident copy (loads it if needed); EAGLE_OK, 2 (too large for HBM: stream it) or an error.
 int eagle_get_resident(eagle_ctx* ctx, const char* path, long rows, long cols, double max_mem_gb, int threads, const GenoEntry** out);
 size_t eagle_resident_budget();

@@ -160,6 +160,67 @@ bool fits_resident(size_t bytes) {
     return bytes + ((size_t)2 << 30) < freeb;
 }
 
+
+// Incremental writer of the 2-bit sidecar "<text file>.e2b" (layout: E2bHeader in eagle_ctx.h).  Rows are packed on the
+// device from the int8 image the caller already holds, copied to its own pinned buffers and written with pwrite();
+// the header goes in last, with the size and mtime of the finished text file, and the file is renamed into place.
+struct SidecarWriter {
+    eagle_ctx* ctx = nullptr;
+    int fd = -1;
+    std::string final_path, tmp_path;
+    long rows = 0, cols = 0, row_bytes = 0, cap_rows = 0;
+    PinBuf pin[2];
+    DevBuf dev[2];
+    bool active() const { return fd >= 0; }
+    ~SidecarWriter() { abandon(); }
+    void abandon() {
+        if (fd >= 0) { close(fd); fd = -1; (void)unlink(tmp_path.c_str()); }
+    }
+    bool open_for(eagle_ctx* c, const char* text_path, long nrows, long ncols, long max_rows_per_call) {
+        if (!eagle_sidecar_enabled() || nrows <= 0 || ncols <= 0) return false;
+        ctx = c; rows = nrows; cols = ncols; cap_rows = std::max(1L, max_rows_per_call);
+        row_bytes = ((ncols + 3) / 4 + 15) / 16 * 16;
+        final_path = std::string(text_path) + ".e2b";
+        tmp_path = final_path + ".tmp";
+        (void)unlink(final_path.c_str());  // a sidecar of an older text file of that name must not survive a failed run
+        fd = open(tmp_path.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
+        if (fd < 0) return false;
+        for (int b = 0; b < 2; b++)
+            if (pin[b].alloc((size_t)cap_rows * row_bytes) != hipSuccess || dev[b].alloc((size_t)cap_rows * row_bytes) != hipSuccess) { abandon(); return false; }
+        return true;
+    }
+    // enqueue on the ctx stream: pack `nrows` rows of the int8 tile and copy them to pinned buffer b
+    int pack(int b, const int8_t* tile, long nrows, long ld) {
+        if (!active() || nrows <= 0) return EAGLE_OK;
+        if (nrows > cap_rows) return eagle_fail(ctx, EAGLE_ERR_ARG, "sidecar: chunk larger than announced");
+        int rc = eagle_dev_pack2b(ctx, tile, nrows, cols, ld, dev[b].as<uint8_t>(), row_bytes, ctx->stream);
+        if (rc) return rc;
+        hipError_t e = hipMemcpyAsync(pin[b].p, dev[b].p, (size_t)nrows * row_bytes, hipMemcpyDeviceToHost, ctx->stream);
+        return e == hipSuccess ? EAGLE_OK : eagle_fail_hip(ctx, e, "sidecar D2H");
+    }
+    // after the stream work of pack(b, ...) has completed
+    void write(int b, long row0, long nrows, int threads) {
+        if (!active() || nrows <= 0) return;
+        if (!pwrite_all(fd, (const char*)pin[b].p, (size_t)nrows * row_bytes, (off_t)sizeof(E2bHeader) + (off_t)row0 * row_bytes, threads)) abandon();
+    }
+    void finish(const char* text_path) {
+        if (!active()) return;
+        struct stat st;
+        if (stat(text_path, &st) != 0) { abandon(); return; }
+        E2bHeader h;
+        memset(&h, 0, sizeof h);
+        memcpy(h.magic, "EAGLE2B", 8);
+        h.version = 1;
+        h.rows = (uint64_t)rows; h.cols = (uint64_t)cols; h.row_bytes = (uint64_t)row_bytes;
+        h.src_size = (uint64_t)st.st_size;
+        h.src_mtime_ns = (int64_t)st.st_mtim.tv_sec * 1000000000L + st.st_mtim.tv_nsec;
+        const bool ok = pwrite(fd, &h, sizeof h, 0) == (ssize_t)sizeof h && ftruncate(fd, (off_t)sizeof h + (off_t)rows * row_bytes) == 0;
+        close(fd);
+        fd = -1;
+        if (!ok || rename(tmp_path.c_str(), final_path.c_str()) != 0) (void)unlink(tmp_path.c_str());
+    }
+};
+
 }  // namespace
 
 extern "C" int eagle_get_row_column(eagle_ctx* ctx, const char* fname, long dims_out[2]) {
@@ -185,7 +246,7 @@ static int create_M_text(eagle_ctx* ctx, const char* fname, const char* asciifna
     }
     const int fdout = open(asciifname, O_CREAT | O_TRUNC | O_WRONLY, 0644);
     if (fdout < 0) return failf(ctx, EAGLE_ERR_OPEN, "ERROR: Could not open  %s", asciifname);
-    struct Closer { int fd; ~Closer() { close(fd); } } closer{fdout};
+    struct Closer { int fd; ~Closer() { if (fd >= 0) close(fd); } } closer{fdout};
     if (!quiet) { say(ctx, ""); say(ctx, " Reading text File  "); say(ctx, ""); say(ctx, " Loading file "); }
     const int threads = host_threads();
     LineIndex ix;
@@ -280,6 +341,19 @@ static int create_M_text(eagle_ctx* ctx, const char* fname, const char* asciifna
     }
     say_head(ctx, m, ix, dims[0], dims[1], 12, "marker text  file");
     if (dev) {
+        close(closer.fd);
+        closer.fd = -1;  // the text file is final: its size and mtime key the sidecar and the cache entry
+        SidecarWriter sc;
+        if (sc.open_for(ctx, asciifname, nlines, L, chunk_rows)) {
+            for (long r0 = 0; r0 < nlines && sc.active(); r0 += chunk_rows) {
+                const long nr = std::min(chunk_rows, nlines - r0);
+                rc = sc.pack(0, dev + r0 * ld, nr, ld);
+                if (rc) return rc;
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                sc.write(0, r0, nr, threads);
+            }
+            sc.finish(asciifname);
+        }
         int8_t* give = dev;
         dev = nullptr;
         return eagle_cache_adopt(ctx, asciifname, nlines, L, n_pad, ld, give);
@@ -299,7 +373,7 @@ static int create_M_plink(eagle_ctx* ctx, const char* fname, const char* asciifn
     }
     const int fdout = open(asciifname, O_CREAT | O_TRUNC | O_WRONLY, 0644);
     if (fdout < 0) return failf(ctx, EAGLE_ERR_OPEN, "ERROR: Could not open  %s", asciifname);
-    struct Closer { int fd; ~Closer() { close(fd); } } closer{fdout};
+    struct Closer { int fd; ~Closer() { if (fd >= 0) close(fd); } } closer{fdout};
     const int threads = host_threads();
     LineIndex ix;
     index_lines(m, threads, ix);
@@ -322,6 +396,8 @@ static int create_M_plink(eagle_ctx* ctx, const char* fname, const char* asciifn
     unsigned long long* flags = (unsigned long long*)((char*)eagle_ctx_scratch(ctx) + 512);   // [0] first third-allele, [1] first missing
     HIPCHK(ctx, hipMemsetAsync(flags, 0xff, 2 * sizeof(unsigned long long), ctx->stream));
 
+    SidecarWriter sc;
+    (void)sc.open_for(ctx, asciifname, nlines, L, chunk_rows);
     RowError err;          // unequal number of columns (found on the host)
     unsigned long long h_flags[2] = {~0ull, ~0ull};
     long written = 0;
@@ -357,7 +433,10 @@ static int create_M_plink(eagle_ctx* ctx, const char* fname, const char* asciifn
             if (rc) return rc;
             HIPCHK(ctx, hipMemcpyAsync(ctx->stage_pin[1], ctx->stage_raw[1], (size_t)good * out_stride, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipMemcpyAsync(h_flags, flags, sizeof h_flags, hipMemcpyDeviceToHost, ctx->stream));
+            rc = sc.pack(0, img, good, ld);
+            if (rc) return rc;
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            sc.write(0, r0, good, threads);
             long ok_rows = good;
             if (h_flags[0] != ~0ull) ok_rows = (long)(h_flags[0] / (unsigned long long)L) - r0;  // the reference stops inside that row
             if (ok_rows > 0 && !pwrite_all(fdout, (const char*)ctx->stage_pin[1], (size_t)ok_rows * out_stride, (off_t)r0 * out_stride, threads))
@@ -399,6 +478,9 @@ static int create_M_plink(eagle_ctx* ctx, const char* fname, const char* asciifn
         return EAGLE_SOFT_SENTINEL;
     }
     say_head(ctx, m, ix, dims[0], dims[1], dims[1] < 25 ? (int)dims[1] : 24, "PLINK ped file");  // :205-214
+    close(closer.fd);
+    closer.fd = -1;
+    sc.finish(asciifname);
     if (keep && nlines == dims[0]) {
         int8_t* give = image.as<int8_t>();
         image.p = nullptr;
@@ -432,7 +514,7 @@ extern "C" int eagle_create_Mt_ascii(eagle_ctx* ctx, const char* f_name, const c
     const int threads = host_threads();
     const int fdout = open(f_name_ascii, O_CREAT | O_TRUNC | O_WRONLY, 0644);
     if (fdout < 0) return failf(ctx, EAGLE_ERR_OPEN, "ERROR: Could not open  %s", f_name_ascii);
-    struct Closer { int fd; ~Closer() { close(fd); } } closer{fdout};
+    struct Closer { int fd; ~Closer() { if (fd >= 0) close(fd); } } closer{fdout};
     const long out_stride = n + 1;
     if (ftruncate(fdout, (off_t)L * out_stride) != 0) return failf(ctx, EAGLE_ERR_OPEN, "ERROR: could not size %s", f_name_ascii);
 
@@ -463,6 +545,8 @@ extern "C" int eagle_create_Mt_ascii(eagle_ctx* ctx, const char* f_name, const c
     for (int b = 0; b < 2; b++) HIPCHK(ctx, hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
     struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int b = 0; b < 2; b++) if (e[b]) (void)hipEventDestroy(e[b]); } } evg{done};
 
+    SidecarWriter sc;
+    (void)sc.open_for(ctx, f_name_ascii, L, n, w);
     // Window k: transpose + encode on the stream, D2H into pinned buffer k&1; the pwrite of window k-1 overlaps it.
     long pend_c0 = -1, pend_rows = 0;
     int pend_b = 0;
@@ -472,6 +556,7 @@ extern "C" int eagle_create_Mt_ascii(eagle_ctx* ctx, const char* f_name, const c
         if (e != hipSuccess) return eagle_fail_hip(ctx, e, "hipEventSynchronize");
         if (!pwrite_all(fdout, (const char*)ctx->stage_pin[pend_b], (size_t)pend_rows * out_stride, (off_t)pend_c0 * out_stride, threads))
             return failf(ctx, EAGLE_ERR_OPEN, "ERROR: could not write %s", f_name_ascii);
+        sc.write(pend_b, pend_c0, pend_rows, threads);
         pend_c0 = -1;
         return EAGLE_OK;
     };
@@ -498,6 +583,8 @@ extern "C" int eagle_create_Mt_ascii(eagle_ctx* ctx, const char* f_name, const c
         if (rc) return rc;
         if (pend_c0 >= 0 && pend_b == b) { rc = flush(); if (rc) return rc; }
         HIPCHK(ctx, hipMemcpyAsync(ctx->stage_pin[b], ctx->stage_raw[b], (size_t)real * out_stride, hipMemcpyDeviceToHost, ctx->stream));
+        rc = sc.pack(b, dst, real, ldn);
+        if (rc) return rc;
         HIPCHK(ctx, hipEventRecord(done[b], ctx->stream));
         const long this_c0 = c0, this_rows = real;
         rc = flush();  // window k-1 goes to disk while window k is on the device
@@ -518,11 +605,12 @@ extern "C" int eagle_create_Mt_ascii(eagle_ctx* ctx, const char* f_name, const c
     say(ctx, " Available memory (gigabytes): %g", max_memory_in_Gbytes);
     say(ctx, "\n\n");
     say(ctx, " The marker file has been Uploaded");
+    close(closer.fd);
+    closer.fd = -1;  // the text file is final: its size and mtime key the sidecar and the cache entry
+    sc.finish(f_name_ascii);
     if (keep) {
         int8_t* give = mt.as<int8_t>();
         mt.p = nullptr;
-        close(closer.fd);
-        closer.fd = -1;  // mtime is final once the descriptor is closed
         return eagle_cache_adopt(ctx, f_name_ascii, L, n, L_pad, ldn, give);
     }
     return EAGLE_OK;

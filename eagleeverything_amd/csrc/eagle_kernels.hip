@@ -896,3 +896,69 @@ extern "C" int eagle_dev_plink_code(eagle_ctx* ctx, const uint8_t* chars, long r
     LAUNCH_CHECK(ctx);
     return EAGLE_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// 2-bit sidecar of a genotype text file (the reference itself once bit-packed its genotypes,
+// MP/RcppFunctions.cpp.gpu:224-358): genotype code g = m + 1 in {0,1,2}, code of column c in bits 2(c%4) of byte c/4.
+//   k_pack2b   : int8 {-1,0,1} rows -> packed rows
+//   k_unpack2b : packed row window -> int8 rows (first code at 2-bit index `shift` of the first byte); code 3 is invalid
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack2b(const int8_t* __restrict__ in, long rows, long cols, long ld_in, uint8_t* __restrict__ out,
+                                                long row_bytes) {
+    const long row = blockIdx.y;
+    const long b = (long)blockIdx.x * 256 + threadIdx.x;
+    if (b >= row_bytes) return;
+    unsigned v = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const long c = 4 * b + q;
+        if (c < cols) v |= ((unsigned)(in[row * ld_in + c] + 1) & 3u) << (2 * q);
+    }
+    out[row * row_bytes + b] = (uint8_t)v;
+}
+__global__ __launch_bounds__(256) void k_unpack2b(const uint8_t* __restrict__ raw, long rows, long cols, long stride, int shift,
+                                                  int8_t* __restrict__ out, long ld_out, int* __restrict__ bad) {
+    const long row = blockIdx.y;
+    const long c4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c4 >= ld_out) return;
+    const uint8_t* src = raw + row * stride;
+    uint32_t packed = 0;
+    int nbad = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const long c = c4 + q;
+        int v = 0;
+        if (c < cols) {
+            const long idx = c + shift;
+            const int g = (src[idx >> 2] >> (2 * (idx & 3))) & 3;
+            if (g == 3) nbad++;
+            v = g - 1;
+        }
+        packed |= ((uint32_t)(uint8_t)(int8_t)v) << (8 * q);
+    }
+    *(uint32_t*)(out + row * ld_out + c4) = packed;
+    if (nbad) atomicAdd(bad, nbad);
+}
+extern "C" int eagle_dev_pack2b(eagle_ctx* ctx, const int8_t* in, long rows, long cols, long ld_in, uint8_t* out, long row_bytes, void* stream) {
+    if (rows <= 0 || row_bytes <= 0) return EAGLE_OK;
+    for (long r0 = 0; r0 < rows; r0 += 65535) {
+        long nr = rows - r0 < 65535 ? rows - r0 : 65535;
+        dim3 grid((unsigned)((row_bytes + 255) / 256), (unsigned)nr);
+        hipLaunchKernelGGL(k_pack2b, grid, dim3(256), 0, (hipStream_t)stream, in + r0 * ld_in, nr, cols, ld_in, out + r0 * row_bytes, row_bytes);
+    }
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+extern "C" int eagle_dev_unpack2b(eagle_ctx* ctx, const uint8_t* raw, long rows, long cols, long stride, int shift, int8_t* out,
+                                  long ld_out, int* bad_dev, void* stream) {
+    if (rows <= 0) return EAGLE_OK;
+    if (ld_out % 4) return eagle_fail(ctx, EAGLE_ERR_ARG, "unpack2b: ld_out must be a multiple of 4");
+    for (long r0 = 0; r0 < rows; r0 += 65535) {
+        long nr = rows - r0 < 65535 ? rows - r0 : 65535;
+        dim3 grid((unsigned)((ld_out / 4 + 255) / 256), (unsigned)nr);
+        hipLaunchKernelGGL(k_unpack2b, grid, dim3(256), 0, (hipStream_t)stream, raw + r0 * stride, nr, cols, stride, shift, out + r0 * ld_out,
+                           ld_out, bad_dev);
+    }
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}

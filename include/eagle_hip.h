@@ -122,7 +122,10 @@ int eagle_extract_geno(eagle_ctx* ctx, const char* f_name_ascii, double max_memo
 /* ---------------------------------------------------------------------------------------------
  * 1b. Marker-file ingestion (the producers of M.ascii / Mt.ascii that ReadMarker() calls, E/R/create_ascii.R:27-58).
  *     Same results byte for byte; additionally the int8 images of both files stay resident in HBM under the OUTPUT
- *     paths, so the eagle_calculateMMt / eagle_calculate_a_and_vara calls that follow never parse text.
+ *     paths, so the eagle_calculateMMt / eagle_calculate_a_and_vara calls that follow never parse text, and a 2-bit
+ *     sidecar "<output>.e2b" (64-byte header + packed rows, a quarter of the text bytes) is left beside each text file:
+ *     every loader of this library reads it instead of the text while the text file keeps the size and mtime recorded in
+ *     it (EAGLE_HIP_SIDECAR=0 disables writing and reading).
  * ------------------------------------------------------------------------------------------- */
 
 /* Replaces  std::vector<long> getRowColumn(std::string fname)      E/src/getRowColumn.cpp:20-72, RcppExports.cpp:143-151

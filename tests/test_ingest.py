@@ -264,3 +264,48 @@ def test_gpu_createMt_streamed_windows(oracle, tmp_path, monkeypatch):
     assert any("block transpose" in s for s in msgs)
     assert _lines(tmp_path / "Mt.ascii") == ["".join(map(str, c)) for c in g.T]
     rcpp_api.drop_cache()
+
+
+@pytest.mark.gpu
+def test_gpu_sidecar_2bit(oracle, golden, tmp_path, monkeypatch):
+    """ReadMarker leaves <file>.e2b (2-bit codes) beside both text files; a later process (dropped cache) loads genotypes
+    from it instead of parsing text.  A sidecar is trusted only while the text file has the recorded size and mtime."""
+    import ctypes as C
+    import torch
+    from eagleeverything_amd import _lib, r_api, rcpp_api
+    g = golden("geno_150x100")
+    geno = r_api.ReadMarker(TXT, type="text", AA=0, AB=1, BB=2, outdir=str(tmp_path))
+    fM, fMt = geno["asciifileM"], geno["asciifileMt"]
+    assert os.path.getsize(fM + ".e2b") == 64 + 150 * 32 and os.path.getsize(fMt + ".e2b") == 64 + 100 * 48
+    exp = g["MMt"].astype(np.float64)
+    for env in ("1", "0"):  # from the sidecar, then from the text
+        monkeypatch.setenv("EAGLE_HIP_SIDECAR", env)
+        rcpp_api.drop_cache()
+        assert np.array_equal(rcpp_api.calculateMMt_rcpp(fM, 8.0, 4, np.nan, (150, 100)), exp)
+        blk = rcpp_api.ReadBlock(fMt, 7, 150, 40)
+        assert np.array_equal(blk, g["M8"].T[7:47].astype(np.float64))
+    monkeypatch.setenv("EAGLE_HIP_SIDECAR", "1")
+    # a column window that does not start on a byte boundary of the packed rows
+    L = _lib.load()
+    ctx = rcpp_api.context()
+    buf = torch.zeros((64, 256), dtype=torch.int8, device="cuda")
+    assert L.eagle_dev_load_ascii(ctx, os.fsencode(fM), 10, 50, 5, 77, buf.data_ptr(), 256, 8.0, 4) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(buf[:50, :77].cpu().numpy(), g["M8"][10:60, 5:82]) and not buf[50:].any() and not buf[:, 77:].any()
+    # proof that the sidecar is what gets read: an invalid code in its payload is reported
+    with open(fM + ".e2b", "r+b") as f:
+        f.seek(64 + 3)
+        f.write(b"\xff")
+    rcpp_api.drop_cache()
+    with pytest.raises(rcpp_api.EagleError, match="invalid genotype codes"):
+        rcpp_api.calculateMMt_rcpp(fM, 8.0, 4, np.nan, (150, 100))
+    # a rewritten text file (new mtime) makes the sidecar stale: the text is parsed again
+    lines = _lines(fM)
+    lines[0] = "2" * 100
+    os.utime(fM + ".e2b")
+    _write(fM, lines)
+    os.utime(fM, ns=(os.stat(fM).st_atime_ns, os.stat(fM).st_mtime_ns + 5_000_000))
+    M2 = g["M8"].astype(np.int64).copy()
+    M2[0, :] = 1
+    assert np.array_equal(rcpp_api.calculateMMt_rcpp(fM, 8.0, 4, np.nan, (150, 100)), (M2 @ M2.T).astype(np.float64))
+    rcpp_api.drop_cache()

@@ -43,6 +43,20 @@ def main():
             out[name + "_warm_s"] = warm   # genotypes already resident in HBM; operands H2D, results D2H
             rcpp_api.drop_cache()
             t = time.perf_counter(); fn(); out[name + "_reload_s"] = time.perf_counter() - t  # cold again, staging buffers already pinned
+        # ingestion: Mt.ascii (+ its 2-bit sidecar) rebuilt from M.ascii on the device, then reloads with / without the sidecar
+        rcpp_api.drop_cache()
+        mt2 = os.path.join(d, "Mt2.ascii")
+        t = time.perf_counter(); rcpp_api.createMt_ASCII_rcpp(geno["asciifileM"], mt2, "text", 8.0, (n, L)); out["createMt_s"] = time.perf_counter() - t
+        with open(mt2, "rb") as fa, open(geno["asciifileMt"], "rb") as fb:
+            out["createMt_identical"] = fa.read() == fb.read()
+        scan2 = lambda: rcpp_api.calculate_a_and_vara_rcpp(mt2, np.nan, S, V, 8.0, (L, n), ahat)
+        t = time.perf_counter(); scan2(); out["scan_after_createMt_s"] = time.perf_counter() - t  # image already resident
+        for env in ("1", "0"):
+            os.environ["EAGLE_HIP_SIDECAR"] = env
+            rcpp_api.drop_cache()
+            t = time.perf_counter(); scan2(); out["scan_reload_sidecar%s_s" % env] = time.perf_counter() - t
+        os.environ.pop("EAGLE_HIP_SIDECAR")
+        out["sidecar_bytes"] = os.path.getsize(mt2 + ".e2b")
         out["scan_cold_markers_per_s"] = L / out["scan_cold_s"]
         out["scan_warm_markers_per_s"] = L / out["scan_warm_s"]
         out["file_bytes_each"] = os.path.getsize(geno["asciifileM"])
