@@ -196,6 +196,12 @@ class DeviceShard:
             self.Wu = torch.zeros((np_, np_), dtype=torch.float64, device=self.dev)
             self.tmp = torch.zeros((np_, np_), dtype=torch.float64, device=self.dev)
 
+    def release_operands(self):
+        """Drop the n x n operand images and the vara workspace (a and vara of the last scan stay)."""
+        self.Sa = self.Va = self.ahat = self.v = self.Wu = self.tmp = None
+        self.ws = None
+        self.torch.cuda.empty_cache()
+
     def scan_operands(self):
         self._check(self.L.eagle_dev_scan_operands(self.ctx, self.Sa.data_ptr(), self.Va.data_ptr(), self.ahat.data_ptr(),
                                                    self.n, self.np_, self.v.data_ptr(), self.Wu.data_ptr(),

@@ -318,8 +318,9 @@ def test_streamed_paths_match_resident(big, api, oracle, monkeypatch):
 
 
 def test_large_n_device_path(api, oracle):
-    """n = 12000 (47 column tiles: odd count, vectors too large for the LDS-resident genotype pass), device-resident
-    entry points only, checked against the oracle on a marker sample and through exact properties of MM^T."""
+    """n = 12000 (47 column tiles: odd count; more individuals than one LDS image of the genotype pass holds, so it sweeps
+    two column chunks), device-resident entry points only, checked against the oracle on a marker sample and through
+    exact properties of MM^T."""
     import torch
     from eagleeverything_amd.sharded import DeviceShard
     n, L = 12000, 4096
@@ -350,6 +351,54 @@ def test_large_n_device_path(api, oracle):
     cols = torch.tensor([0, 1, 255, 256, 6000, n - 1], device=sh.dev)
     ref_cols = Mt.double().T @ Mt[:, cols].double()
     assert torch.equal(MMt[:, cols], ref_cols)
+    assert float(mx) == float(MMt.max())
+
+
+def test_config_C3_shape_single_gpu(api, oracle):
+    """BASELINE.json configs[2] at its full shape on ONE card (10,000 individuals x 1,000,000 markers, resident): the scan
+    against the oracle on a marker sample, MM^T through exact size-independent properties (diagonal = sums of squares,
+    symmetry, selected columns against an int-exact torch product), arg-max against the full tsq vector."""
+    import torch
+    from eagleeverything_amd.sharded import DeviceShard
+    n, L = 10000, 1000000
+    sh = DeviceShard(n, L)
+    sh.fill_synthetic(seed=20240601)
+    gen = torch.Generator(device=sh.dev)
+    gen.manual_seed(11)
+    A = torch.randn((n, 48), generator=gen, device=sh.dev, dtype=torch.float64) / 40.0
+    S = 0.5 * torch.eye(n, dtype=torch.float64, device=sh.dev) + A @ A.T
+    V = 0.6 * torch.eye(n, dtype=torch.float64, device=sh.dev) - 0.03 * (A[:, :6] @ A[:, :6].T)
+    ahat = torch.randn(n, generator=gen, device=sh.dev, dtype=torch.float64)
+    sh.set_operands(S, V, ahat)
+    del A
+    sh.mode = 1
+    sh.scan()
+    torch.cuda.synchronize()
+    rows = torch.cat([torch.arange(0, 96), torch.arange(499968, 500064), torch.arange(L - 96, L)]).to(sh.dev)
+    Mt_s = sh.Mt8[rows][:, :n].cpu().numpy()
+    a_ref, v_ref = oracle.scan_from_i8(Mt_s, S.cpu().numpy(), V.cpu().numpy(), ahat.cpu().numpy())
+    np.testing.assert_allclose(sh.a[rows].cpu().numpy(), a_ref, rtol=1e-9, atol=1e-12 * np.abs(a_ref).max())
+    np.testing.assert_allclose(sh.vara[rows].cpu().numpy(), v_ref, rtol=1e-9)
+    tsq = sh.a[:L] ** 2 / sh.vara[:L]
+    tsqmax, gidx, near = sh.best()
+    assert gidx == int(torch.argmax(tsq)) and tsqmax == float(tsq.max())
+    del S, V, tsq
+    sh.release_operands()
+    # MM^T at 2 x 10^14 multiply-adds: exact integer properties
+    sh.individual_major()
+    c32 = sh.mmt_partial()
+    MMt, mx = sh.mmt_finish(c32)
+    del c32
+    cols = torch.tensor([0, 1, 255, 256, 4999, 5120, n - 1], device=sh.dev)
+    diag_ref = torch.zeros(n, dtype=torch.float64, device=sh.dev)
+    cols_ref = torch.zeros((n, cols.numel()), dtype=torch.float64, device=sh.dev)
+    for r0 in range(0, L, 65536):
+        blk = sh.Mt8[r0:min(L, r0 + 65536), :n]
+        diag_ref += (blk.to(torch.int16) ** 2).sum(dim=0, dtype=torch.int64).double()
+        cols_ref += blk.double().T @ blk[:, cols].double()
+    assert torch.equal(torch.diagonal(MMt), diag_ref)
+    assert torch.equal(MMt, MMt.T)
+    assert torch.equal(MMt[:, cols], cols_ref)
     assert float(mx) == float(MMt.max())
 
 
