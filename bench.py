@@ -27,6 +27,7 @@ if ROOT not in sys.path:
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix, AMD datasheet (the microarch guide lists no fp64 row)
 I8_MFMA_PEAK_TOPS = 5000.0     # dense int8 = 2x the 2.5 PF bf16 dense peak (MI355X_MICROARCH.md, Matrix cores)
+FP4_MFMA_PEAK_TOPS = 10000.0   # dense fp4 / fp6 on the block-scaled path = 4x bf16 (same guide)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -120,6 +121,7 @@ def main():
     sh.nslices = args.slices
     sh.fill_synthetic()
     sh.individual_major()
+    sh.individual_major_fp4()  # operand image of the MM^T kernel (made once per shard, like the int8 images)
     torch.cuda.synchronize(dev)
     t_gen = time.time() - t0
 
@@ -256,8 +258,9 @@ def main():
                           "achieved": Lp * np_ / gpass_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": Lp * np_ / gpass_s / 1e9 / HBM_PEAK_GBS, "kernel_ms": gpass_s * 1e3},
         "scan_prepare_ms": gemv_s * 1e3,  # inside a step: the same pass fused with the diagonal term of vara, + slicing of W (i8 mode)
-        "syrk_i8": {"bound": "mfma", "achieved": (np_ * (np_ + 128.0)) * Lp / syrk_s / 1e12, "peak": I8_MFMA_PEAK_TOPS,
-                    "unit": "TFLOP/s", "frac": (np_ * (np_ + 128.0)) * Lp / syrk_s / 1e12 / I8_MFMA_PEAK_TOPS,
+        "syrk_f4": {"bound": "mfma", "kernel": "k_syrk_f4 (v_mfma_scale_f32_32x32x64_f8f6f4, fp4 x fp4, exact)", "dtype": "fp4",
+                    "achieved": (np_ * (np_ + 256.0)) * Lp / syrk_s / 1e12, "peak": FP4_MFMA_PEAK_TOPS,
+                    "unit": "TFLOP/s", "frac": (np_ * (np_ + 256.0)) * Lp / syrk_s / 1e12 / FP4_MFMA_PEAK_TOPS,
                     "kernel_ms": syrk_s * 1e3},
     }
 

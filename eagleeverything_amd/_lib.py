@@ -52,6 +52,7 @@ SIGNATURES = {
     "eagle_dev_i8_to_f64_colmajor": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_void_p,
                                                C.c_void_p]),
     "eagle_dev_mmt_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p]),
+    "eagle_dev_mmt_accumulate_f4": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p]),
     "eagle_dev_mmt_downdate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_void_p,
                                          C.c_void_p]),
     "eagle_dev_mmt_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_void_p,
@@ -64,6 +65,12 @@ SIGNATURES = {
     "eagle_dev_vara_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
     "eagle_vara_i8_workspace_bytes": (C.c_int64, [C.c_long, C.c_long, C.c_int]),
+    "eagle_vara_f6_workspace_bytes": (C.c_int64, [C.c_long, C.c_long, C.c_int]),
+    "eagle_dev_pack_fp4": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p]),
+    "eagle_dev_vara_f6_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_int,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eagle_dev_vara_f6_mfma": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]),
     "eagle_dev_vara_i8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_int,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "eagle_dev_vara_i8_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_int,

@@ -118,6 +118,7 @@ extern "C" void eagle_drop_cache(eagle_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     for (auto& g : ctx->cache) if (g.dev) (void)hipFree(g.dev);
     ctx->cache.clear();
+    if (ctx->f4_buf) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->f4_buf); ctx->f4_buf = nullptr; ctx->f4_cap = 0; }
 }
 
 extern "C" void eagle_close(eagle_ctx* ctx) {
@@ -132,12 +133,21 @@ extern "C" void eagle_close(eagle_ctx* ctx) {
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->gemv_ws) (void)hipFree(ctx->gemv_ws);
+    if (ctx->f4_buf) (void)hipFree(ctx->f4_buf);
     for (int b = 0; b < 2; b++) { if (ctx->stage_pin[b]) (void)hipHostFree(ctx->stage_pin[b]); if (ctx->stage_raw[b]) (void)hipFree(ctx->stage_raw[b]); }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
 extern "C" void* eagle_ctx_scratch(eagle_ctx* ctx) { return ctx->d_scratch; }
+extern "C" void* eagle_ctx_f4_buffer(eagle_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->f4_cap) return ctx->f4_buf;
+    if (ctx->f4_buf) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->f4_buf); ctx->f4_buf = nullptr; ctx->f4_cap = 0; }
+    hipError_t e = hipMalloc(&ctx->f4_buf, bytes);
+    if (e != hipSuccess) { (void)eagle_fail_hip(ctx, e, "fp4 image hipMalloc"); ctx->f4_buf = nullptr; return nullptr; }
+    ctx->f4_cap = bytes;
+    return ctx->f4_buf;
+}
 extern "C" const char* eagle_last_error(eagle_ctx* ctx) { return ctx ? ctx->err : g_open_err; }
 extern "C" void eagle_set_message_callback(eagle_ctx* ctx, eagle_message_fn fn, void* user) {
     if (ctx) { ctx->msg_fn = fn; ctx->msg_user = user; }

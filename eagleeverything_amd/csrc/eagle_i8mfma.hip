@@ -214,8 +214,10 @@ static int syrk_pair_table(eagle_ctx* ctx, int nt, const int** out, hipStream_t 
 static int g_tune = 0;
 extern "C" void eagle_dev_set_tune(int v) { g_tune = v; }
 
-extern "C" int eagle_dev_mmt_accumulate(eagle_ctx* ctx, const int8_t* M8, long n_pad, long L_pad, long ld, int32_t* C32,
-                                        void* stream) {
+// The int8 form of the MM^T kernel (the shipped one is k_syrk_f4 below: same engine, fp4 operands, twice the markers per
+// stage).  Kept for the schedule ablations of tools/bench_i8_engine.py; not part of the public ABI.
+extern "C" int eagle_dev_mmt_accumulate_i8(eagle_ctx* ctx, const int8_t* M8, long n_pad, long L_pad, long ld, int32_t* C32,
+                                           void* stream) {
     if (n_pad % T8 || L_pad % BK8 || ld % 128 || L_pad > ld || n_pad <= 0 || (double)ld * T8 >= 2147483648.0)
         return eagle_fail(ctx, EAGLE_ERR_ARG, "mmt_accumulate: layout contract violated (n_pad % 256, L_pad % 128, ld % 128, ld < 2^23)");
     if (L_pad == 0) return EAGLE_OK;
@@ -561,4 +563,474 @@ extern "C" int eagle_dev_vara_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, 
     int rc = eagle_dev_vara_i8_prepare(ctx, Mt8, L_pad, n_pad, ld, Wu, nslices, ws, nullptr, nullptr, stream);
     if (rc) return rc;
     return eagle_dev_vara_i8_mfma(ctx, Mt8, L_pad, n_pad, ld, nslices, ws, vara_out, err_bound_dev, stream);
+}
+
+// ================================================================================================
+// vara on the block-scaled matrix path: genotypes as fp4 (e2m1: -1, 0, +1 are exact), digits of Wu as fp6 (e2m3).
+//
+// v_mfma_scale_f32_32x32x64_f8f6f4 multiplies K = 64 per instruction in the cycles the int8 form needs for K = 32, and an
+// e2m3 number holds every integer d in [-16, 16] as d/8.  So Wu is cut into balanced base-33 digits instead of base-256
+// ones (5.04 bits per digit at twice the MAC rate = 10.1 bits per matrix cycle against 8), the products m * d/8 and their
+// fp32 sums are exact (multiples of 1/8 below 2^24), and everything downstream of the accumulators is the integer
+// arithmetic of the int8 path.  tools/ubench/fp6_probe.hip: bit-exact against the integer product, 6.0 POP/s against
+// 3.04 POP/s for the int8 instruction in the same register-resident loop on random operands.
+//
+//   Wu = 2^-f * sum_{s<S} D_s 33^s + R,  |R_jk| <= 2^(-f-1),  f = 5S - 1 - e,  max|Wu| < 2^e,  D_s in [-16,16]
+//   (Q = rint(Wu 2^f) is below 2^(5S-1) <= (33^S - 1)/2, the largest balanced S-digit number, for S <= 12.)
+//
+// Operand images.  A: Mt4[L_pad][n_pad/2], two genotypes per byte (low nibble first) -- a 256-marker x 256-individual
+// stage is 256 rows x 128 bytes, the same LDS image, DMA and fragment addressing as the int8 engine's 128-individual
+// stage.  B: per (slice, column tile ct, stage kt <= ct) one 48 KiB blob already in LDS order: a lane's fragment of 32
+// digits is a 24-byte little-endian 6-bit stream, stored as its first 16 bytes in a 256 x 128-byte plane (chunk index
+// XOR (row>>1)&7, read with ds_read_b128 like the A image) and its last 8 bytes in a 256 x 64-byte plane (8-byte slot
+// XOR (row>>2)&7, ds_read_b64, conflict-free); the blob is copied global -> LDS by 48 linear 1 KiB LDS-DMA pieces.
+// A stage is 80 KiB, double buffered = the whole 160 KiB of LDS.
+// ================================================================================================
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+#define F6_A_BYTES 32768
+#define F6_B16_BYTES 32768
+#define F6_B8_BYTES 16384
+#define F6_BLOB (F6_B16_BYTES + F6_B8_BYTES)
+#define F6_STAGE (F6_A_BYTES + F6_BLOB)
+#define VARA6_SMAX_AUTO 11
+
+__global__ __launch_bounds__(256) void k_pack_fp4(const int8_t* __restrict__ in, long rows, long ld_in, uint8_t* __restrict__ out, long ld4) {
+    const long row = blockIdx.y;
+    const long b = (long)blockIdx.x * 256 + threadIdx.x;
+    if (b >= ld4) return;
+    const int m0 = in[row * ld_in + 2 * b], m1 = in[row * ld_in + 2 * b + 1];
+    const unsigned c0 = m0 == 0 ? 0u : (m0 > 0 ? 0x2u : 0xAu), c1 = m1 == 0 ? 0u : (m1 > 0 ? 0x2u : 0xAu);
+    out[row * ld4 + b] = (uint8_t)(c0 | (c1 << 4));
+}
+extern "C" int eagle_dev_pack_fp4(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, void* Mt4, void* stream) {
+    if (n_pad % T8 || ld % 16 || n_pad > ld) return eagle_fail(ctx, EAGLE_ERR_ARG, "pack_fp4: layout contract violated");
+    if (L_pad <= 0) return EAGLE_OK;
+    for (long r0 = 0; r0 < L_pad; r0 += 65535) {
+        const long nr = L_pad - r0 < 65535 ? L_pad - r0 : 65535;
+        dim3 grid((unsigned)((n_pad / 2 + 255) / 256), (unsigned)nr);
+        hipLaunchKernelGGL(k_pack_fp4, grid, dim3(256), 0, (hipStream_t)stream, Mt8 + r0 * ld, nr, ld, (uint8_t*)Mt4 + r0 * (n_pad / 2), n_pad / 2);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "k_pack_fp4");
+    return EAGLE_OK;
+}
+
+// One block: dW, sumdiag, digit count (hdr->S), scale exponent f (hdr->pad) and the error bound n_pad^2 2^(-f-1).
+__global__ __launch_bounds__(256) void k_vara_prep6(const double* __restrict__ Wu, long n_pad, int forced, VaraHdr* __restrict__ hdr,
+                                                    double* __restrict__ dW) {
+    double s = 0.0;
+    for (long k = threadIdx.x; k < n_pad; k += 256) {
+        double d = Wu[k * n_pad + k];
+        dW[k] = d;
+        s += fabs(d);
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int e = 0;
+        const double mx = hdr->maxabs_off;
+        if (mx > 0.0) (void)frexp(mx, &e);
+        const double nn = (double)n_pad * (double)n_pad;
+        int S = forced;
+        if (S <= 0) {
+            const double target = 1e-9 * 0.5 * red[0];
+            S = VARA6_SMAX_AUTO;
+            for (int c = 4; c <= VARA6_SMAX_AUTO; c++)
+                if (ldexp(nn, e - 5 * c) <= target) { S = c; break; }
+        }
+        if (mx == 0.0) S = 1;
+        hdr->S = S;
+        hdr->pad = 5 * S - 1 - e;  // f
+        hdr->sumdiag = red[0];
+        hdr->bound = mx > 0.0 ? ldexp(nn, e - 5 * S) : 0.0;
+    }
+}
+
+__device__ __forceinline__ long f6_blob_index(int ct, int kt) { return (long)ct * (ct + 1) / 2 + kt; }
+
+// Digits of the 32 x 32 tile Wu[j0.., k0..] -> its fragment (rows k0%256.., fragment (j0%256)/32) of blob (ct, kt), all slices.
+__global__ __launch_bounds__(256) void k_slice_w6(const double* __restrict__ Wu, long np, const VaraHdr* __restrict__ hdr,
+                                                  uint8_t* __restrict__ Bs6, long nblobs) {
+    const long j0 = (long)blockIdx.y * 32, k0 = (long)blockIdx.x * 32;
+    const int ct = (int)(k0 >> 8), kt = (int)(j0 >> 8);
+    if (kt > ct) return;
+    __shared__ double tile[32][33];
+    __shared__ uint8_t codes[12][32][32];  // [slice][kk][jj]
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = Wu[(j0 + r) * np + k0 + tx];  // tile[jj][kk]
+    __syncthreads();
+    const int S = hdr->S, f = hdr->pad;
+    for (int jj = ty * 4; jj < ty * 4 + 4; jj++) {
+        long long Q = (j0 + jj == k0 + tx) ? 0 : llrint(ldexp(tile[jj][tx], f));
+        for (int s = 0; s < S; s++) {
+            long long d = Q % 33;           // (-33, 33)
+            if (d > 16) d -= 33;
+            if (d < -16) d += 33;
+            Q = (Q - d) / 33;               // exact
+            codes[s][tx][jj] = (uint8_t)((d < 0 ? 0x20 : 0) | (int)(d < 0 ? -d : d));  // e2m3 of d/8: magnitude code = |d|
+        }
+    }
+    __syncthreads();
+    const int frag = (int)((j0 & 255) >> 5);
+    for (int item = threadIdx.x; item < S * 32 * 8; item += 256) {
+        const int g = item & 7, kk = (item >> 3) & 31, s = item >> 8;
+        const unsigned c0 = codes[s][kk][4 * g], c1 = codes[s][kk][4 * g + 1], c2 = codes[s][kk][4 * g + 2], c3 = codes[s][kk][4 * g + 3];
+        const unsigned w24 = c0 | (c1 << 6) | (c2 << 12) | (c3 << 18);
+        const int c = (int)(k0 & 255) + kk;  // row of the blob
+        uint8_t* blob = Bs6 + ((size_t)s * nblobs + f6_blob_index(ct, kt)) * F6_BLOB;
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            const int p = 3 * g + b;
+            uint8_t* dst = p < 16 ? blob + c * 128 + ((frag ^ ((c >> 1) & 7)) << 4) + p
+                                  : blob + F6_B16_BYTES + c * 64 + ((frag ^ ((c >> 2) & 7)) << 3) + (p - 16);
+            *dst = (uint8_t)(w24 >> (8 * b));
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void k_vara_f6(const int8_t* __restrict__ Mt8, long ld, const uint8_t* __restrict__ Mt4, long ld4, int ntm,
+                                                    const uint8_t* __restrict__ Bs6, long nblobs, long np, const VaraHdr* __restrict__ hdr,
+                                                    long long* __restrict__ q, long Lp) {
+    extern __shared__ __attribute__((aligned(1024))) int8_t lds6[];  // 2 x (A 32 KiB | B16 32 KiB | B8 16 KiB)
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int nslices = hdr->S;
+    const int mt = (slot / nslices) * 8 + xcd, sl = slot % nslices;
+    if (mt >= ntm) return;
+    const int nct = (int)(np / T8), npair = (nct + 1) / 2;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = w >> 2, wc = w & 3;
+    const int ldi = (int)ld, ld4i = (int)ld4;
+    const T8Lane lnA = t8_lane(lane, ld4i);
+    const __amdgpu_buffer_rsrc_t rsA4 = t8_rsrc((const int8_t*)Mt4 + (long)mt * T8 * ld4, ld4i);
+    const __amdgpu_buffer_rsrc_t rsA8 = t8_rsrc(Mt8 + (long)mt * T8 * ld, ldi);  // epilogue: genotype bytes
+    const __amdgpu_buffer_rsrc_t rsB =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(Bs6 + (size_t)sl * nblobs * F6_BLOB), 0, (int)(nblobs * F6_BLOB), 0x00020000);
+    const int lane16 = lane << 4;
+
+    VaraIt cur, nxt;  // nk counts 256-individual stages here
+    auto set_tile = [&](VaraIt& it) {
+        while (it.p < npair) {
+            int ct = it.half == 0 ? it.p : nct - 1 - it.p;
+            if (it.half == 1 && ct == it.p) { it.p++; it.half = 0; continue; }
+            it.ct = ct; it.kt = 0; it.nk = ct + 1; it.valid = true;
+            return;
+        }
+        it.valid = false;
+    };
+    auto advance = [&](VaraIt& it) {
+        if (++it.kt < it.nk) return;
+        if (it.half == 0) it.half = 1; else { it.half = 0; it.p++; }
+        set_tile(it);
+    };
+    auto stage = [&](const VaraIt& it, int8_t* dst) {
+        t8_stage(rsA4, lnA, ld4i, it.kt * 128, dst, w);  // 256 individuals = 128 bytes of every marker row
+        const int blob = (int)f6_blob_index(it.ct, it.kt) * F6_BLOB;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const int piece = w * 6 + i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(dst + F6_A_BYTES + piece * 1024), 16, lane16,
+                                                     blob + piece * 1024, 0, 0);
+        }
+    };
+    cur.p = 0; cur.half = 0; set_tile(cur);
+    if (!cur.valid) return;
+    nxt = cur;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int x = 0; x < 16; x++) acc[m][n][x] = 0.f;
+    long long keep[4] = {0, 0, 0, 0};
+    const int r = lane & 31, h = lane >> 5;
+    const int col = r, hrow = 4 * h;
+    const int xsel = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
+    // fragment read offsets (bytes) inside a stage
+    const int offA = (wr * 128 + r) * 128, offB16 = F6_A_BYTES + (wc * 64 + r) * 128, offB8 = F6_A_BYTES + F6_B16_BYTES + (wc * 64 + r) * 64;
+    int ch16[4], ch8[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+        ch16[ks] = ((2 * ks + h) ^ ((r >> 1) & 7)) << 4;
+        ch8[ks] = ((2 * ks + h) ^ ((r >> 2) & 7)) << 3;
+    }
+
+    stage(nxt, lds6);
+    advance(nxt);
+    __syncthreads();
+    int buf = 0;
+    while (cur.valid) {
+        const int8_t* st = lds6 + buf * F6_STAGE;
+        if (nxt.valid) {
+            stage(nxt, lds6 + (buf ^ 1) * F6_STAGE);
+            advance(nxt);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            i32x8 a[4], bb[2];
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const i32x4 v = *(const i32x4*)(st + offA + m * (32 * 128) + ch16[ks]);
+                a[m][0] = v[0]; a[m][1] = v[1]; a[m][2] = v[2]; a[m][3] = v[3];
+                a[m][4] = 0; a[m][5] = 0; a[m][6] = 0; a[m][7] = 0;
+            }
+#pragma unroll
+            for (int n = 0; n < 2; n++) {
+                const i32x4 v = *(const i32x4*)(st + offB16 + n * (32 * 128) + ch16[ks]);
+                const i32x2 u = *(const i32x2*)(st + offB8 + n * (32 * 64) + ch8[ks]);
+                bb[n][0] = v[0]; bb[n][1] = v[1]; bb[n][2] = v[2]; bb[n][3] = v[3]; bb[n][4] = u[0]; bb[n][5] = u[1];
+                bb[n][6] = 0; bb[n][7] = 0;
+            }
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int n = 0; n < 2; n++)
+                    acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[m], bb[n], acc[m][n], 4, 2, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        }
+        if (cur.kt == cur.nk - 1) {
+            const int mvoff = (wr * 128 + hrow) * ldi + wc * 64 + col;
+            const int msoff = cur.ct * T8;
+            const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                int v16[16], v8[8], v4[4], v2[2];
+#pragma unroll
+                for (int x = 0; x < 16; x++) {
+                    const int so = (m * 32 + (x & 3) + 8 * (x >> 2)) * ldi + msoff;
+                    const int m0 = (int)(int8_t)__builtin_amdgcn_raw_buffer_load_b8(rsA8, mvoff, so, 0);
+                    const int m1 = (int)(int8_t)__builtin_amdgcn_raw_buffer_load_b8(rsA8, mvoff, so + 32, 0);
+                    v16[x] = (int)(acc[m][0][x] * 8.0f) * m0 + (int)(acc[m][1][x] * 8.0f) * m1;  // accumulators are exact multiples of 1/8
+                    acc[m][0][x] = 0.f;
+                    acc[m][1][x] = 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++) { int snd = b0 ? v16[i] : v16[i + 8]; int kp = b0 ? v16[i + 8] : v16[i]; v8[i] = kp + __shfl_xor(snd, 1); }
+#pragma unroll
+                for (int i = 0; i < 4; i++) { int snd = b1 ? v8[i] : v8[i + 4]; int kp = b1 ? v8[i + 4] : v8[i]; v4[i] = kp + __shfl_xor(snd, 2); }
+#pragma unroll
+                for (int i = 0; i < 2; i++) { int snd = b2 ? v4[i] : v4[i + 2]; int kp = b2 ? v4[i + 2] : v4[i]; v2[i] = kp + __shfl_xor(snd, 4); }
+                int v1 = (b3 ? v2[1] : v2[0]) + __shfl_xor(b3 ? v2[0] : v2[1], 8);
+                v1 += __shfl_xor(v1, 16);
+                keep[m] += v1;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            advance(cur);
+        } else {
+            cur.kt++;
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    long long* qs = q + (long)sl * Lp + (long)mt * T8 + wr * 128 + hrow + (xsel & 3) + 8 * (xsel >> 2);
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+        if ((lane & 16) == 0 && keep[m]) atomicAdd((unsigned long long*)&qs[m * 32], (unsigned long long)keep[m]);
+}
+
+__global__ __launch_bounds__(256) void k_vara_f6_finish(const long long* __restrict__ q, long Lp, const VaraHdr* __restrict__ hdr,
+                                                        const double* __restrict__ vdiag, double* __restrict__ vara) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Lp) return;
+    const int S = hdr->S, f = hdr->pad;
+    double x = 0.0;
+    for (int s = S - 1; s >= 0; s--) x = x * 33.0 + (double)q[(long)s * Lp + i];  // Horner, most significant digit first
+    vara[i] = vdiag[i] + ldexp(x, -f);
+}
+
+// workspace: [ VaraHdr (256) | q: Smax*L_pad int64 | dW: n_pad f64 | vdiag: L_pad f64 | Bs6: Smax * nblobs * 48 KiB ]
+static int ws6_smax(int nslices) { return nslices > 0 ? nslices : VARA6_SMAX_AUTO; }
+static long f6_nblobs(long n_pad) { const long nct = n_pad / T8; return nct * (nct + 1) / 2; }
+extern "C" int64_t eagle_vara_f6_workspace_bytes(long n_pad, long L_pad, int nslices) {
+    const int smax = ws6_smax(nslices);
+    return (int64_t)(ws_bs_off(n_pad, L_pad, smax) + (size_t)smax * f6_nblobs(n_pad) * F6_BLOB);
+}
+static int vara_f6_check(eagle_ctx* ctx, long L_pad, long n_pad, long ld, int nslices) {
+    if (L_pad % T8 || n_pad % T8 || ld % 128 || n_pad > ld || nslices < 0 || nslices > 12 || (double)ld * T8 >= 2147483648.0 ||
+        (double)f6_nblobs(n_pad) * F6_BLOB >= 4294967296.0)
+        return eagle_fail(ctx, EAGLE_ERR_ARG, "vara_f6: layout contract violated (L_pad % 256, n_pad % 256, 0 <= nslices <= 12)");
+    return EAGLE_OK;
+}
+
+extern "C" int eagle_dev_vara_f6_prepare(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu, int nslices,
+                                         void* ws, const double* v, double* a_out, void* stream) {
+    int rc = vara_f6_check(ctx, L_pad, n_pad, ld, nslices);
+    if (rc) return rc;
+    if (L_pad == 0) return EAGLE_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int smax = ws6_smax(nslices);
+    VaraHdr* hdr = (VaraHdr*)ws;
+    double* dW = (double*)((char*)ws + ws_dw_off(L_pad, smax));
+    double* vdiag = (double*)((char*)ws + ws_vd_off(n_pad, L_pad, smax));
+    uint8_t* Bs6 = (uint8_t*)((char*)ws + ws_bs_off(n_pad, L_pad, smax));
+    hipError_t e = hipMemsetAsync(ws, 0, ws_dw_off(L_pad, smax), s);  // header and q
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "vara_f6 memset");
+    hipLaunchKernelGGL(k_absmax_offdiag, dim3(1024), dim3(256), 0, s, Wu, n_pad, (unsigned long long*)&hdr->maxabs_off);
+    hipLaunchKernelGGL(k_vara_prep6, dim3(1), dim3(256), 0, s, Wu, n_pad, nslices, hdr, dW);
+    rc = eagle_dev_gemv2_i8(ctx, Mt8, L_pad, n_pad, ld, v ? v : dW, dW, 1.0, v ? a_out : nullptr, vdiag, stream);
+    if (rc) return rc;
+    dim3 g2((unsigned)(n_pad / 32), (unsigned)(n_pad / 32));
+    hipLaunchKernelGGL(k_slice_w6, g2, dim3(256), 0, s, Wu, n_pad, hdr, Bs6, f6_nblobs(n_pad));
+    e = hipGetLastError();
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "vara_f6_prepare");
+    return EAGLE_OK;
+}
+
+extern "C" int eagle_dev_vara_f6_mfma(eagle_ctx* ctx, const int8_t* Mt8, const void* Mt4, long L_pad, long n_pad, long ld, int nslices,
+                                      void* ws, double* vara_out, double* err_bound_dev, void* stream) {
+    int rc = vara_f6_check(ctx, L_pad, n_pad, ld, nslices);
+    if (rc) return rc;
+    if (L_pad == 0) return EAGLE_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int smax = ws6_smax(nslices);
+    VaraHdr* hdr = (VaraHdr*)ws;
+    long long* q = (long long*)((char*)ws + ws_q_off());
+    double* vdiag = (double*)((char*)ws + ws_vd_off(n_pad, L_pad, smax));
+    uint8_t* Bs6 = (uint8_t*)((char*)ws + ws_bs_off(n_pad, L_pad, smax));
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t ea = hipFuncSetAttribute((const void*)k_vara_f6, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F6_STAGE);
+        if (ea != hipSuccess) return eagle_fail_hip(ctx, ea, "hipFuncSetAttribute(k_vara_f6)");
+        attr_done = true;
+    }
+    const int ntm = (int)(L_pad / T8);
+    const int groups = (ntm + 7) / 8;
+    hipLaunchKernelGGL(k_vara_f6, dim3((unsigned)(groups * 8 * smax)), dim3(512), 2 * F6_STAGE, s, Mt8, ld, (const uint8_t*)Mt4, n_pad / 2, ntm, Bs6,
+                       f6_nblobs(n_pad), n_pad, hdr, q, L_pad);
+    hipLaunchKernelGGL(k_vara_f6_finish, dim3((unsigned)((L_pad + 255) / 256)), dim3(256), 0, s, q, L_pad, hdr, vdiag, vara_out);
+    if (err_bound_dev) hipLaunchKernelGGL(k_vara_i8_bound, dim3(1), dim3(1), 0, s, hdr, err_bound_dev, (int*)nullptr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "vara_f6_mfma");
+    return EAGLE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MM^T on the same instruction with BOTH operands fp4: C32 += M M^T from the individual-major fp4 image M4[n_pad][L_pad/2].
+// A stage is 256 markers = 128 bytes per individual row -- the int8 engine's LDS image, DMA and fragment addressing
+// unchanged -- so the same 64 KiB fill and the same 32 matrix instructions per wave now cover twice the markers.
+// Products are +-1, fp32 partial sums are exact integers (a K split is far below 2^24 markers), int32 atomics as before.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void k_syrk_f4(const uint8_t* __restrict__ M4, long ld4, const int* __restrict__ pairs, int npairs,
+                                                    int nblocks, long nstages, long stages_per_split, int32_t* __restrict__ C, long ldc) {
+    __shared__ __attribute__((aligned(1024))) int8_t lds[2][2][TILE_BYTES];
+    const int cpx = (gridDim.x + 7) / 8;
+    const int lid = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+    if (lid >= nblocks) return;
+    const int split = lid / npairs;
+    const int pr = pairs[lid - split * npairs];
+    const int ti = pr >> 16, tj = pr & 0xffff;
+    const long s0 = (long)split * stages_per_split;
+    long s1 = s0 + stages_per_split;
+    if (s1 > nstages) s1 = nstages;
+    if (s0 >= s1) return;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = w >> 2, wc = w & 3;
+    const int ldi = (int)ld4;
+    const T8Lane ln = t8_lane(lane, ldi);
+    const __amdgpu_buffer_rsrc_t rsA = t8_rsrc((const int8_t*)M4 + (long)ti * T8 * ld4, ldi);
+    const __amdgpu_buffer_rsrc_t rsB = t8_rsrc((const int8_t*)M4 + (long)tj * T8 * ld4, ldi);
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int x = 0; x < 16; x++) acc[m][n][x] = 0.f;
+    t8_stage(rsA, ln, ldi, (int)(s0 * BK8), lds[0][0], w);
+    t8_stage(rsB, ln, ldi, (int)(s0 * BK8), lds[0][1], w);
+    __syncthreads();
+    int cur = 0;
+    const T8Read rd = t8_read_init(wr, wc, lane);
+    for (long s = s0; s < s1; s++) {
+        if (s + 1 < s1) {
+            const int kn = (int)((s + 1) * BK8);
+            t8_stage(rsA, ln, ldi, kn, lds[cur ^ 1][0], w);
+            t8_stage(rsB, ln, ldi, kn, lds[cur ^ 1][1], w);
+        }
+        const int8_t* pa = lds[cur][0] + rd.offA;
+        const int8_t* pb = lds[cur][1] + rd.offB;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            i32x8 a[4], b[2];
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const i32x4 v = *(const i32x4*)(pa + m * (32 * BK8) + rd.ch[ks]);
+                a[m][0] = v[0]; a[m][1] = v[1]; a[m][2] = v[2]; a[m][3] = v[3]; a[m][4] = 0; a[m][5] = 0; a[m][6] = 0; a[m][7] = 0;
+            }
+#pragma unroll
+            for (int n = 0; n < 2; n++) {
+                const i32x4 v = *(const i32x4*)(pb + n * (32 * BK8) + rd.ch[ks]);
+                b[n][0] = v[0]; b[n][1] = v[1]; b[n][2] = v[2]; b[n][3] = v[3]; b[n][4] = 0; b[n][5] = 0; b[n][6] = 0; b[n][7] = 0;
+            }
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int n = 0; n < 2; n++)
+                    acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[m], b[n], acc[m][n], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    const int col = lane & 31, rq = 4 * (lane >> 5);
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int x = 0; x < 16; x++) {
+                long i = (long)ti * T8 + wr * 128 + m * 32 + (x & 3) + 8 * (x >> 2) + rq;
+                long j = (long)tj * T8 + wc * 64 + n * 32 + col;
+                int v = (int)acc[m][n][x];
+                if (v) atomicAdd(&C[i * ldc + j], v);
+            }
+}
+
+// C32[np][np] += M M^T over the marker columns [0, L_pad) of the fp4 image M4[n_pad][ld4 bytes] (eagle_dev_pack_fp4 of M8).
+extern "C" int eagle_dev_mmt_accumulate_f4(eagle_ctx* ctx, const void* M4, long n_pad, long L_pad, long ld4, int32_t* C32, void* stream) {
+    if (n_pad % T8 || L_pad % 256 || ld4 % 128 || L_pad > ld4 * 2 || n_pad <= 0 || (double)ld4 * T8 >= 2147483648.0)
+        return eagle_fail(ctx, EAGLE_ERR_ARG, "mmt_accumulate_f4: layout contract violated (n_pad % 256, L_pad % 256, ld4 % 128)");
+    if (L_pad == 0) return EAGLE_OK;
+    const int nt = (int)(n_pad / T8);
+    const long npairs = (long)nt * (nt + 1) / 2;
+    const long nstages = L_pad / 256;
+    long want = (10L * 256 + npairs - 1) / npairs;
+    long maxsplit = nstages / 16 > 0 ? nstages / 16 : 1;
+    long nsplit = want < maxsplit ? want : maxsplit;
+    if (nsplit < 1) nsplit = 1;
+    long per = (nstages + nsplit - 1) / nsplit;
+    if (per * 256 >= (1L << 24)) per = (1L << 24) / 256 - 1;  // fp32 partial sums stay exact integers
+    nsplit = (nstages + per - 1) / per;
+    const long nblocks = npairs * nsplit;
+    if (nblocks >= (1L << 30)) return eagle_fail(ctx, EAGLE_ERR_ARG, "mmt_accumulate_f4: too many workgroups");
+    const int* pairs = nullptr;
+    int rc = syrk_pair_table(ctx, nt, &pairs, (hipStream_t)stream);
+    if (rc) return rc;
+    dim3 grid((unsigned)((nblocks + 7) / 8 * 8));
+    hipLaunchKernelGGL(k_syrk_f4, grid, dim3(512), 0, (hipStream_t)stream, (const uint8_t*)M4, ld4, pairs, (int)npairs, (int)nblocks, nstages, per,
+                       C32, n_pad);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "k_syrk_f4");
+    return EAGLE_OK;
+}
+
+// Public int8 entry: packs the int8 image to fp4 (one extra read of it, 0.3 bytes written per genotype byte) into a
+// ctx-owned buffer and runs k_syrk_f4.  Callers that keep the fp4 image themselves use eagle_dev_mmt_accumulate_f4.
+extern "C" int eagle_dev_mmt_accumulate(eagle_ctx* ctx, const int8_t* M8, long n_pad, long L_pad, long ld, int32_t* C32, void* stream) {
+    if (n_pad % T8 || L_pad % 256 || ld % 16 || L_pad > ld || n_pad <= 0)
+        return eagle_fail(ctx, EAGLE_ERR_ARG, "mmt_accumulate: layout contract violated (n_pad % 256, L_pad % 256, ld % 16)");
+    if (L_pad == 0) return EAGLE_OK;
+    void* buf = eagle_ctx_f4_buffer(ctx, (size_t)n_pad * (size_t)(L_pad / 2));
+    if (!buf) return EAGLE_ERR_HIP;
+    int rc = eagle_dev_pack_fp4(ctx, M8, n_pad, L_pad, ld, buf, stream);
+    if (rc) return rc;
+    return eagle_dev_mmt_accumulate_f4(ctx, buf, n_pad, L_pad, L_pad / 2, C32, stream);
 }

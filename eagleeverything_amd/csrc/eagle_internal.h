@@ -16,6 +16,8 @@ int eagle_dev_gemm_f64(eagle_ctx* ctx, const double* A, const double* B, double*
 int eagle_dev_colgemv(eagle_ctx* ctx, const double* At, long n, long n_pad, const double* x, double* out, void* stream);
 // 4 KiB of ctx-owned device scratch (flags, small reductions); stream-ordered use only
 void* eagle_ctx_scratch(eagle_ctx* ctx);
+// grow-only ctx-owned device buffer for the fp4 image of a genotype tile (NULL + last_error on failure)
+void* eagle_ctx_f4_buffer(eagle_ctx* ctx, size_t bytes);
 int eagle_dev_gemv2_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* v, const double* w,
                        double scale, double* out_a, double* out_d, void* stream);
 int eagle_dev_extract_col(eagle_ctx* ctx, const int8_t* M8, long n, long ld, long col, int* out, void* stream);

@@ -99,12 +99,15 @@ class DeviceShard:
         self.Lp = int(self.L.eagle_pad(self.Lloc))
         self.Mt8 = torch.zeros((self.Lp, self.np_), dtype=torch.int8, device=self.dev)  # marker-major
         self.M8 = None                                                                   # individual-major
+        self.M4 = None                                                                   # individual-major, fp4
         self.a = torch.zeros(self.Lp, dtype=torch.float64, device=self.dev)
         self.vara = torch.zeros(self.Lp, dtype=torch.float64, device=self.dev)
         self._scratch = torch.zeros(3 * 1024, dtype=torch.float64, device=self.dev)
         self._best = torch.zeros(3, dtype=torch.int64, device=self.dev)  # eagle_best: {f64, i64, i64}
         self.Sa = self.Va = self.ahat = self.v = self.Wu = self.tmp = None
         self.ws = None
+        self._ws_mode = None
+        self.Mt4 = None
         self.mode = 0
         self.nslices = 0  # 0 = chosen by the library from its error bound
 
@@ -155,15 +158,24 @@ class DeviceShard:
                                                       self.M8.data_ptr(), self.Lp, self._stream()))
         return self.M8
 
+    def individual_major_fp4(self):
+        """M4: the individual-major genotypes as fp4 (two per byte), the operand image of the MM^T kernel."""
+        if self.M4 is None:
+            M8 = self.individual_major()
+            self.M4 = self.torch.empty((self.np_, self.Lp // 2), dtype=self.torch.uint8, device=self.dev)
+            self._check(self.L.eagle_dev_pack_fp4(self.ctx, M8.data_ptr(), self.np_, self.Lp, self.Lp, self.M4.data_ptr(),
+                                                  self._stream()))
+        return self.M4
+
     # ---- MM^T -----------------------------------------------------------------------------------
     def mmt_partial(self, out=None):
         """Exact int32 partial M_s M_s^T of this shard (upper-triangular 256-tiles live)."""
         torch = self.torch
-        M8 = self.individual_major()
+        M4 = self.individual_major_fp4()
         c32 = out if out is not None else torch.empty((self.np_, self.np_), dtype=torch.int32, device=self.dev)
         c32.zero_()
-        self._check(self.L.eagle_dev_mmt_accumulate(self.ctx, M8.data_ptr(), self.np_, self.Lp, self.Lp, c32.data_ptr(),
-                                                    self._stream()))
+        self._check(self.L.eagle_dev_mmt_accumulate_f4(self.ctx, M4.data_ptr(), self.np_, self.Lp, self.Lp // 2, c32.data_ptr(),
+                                                       self._stream()))
         return c32
 
     def mmt_finish(self, c32, normalise=False):
@@ -212,24 +224,39 @@ class DeviceShard:
                                              1.0, self.a.data_ptr(), self._stream()))
 
     def _ws(self):
-        if self.ws is None:
-            nb = int(self.L.eagle_vara_i8_workspace_bytes(self.np_, self.Lp, self.nslices))
+        if self.ws is None or self._ws_mode != self.mode:
+            fn = self.L.eagle_vara_f6_workspace_bytes if self.mode == 2 else self.L.eagle_vara_i8_workspace_bytes
+            nb = int(fn(self.np_, self.Lp, self.nslices))
+            self.ws = None
             self.ws = self.torch.empty(nb, dtype=self.torch.uint8, device=self.dev)
+            self._ws_mode = self.mode
         return self.ws
+
+    def fp4_image(self):
+        """Mt4: the genotypes as fp4 (two per byte), made once per shard for the fp4 x fp6 vara kernel (mode 2)."""
+        if self.Mt4 is None:
+            self.Mt4 = self.torch.empty((self.Lp, self.np_ // 2), dtype=self.torch.uint8, device=self.dev)
+            self._check(self.L.eagle_dev_pack_fp4(self.ctx, self.Mt8.data_ptr(), self.Lp, self.np_, self.np_, self.Mt4.data_ptr(),
+                                                  self._stream()))
+        return self.Mt4
 
     def vara_prepare(self, with_a=True):
         """int8 path, phase 1: slice W, and ONE pass over the genotypes for a = Mt v and the diagonal term of vara."""
         ws = self._ws()
-        self._check(self.L.eagle_dev_vara_i8_prepare(self.ctx, self.Mt8.data_ptr(), self.Lp, self.np_, self.np_,
-                                                     self.Wu.data_ptr(), self.nslices, ws.data_ptr(),
-                                                     self.v.data_ptr() if with_a else None,
-                                                     self.a.data_ptr() if with_a else None, self._stream()))
+        prep = self.L.eagle_dev_vara_f6_prepare if self.mode == 2 else self.L.eagle_dev_vara_i8_prepare
+        self._check(prep(self.ctx, self.Mt8.data_ptr(), self.Lp, self.np_, self.np_,
+                    self.Wu.data_ptr(), self.nslices, ws.data_ptr(), self.v.data_ptr() if with_a else None,
+                    self.a.data_ptr() if with_a else None, self._stream()))
 
     def vara_kernel(self):
         """The dominant kernel alone: fp64 MFMA vara kernel (mode 0) or the int8 MFMA kernel + finish (mode 1)."""
         if self.mode == 0:
             self._check(self.L.eagle_dev_vara_f64(self.ctx, self.Mt8.data_ptr(), self.Lp, self.np_, self.np_,
                                                   self.Wu.data_ptr(), self.vara.data_ptr(), self._stream()))
+        elif self.mode == 2:
+            self._check(self.L.eagle_dev_vara_f6_mfma(self.ctx, self.Mt8.data_ptr(), self.fp4_image().data_ptr(), self.Lp, self.np_,
+                                                      self.np_, self.nslices, self._ws().data_ptr(), self.vara.data_ptr(), None,
+                                                      self._stream()))
         else:
             self._check(self.L.eagle_dev_vara_i8_mfma(self.ctx, self.Mt8.data_ptr(), self.Lp, self.np_, self.np_, self.nslices,
                                                       self._ws().data_ptr(), self.vara.data_ptr(), None, self._stream()))

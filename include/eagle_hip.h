@@ -194,9 +194,14 @@ int eagle_dev_i8_to_f64_colmajor(eagle_ctx* ctx, const int8_t* in, long rows, lo
                                  double* out_colmajor, void* stream);
 
 /* C32[np][np] (int32, row-major, caller-zeroed) += M8 * M8^T over the marker columns [0, L_pad).
- * Upper-triangular tiles only; exact integers, order independent (integer atomics). */
+ * Upper-triangular tiles only; exact integers, order independent (integer atomics).  The products run on
+ * v_mfma_scale_f32_32x32x64_f8f6f4 with both operands fp4 (-1, 0, +1 are exact e2m1 numbers; fp32 partial sums of a K
+ * split are exact integers): eagle_dev_mmt_accumulate packs the int8 image into a ctx-owned fp4 buffer first,
+ * eagle_dev_mmt_accumulate_f4 takes an image the caller made with eagle_dev_pack_fp4 (M4[n_pad][ld4 bytes], two
+ * genotypes per byte).  n_pad % 256 == 0, L_pad % 256 == 0. */
 int eagle_dev_mmt_accumulate(eagle_ctx* ctx, const int8_t* M8, long n_pad, long L_pad, long ld, int32_t* C32,
                              void* stream);
+int eagle_dev_mmt_accumulate_f4(eagle_ctx* ctx, const void* M4, long n_pad, long L_pad, long ld4, int32_t* C32, void* stream);
 /* C32 -= sum over the listed marker columns of m_c m_c^T  (the selected_loci masking of
  * calculateMMt_rcpp.cpp:88-92 applied as an exact rank-k downdate). cols_dev: device array of long. */
 int eagle_dev_mmt_downdate(eagle_ctx* ctx, const int8_t* M8, long n_pad, long ld, const long* cols_dev,
@@ -237,6 +242,17 @@ int eagle_dev_vara_i8_mfma(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n
                            double* vara_out, double* err_bound_dev, void* stream);
 int eagle_dev_vara_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu,
                       int nslices, void* ws, double* vara_out, double* err_bound_dev, void* stream);
+/* The same quadratic form on the block-scaled matrix path (v_mfma_scale_f32_32x32x64_f8f6f4): genotypes as fp4, balanced
+ * base-33 digits of Wu as fp6 (every integer in [-16,16] is an e2m3 number / 8), exact fp32 sums, twice the MAC rate of
+ * the int8 instruction.  Mt4: [L_pad][n_pad/2] bytes made once per genotype matrix by eagle_dev_pack_fp4 (two genotypes
+ * per byte).  nslices: 0 = automatic (same 1e-9 criterion), 1..12 = fixed; absolute error bound n_pad^2 * 2^(e-5S).
+ * The workspace head has the layout of the int8 one ({max|offdiag|; S; f; bound; sum|diag|}). */
+int64_t eagle_vara_f6_workspace_bytes(long n_pad, long L_pad, int nslices);
+int eagle_dev_pack_fp4(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, void* Mt4, void* stream);
+int eagle_dev_vara_f6_prepare(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu,
+                              int nslices, void* ws, const double* v, double* a_out, void* stream);
+int eagle_dev_vara_f6_mfma(eagle_ctx* ctx, const int8_t* Mt8, const void* Mt4, long L_pad, long n_pad, long ld, int nslices,
+                           void* ws, double* vara_out, double* err_bound_dev, void* stream);
 /* zero a[i], vara[i] at the listed rows (row masking of calculate_a_and_vara_rcpp.cpp:79-84: a zeroed
  * marker row yields exactly a = 0, vara = 0). rows_dev: device array of long, entries outside [0,L) ignored. */
 int eagle_dev_zero_rows(eagle_ctx* ctx, double* a, double* vara, long L, const long* rows_dev, long nrows,

@@ -354,6 +354,39 @@ def test_large_n_device_path(api, oracle):
     assert float(mx) == float(MMt.max())
 
 
+def test_vara_fp4_fp6_engine(api, oracle):
+    """The block-scaled form of the vara kernel (genotypes fp4, base-33 digits of W as fp6, exact fp32 sums): against the
+    oracle with the automatic digit count, and inside its documented bound n_pad^2 * 2^(e-5S) with fewer digits."""
+    import torch
+    from eagleeverything_amd.sharded import DeviceShard
+    n, L = 700, 3000
+    sh = DeviceShard(n, L)
+    sh.fill_synthetic(seed=3)
+    gen = torch.Generator(device=sh.dev)
+    gen.manual_seed(5)
+    A = torch.randn((n, 48), generator=gen, device=sh.dev, dtype=torch.float64) / 32.0
+    S = 0.5 * torch.eye(n, dtype=torch.float64, device=sh.dev) + A @ A.T
+    V = 0.6 * torch.eye(n, dtype=torch.float64, device=sh.dev) - 0.03 * (A[:, :6] @ A[:, :6].T)
+    ahat = torch.randn(n, generator=gen, device=sh.dev, dtype=torch.float64)
+    sh.set_operands(S, V, ahat)
+    a_ref, v_ref = oracle.scan_from_i8(sh.Mt8[:L, :n].cpu().numpy(), S.cpu().numpy(), V.cpu().numpy(), ahat.cpu().numpy())
+    sh.mode = 2
+    sh.scan()
+    torch.cuda.synchronize()
+    first = sh.vara[:L].cpu().numpy()
+    np.testing.assert_allclose(first, v_ref, rtol=1e-9)
+    np.testing.assert_allclose(sh.a[:L].cpu().numpy(), a_ref, rtol=1e-9, atol=1e-12 * np.abs(a_ref).max())
+    sh.scan()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(sh.vara[:L].cpu().numpy(), first)  # integer atomics: bitwise reproducible
+    for S_ in (4, 6, 8, 10):
+        sh.nslices, sh.ws = S_, None
+        sh.scan()
+        torch.cuda.synchronize()
+        used, bound, _ = sh.vara_i8_info()
+        assert used == S_ and np.abs(sh.vara[:L].cpu().numpy() - v_ref).max() <= bound + 1e-12 * np.abs(v_ref).max()
+
+
 def test_config_C3_shape_single_gpu(api, oracle):
     """BASELINE.json configs[2] at its full shape on ONE card (10,000 individuals x 1,000,000 markers, resident): the scan
     against the oracle on a marker sample, MM^T through exact size-independent properties (diagonal = sums of squares,

@@ -19,9 +19,22 @@ ldpad = int(os.environ.get("LDPAD", 0))
 M8p = torch.zeros((sh.np_, sh.Lp + ldpad), dtype=torch.int8, device=sh.dev)
 M8p[:, :sh.Lp] = sh.M8
 import ctypes as C
+lib.eagle_dev_pack_fp4.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p]
+lib.eagle_dev_mmt_accumulate_f4.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p]
+lib.eagle_dev_mmt_accumulate_f4.restype = C.c_int
+lib.eagle_dev_mmt_accumulate_i8.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p]
+lib.eagle_dev_mmt_accumulate_i8.restype = C.c_int
+M4 = torch.zeros((sh.np_, sh.Lp // 2), dtype=torch.uint8, device=sh.dev)
+assert lib.eagle_dev_pack_fp4(sh.ctx, sh.M8.data_ptr(), sh.np_, sh.Lp, sh.Lp, M4.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+use_f4 = False
 def run_syrk(out):
     out.zero_()
-    rc = lib.eagle_dev_mmt_accumulate(sh.ctx, M8p.data_ptr(), sh.np_, sh.Lp, sh.Lp + ldpad, out.data_ptr(),
+    if use_f4:
+        rc = lib.eagle_dev_mmt_accumulate_f4(sh.ctx, M4.data_ptr(), sh.np_, sh.Lp, sh.Lp // 2, out.data_ptr(),
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+        return
+    rc = lib.eagle_dev_mmt_accumulate_i8(sh.ctx, M8p.data_ptr(), sh.np_, sh.Lp, sh.Lp + ldpad, out.data_ptr(),
                                       C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0
 ref = None
@@ -29,7 +42,8 @@ res = {v: [] for v in variants}
 ops = (sh.np_ * (sh.np_ + 256.0)) * sh.Lp
 for rnd in range(5):
     for v in variants:
-        lib.eagle_dev_set_tune(v % 100)
+        lib.eagle_dev_set_tune(0 if v == 8 else v % 100)
+        use_f4 = v == 8
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         c32.zero_()
         e0.record(); run_syrk(c32); e1.record()
