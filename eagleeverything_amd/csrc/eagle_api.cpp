@@ -105,7 +105,8 @@ extern "C" eagle_ctx* eagle_open(int device) {
         delete ctx;
         return nullptr;
     }
-    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->load_stream, hipStreamNonBlocking)) != hipSuccess) {
         snprintf(g_open_err, sizeof g_open_err, "hipStreamCreate: %s", hipGetErrorString(e));
         delete ctx;
         return nullptr;
@@ -136,6 +137,7 @@ extern "C" void eagle_close(eagle_ctx* ctx) {
     if (ctx->f4_buf) (void)hipFree(ctx->f4_buf);
     for (int b = 0; b < 2; b++) { if (ctx->stage_pin[b]) (void)hipHostFree(ctx->stage_pin[b]); if (ctx->stage_raw[b]) (void)hipFree(ctx->stage_raw[b]); }
     (void)hipStreamDestroy(ctx->stream);
+    if (ctx->load_stream) (void)hipStreamDestroy(ctx->load_stream);
     delete ctx;
 }
 
@@ -544,10 +546,45 @@ size_t eagle_resident_budget() { return resident_budget(); }
 static long stream_chunk_rows(long row_bytes, long total_rows_pad) {
     size_t budget = resident_budget();
     if (budget == (size_t)-1) budget = (size_t)8 << 30;  // 8 GiB chunks when streaming because HBM is full
-    long rows = (long)(budget / (size_t)row_bytes) / 256 * 256;
+    long rows = (long)(budget / 2 / (size_t)row_bytes) / 256 * 256;  // two chunk buffers share the budget
     if (rows < 256) rows = 256;
     return rows < total_rows_pad ? rows : total_rows_pad;
 }
+
+// Out-of-core streaming: chunk k+1 is read (pread -> pinned -> H2D -> decode, all on ctx->load_stream) while the kernels
+// of chunk k run on ctx->stream.  Two chunk buffers; an event per buffer says when its kernels are done.
+struct ChunkRing {
+    int8_t* buf[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    long k = 0;
+    ~ChunkRing() { for (int b = 0; b < 2; b++) if (done[b]) (void)hipEventDestroy(done[b]); }
+    int init(eagle_ctx* ctx) {
+        for (int b = 0; b < 2; b++) HIPCHK(ctx, hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
+        return EAGLE_OK;
+    }
+    // returns the buffer holding the freshly loaded tile (zero padded to clear_bytes); the caller launches its kernels on
+    // ctx->stream and then calls computed()
+    int load(eagle_ctx* ctx, const char* path, long row0, long nrows, long col0, long ncols, long ld, size_t clear_bytes, double mem_gb,
+             int threads, int8_t** out) {
+        const int b = (int)(k & 1);
+        if (k >= 2) HIPCHK(ctx, hipEventSynchronize(done[b]));  // the kernels that read this buffer two chunks ago
+        hipStream_t main = ctx->stream;
+        ctx->stream = ctx->load_stream;  // every loader below works on ctx->stream
+        int rc = EAGLE_OK;
+        hipError_t e = hipMemsetAsync(buf[b], 0, clear_bytes, ctx->stream);
+        if (e != hipSuccess) rc = eagle_fail_hip(ctx, e, "chunk memset");
+        if (!rc) rc = eagle_dev_load_ascii(ctx, path, row0, nrows, col0, ncols, buf[b], ld, mem_gb, threads);
+        if (!rc && (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) rc = eagle_fail_hip(ctx, e, "chunk load sync");
+        ctx->stream = main;
+        *out = buf[b];
+        return rc;
+    }
+    int computed(eagle_ctx* ctx) {
+        HIPCHK(ctx, hipEventRecord(done[(int)(k & 1)], ctx->stream));
+        k++;
+        return EAGLE_OK;
+    }
+};
 
 // column-major n x n host matrix -> zero padded np x np device image (row-major image of the transpose)
 static int upload_square(eagle_ctx* ctx, const double* host, long n, long np, double* dev) {
@@ -626,14 +663,18 @@ extern "C" int eagle_calculateMMt(eagle_ctx* ctx, const char* f_name_ascii, doub
         // M.ascii does not fit (or may not stay) in HBM: stream column windows of every line (= marker chunks) and
         // accumulate the exact integer partial products, MMt = sum_w M_w M_w^T.
         const long Lw = stream_chunk_rows(np, eagle_pad(L));  // window width in markers; rows of the window = np
-        HIPCHK(ctx, win.alloc((size_t)np * Lw));
+        HIPCHK(ctx, win.alloc((size_t)2 * np * Lw));
+        ChunkRing ring;
+        if ((rc = ring.init(ctx))) return rc;
+        ring.buf[0] = win.as<int8_t>();
+        ring.buf[1] = win.as<int8_t>() + (size_t)np * Lw;
         if (!quiet) say(ctx, " M.ascii streamed through HBM in windows of %ld markers", Lw);
         for (long c0 = 0; c0 < L; c0 += Lw) {
             const long nc = std::min(Lw, L - c0);
-            HIPCHK(ctx, hipMemsetAsync(win.p, 0, (size_t)np * Lw, ctx->stream));
-            rc = eagle_dev_load_ascii(ctx, f_name_ascii, 0, n, c0, nc, win.as<int8_t>(), Lw, max_memory_in_Gbytes, threads);
+            int8_t* wtile = nullptr;
+            rc = ring.load(ctx, f_name_ascii, 0, n, c0, nc, Lw, (size_t)np * Lw, max_memory_in_Gbytes, threads, &wtile);
             if (rc) return rc;
-            rc = eagle_dev_mmt_accumulate(ctx, win.as<int8_t>(), np, Lw, Lw, c32.as<int32_t>(), ctx->stream);
+            rc = eagle_dev_mmt_accumulate(ctx, wtile, np, Lw, Lw, c32.as<int32_t>(), ctx->stream);
             if (rc) return rc;
             std::vector<long> in_win;
             for (long c : sel) if (c >= c0 && c < c0 + nc) in_win.push_back(c - c0);
@@ -643,10 +684,11 @@ extern "C" int eagle_calculateMMt(eagle_ctx* ctx, const char* f_name_ascii, doub
                 HIPCHK(ctx, hipMemcpyAsync(dw.p, in_win.data(), sizeof(long) * in_win.size(), hipMemcpyHostToDevice, ctx->stream));
                 // duplicates of one column must be dropped across the whole list, which k_mmt_downdate does per call:
                 // selected_loci entries are distinct columns in any sane call; duplicates inside one window are handled
-                rc = eagle_dev_mmt_downdate(ctx, win.as<int8_t>(), np, Lw, dw.as<long>(), (long)in_win.size(), c32.as<int32_t>(), ctx->stream);
+                rc = eagle_dev_mmt_downdate(ctx, wtile, np, Lw, dw.as<long>(), (long)in_win.size(), c32.as<int32_t>(), ctx->stream);
                 if (rc) return rc;
                 HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
             }
+            if ((rc = ring.computed(ctx))) return rc;
         }
     }
     if (ctx->mmt_n != n) {
@@ -730,7 +772,7 @@ extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_asc
     const size_t wsb = use_i8 ? (size_t)eagle_vara_i8_workspace_bytes(np, Lc, nslices) : 0;
     const double t0 = now_s();
     if ((rc = arena_reserve(ctx, 4 * arena_round(sq) + 2 * arena_round(sizeof(double) * np) + arena_round(wsb) +
-                                     (streamed ? arena_round((size_t)Lc * np) : 0))))
+                                     (streamed ? 2 * arena_round((size_t)Lc * np) : 0))))
         return rc;
     double* Sa = arena_take<double>(ctx, sq);
     double* Va = arena_take<double>(ctx, sq);
@@ -739,7 +781,12 @@ extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_asc
     double* ah = arena_take<double>(ctx, sizeof(double) * np);
     double* v = arena_take<double>(ctx, sizeof(double) * np);
     void* ws = arena_take<char>(ctx, wsb);
-    int8_t* chunk = streamed ? arena_take<int8_t>(ctx, (size_t)Lc * np) : nullptr;
+    ChunkRing ring;
+    if (streamed) {
+        if ((rc = ring.init(ctx))) return rc;
+        ring.buf[0] = arena_take<int8_t>(ctx, (size_t)Lc * np);
+        ring.buf[1] = arena_take<int8_t>(ctx, (size_t)Lc * np);
+    }
     if ((rc = upload_square(ctx, inv_MMt_sqrt, n, np, Sa))) return rc;
     if ((rc = upload_square(ctx, dim_reduced_vara, n, np, Va))) return rc;
     if ((rc = upload_vec(ctx, a, n, np, ah))) return rc;
@@ -752,12 +799,13 @@ extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_asc
     // one pass per marker block: the whole file when it is resident, else chunks read back from the file
     for (long r0 = 0; r0 < L; r0 += Lc) {
         const long nr = std::min(Lc, L - r0), nrp = eagle_pad(nr);
-        const int8_t* Mt8 = streamed ? chunk : g->dev;
+        const int8_t* Mt8 = streamed ? nullptr : g->dev;
         const long ldm = streamed ? np : g->ld;
         if (streamed) {
-            HIPCHK(ctx, hipMemsetAsync(chunk, 0, (size_t)nrp * np, ctx->stream));
-            rc = eagle_dev_load_ascii(ctx, f_name_ascii, r0, nr, 0, n, chunk, np, max_memory_in_Gbytes, host_threads());
+            int8_t* tile = nullptr;
+            rc = ring.load(ctx, f_name_ascii, r0, nr, 0, n, np, (size_t)nrp * np, max_memory_in_Gbytes, host_threads(), &tile);
             if (rc) return rc;
+            Mt8 = tile;
         }
         if (use_i8) {
             // one pass over the genotypes gives a = Mt v and the diagonal term of vara; then the int8 MFMA kernel
@@ -770,7 +818,7 @@ extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_asc
             rc = eagle_dev_vara_f64(ctx, Mt8, nrp, np, ldm, Wu, ctx->d_vara + r0, ctx->stream);
         }
         if (rc) return rc;
-        if (streamed) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the chunk buffer is reused
+        if (streamed && (rc = ring.computed(ctx))) return rc;
     }
     if (timing_on()) {
         (void)hipStreamSynchronize(ctx->stream);
@@ -895,22 +943,28 @@ extern "C" int eagle_calculate_reduced_a(eagle_ctx* ctx, const char* f_name_asci
     HIPCHK(ctx, Pa.alloc(sizeof(double) * (size_t)np * np));
     HIPCHK(ctx, yv.alloc(sizeof(double) * np)); HIPCHK(ctx, py.alloc(sizeof(double) * np));
     HIPCHK(ctx, out.alloc(sizeof(double) * Lp));
-    if (streamed) HIPCHK(ctx, chunk.alloc((size_t)Lc * np));
+    ChunkRing ring;
+    if (streamed) {
+        HIPCHK(ctx, chunk.alloc((size_t)2 * Lc * np));
+        if ((rc = ring.init(ctx))) return rc;
+        ring.buf[0] = chunk.as<int8_t>();
+        ring.buf[1] = chunk.as<int8_t>() + (size_t)Lc * np;
+    }
     if ((rc = upload_square(ctx, P, n, np, Pa.as<double>()))) return rc;
     if ((rc = upload_vec(ctx, y, n, np, yv.as<double>()))) return rc;
     rc = eagle_dev_colgemv(ctx, Pa.as<double>(), n, np, yv.as<double>(), py.as<double>(), ctx->stream);  // :82
     if (rc) return rc;
     for (long r0 = 0; r0 < L; r0 += Lc) {  // :83-84, one pass per marker block (the whole file when resident)
         const long nr = std::min(Lc, L - r0), nrp = eagle_pad(nr);
+        int8_t* tile = nullptr;
         if (streamed) {
-            HIPCHK(ctx, hipMemsetAsync(chunk.p, 0, (size_t)nrp * np, ctx->stream));
-            rc = eagle_dev_load_ascii(ctx, f_name_ascii, r0, nr, 0, n, chunk.as<int8_t>(), np, max_memory_in_Gbytes, host_threads());
+            rc = ring.load(ctx, f_name_ascii, r0, nr, 0, n, np, (size_t)nrp * np, max_memory_in_Gbytes, host_threads(), &tile);
             if (rc) return rc;
         }
-        rc = eagle_dev_gemv_i8(ctx, streamed ? chunk.as<int8_t>() : g->dev, nrp, np, streamed ? np : g->ld, py.as<double>(), varG,
+        rc = eagle_dev_gemv_i8(ctx, streamed ? tile : g->dev, nrp, np, streamed ? np : g->ld, py.as<double>(), varG,
                                out.as<double>() + r0, ctx->stream);
         if (rc) return rc;
-        if (streamed) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (streamed && (rc = ring.computed(ctx))) return rc;
     }
     if (!sel.empty()) {  // :74-78
         HIPCHK(ctx, dsel.alloc(sizeof(long) * sel.size()));

@@ -28,6 +28,7 @@ struct GenoEntry {
 struct eagle_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t load_stream = nullptr;  // tile loads of the streamed (out-of-core) paths run here, under the kernels of `stream`
     char err[1024] = {0};
     eagle_message_fn msg_fn = nullptr;
     void* msg_user = nullptr;
