@@ -21,6 +21,7 @@
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
 
 #define T8 256          /* block tile (rows of A, rows of B) */
 #define BK8 128         /* K bytes per stage */
@@ -588,7 +589,6 @@ extern "C" int eagle_dev_vara_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, 
 // ================================================================================================
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
-typedef int i32x2 __attribute__((ext_vector_type(2)));
 #define F6_A_BYTES 32768
 #define F6_B16_BYTES 32768
 #define F6_B8_BYTES 16384
@@ -596,20 +596,32 @@ typedef int i32x2 __attribute__((ext_vector_type(2)));
 #define F6_STAGE (F6_A_BYTES + F6_BLOB)
 #define VARA6_SMAX_AUTO 11
 
+// 16 genotypes (one 16-byte load) -> 8 bytes per thread.  int8 m in {0x00, 0x01, 0xFF} -> e2m1 code ((m & 1) << 1) | ((m & 0x80) >> 4)
+// = {0x0, 0x2, 0xA}; the codes of bytes 0,1 / 2,3 of a dword fold into its bytes 0 / 2 with one shift-or.
 __global__ __launch_bounds__(256) void k_pack_fp4(const int8_t* __restrict__ in, long rows, long ld_in, uint8_t* __restrict__ out, long ld4) {
     const long row = blockIdx.y;
-    const long b = (long)blockIdx.x * 256 + threadIdx.x;
-    if (b >= ld4) return;
-    const int m0 = in[row * ld_in + 2 * b], m1 = in[row * ld_in + 2 * b + 1];
-    const unsigned c0 = m0 == 0 ? 0u : (m0 > 0 ? 0x2u : 0xAu), c1 = m1 == 0 ? 0u : (m1 > 0 ? 0x2u : 0xAu);
-    out[row * ld4 + b] = (uint8_t)(c0 | (c1 << 4));
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;  // group of 16 genotypes
+    if (g * 8 >= ld4) return;
+    const i32x4 x = *(const i32x4*)(in + row * ld_in + g * 16);
+    unsigned h[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const unsigned u = (unsigned)x[i];
+        const unsigned c = ((u & 0x01010101u) << 1) | ((u & 0x80808080u) >> 4);
+        const unsigned t = c | (c >> 4);
+        h[i] = (t & 0xffu) | ((t >> 8) & 0xff00u);
+    }
+    i32x2 o;
+    o[0] = (int)(h[0] | (h[1] << 16));
+    o[1] = (int)(h[2] | (h[3] << 16));
+    *(i32x2*)(out + row * ld4 + g * 8) = o;
 }
 extern "C" int eagle_dev_pack_fp4(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, void* Mt4, void* stream) {
     if (n_pad % T8 || ld % 16 || n_pad > ld) return eagle_fail(ctx, EAGLE_ERR_ARG, "pack_fp4: layout contract violated");
     if (L_pad <= 0) return EAGLE_OK;
     for (long r0 = 0; r0 < L_pad; r0 += 65535) {
         const long nr = L_pad - r0 < 65535 ? L_pad - r0 : 65535;
-        dim3 grid((unsigned)((n_pad / 2 + 255) / 256), (unsigned)nr);
+        dim3 grid((unsigned)((n_pad / 16 + 255) / 256), (unsigned)nr);
         hipLaunchKernelGGL(k_pack_fp4, grid, dim3(256), 0, (hipStream_t)stream, Mt8 + r0 * ld, nr, ld, (uint8_t*)Mt4 + r0 * (n_pad / 2), n_pad / 2);
     }
     hipError_t e = hipGetLastError();

@@ -11,7 +11,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 OPS=/tmp/eagle_bench_operands.pt
 ARGS="$ROOT/bench.py --cpu-sample 0 --steps 3 --warmup 1 --load-operands $OPS $@"
-KF="--kernel-include-regex k_vara_i8|k_syrk_i8|k_gemm_f64|k_gemv|k_mmt_finish|k_slice_w"
+KF="--kernel-include-regex k_vara_i8|k_syrk_f4|k_gemm_f64|k_gemv|k_mmt_finish|k_slice_w|k_pack_fp4"
 echo "== stats pass"; 
 # the stats pass profiles the default bench command itself (model-algebra operands; only the CPU sample is skipped)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $ROOT/bench.py --cpu-sample 0 --save-operands $OPS "$@" > $OUT/stats.log 2>&1 || { tail -5 $OUT/stats.log; exit 1; }
