@@ -308,7 +308,8 @@ def main():
                                    "single trait, full calculate_a_and_vara pass + tsq arg-max" % (n, Lloc),
                        "n": n, "markers_per_gpu": Lloc, "markers_total": Ltot,
                        "parallelism": "marker-shard x%d" % world + (" (REHEARSAL: gloo, ranks share one card)" if backend == "gloo" and world > 1 else ""),
-                       "scan_mode": args.mode, "slices": S_used, "vara_abs_error_bound": vara_bound, "operands": "simple" if args.simple_operands else "model algebra on MM^T" + (" (reloaded)" if args.load_operands else "")},
+                       "scan_mode": args.mode, "slices": S_used, "vara_abs_error_bound": vara_bound,
+                       "vara_rel_error_bound": (vara_bound / (0.5 * sh.last_sumdiag) if sh.mode else None), "operands": "simple" if args.simple_operands else "model algebra on MM^T" + (" (reloaded)" if args.load_operands else "")},
             "mmt_build_s": mmt_build_s, "selected_marker": int(sel[0]), "tsqmax": sel[1],
             "roofline": roof, "roofline_secondary": secondary, "cpu_baseline": cpu, "parity": parity,
             "device": info, "setup_s": {"genotypes": t_gen, "operands": t_ops},

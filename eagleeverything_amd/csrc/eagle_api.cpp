@@ -117,7 +117,7 @@ extern "C" eagle_ctx* eagle_open(int device) {
 extern "C" void eagle_drop_cache(eagle_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    for (auto& g : ctx->cache) if (g.dev) (void)hipFree(g.dev);
+    for (auto& g : ctx->cache) { if (g.dev) (void)hipFree(g.dev); if (g.dev_s) (void)hipFree(g.dev_s); if (g.cshift) (void)hipFree(g.cshift); }
     ctx->cache.clear();
     if (ctx->f4_buf) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->f4_buf); ctx->f4_buf = nullptr; ctx->f4_cap = 0; }
 }
@@ -495,7 +495,12 @@ const GenoEntry* eagle_cache_find(eagle_ctx* ctx, const char* path, long rows, l
 }
 static void cache_drop_path(eagle_ctx* ctx, const char* path) {
     for (size_t i = 0; i < ctx->cache.size();)
-        if (ctx->cache[i].path == path) { (void)hipFree(ctx->cache[i].dev); ctx->cache.erase(ctx->cache.begin() + i); } else i++;
+        if (ctx->cache[i].path == path) {
+            (void)hipFree(ctx->cache[i].dev);
+            if (ctx->cache[i].dev_s) (void)hipFree(ctx->cache[i].dev_s);
+            if (ctx->cache[i].cshift) (void)hipFree(ctx->cache[i].cshift);
+            ctx->cache.erase(ctx->cache.begin() + i);
+        } else i++;
 }
 int eagle_cache_adopt(eagle_ctx* ctx, const char* path, long rows, long cols, long rows_pad, long ld, int8_t* dev) {
     cache_drop_path(ctx, path);
@@ -760,7 +765,7 @@ extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_asc
     }
     const long np = eagle_pad(n), Lp = eagle_pad(L);
     const size_t sq = sizeof(double) * (size_t)np * np;
-    const bool use_i8 = ctx->scan_mode == 1 && 64.0 * 128.0 * (double)np < 2147483648.0;
+    const bool use_i8 = ctx->scan_mode == 1 && 64.0 * 512.0 * (double)np < 2147483648.0;
     const int nslices = ctx->scan_slices;
     GenoEntry* g = nullptr;
     rc = get_resident(ctx, f_name_ascii, L, n, max_memory_in_Gbytes, host_threads(), &g,
@@ -772,7 +777,7 @@ extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_asc
     const size_t wsb = use_i8 ? (size_t)eagle_vara_i8_workspace_bytes(np, Lc, nslices) : 0;
     const double t0 = now_s();
     if ((rc = arena_reserve(ctx, 4 * arena_round(sq) + 2 * arena_round(sizeof(double) * np) + arena_round(wsb) +
-                                     (streamed ? 2 * arena_round((size_t)Lc * np) : 0))))
+                                     (streamed ? (use_i8 ? 4 : 2) * arena_round((size_t)Lc * np) + 2 * arena_round((size_t)Lc) : 0))))
         return rc;
     double* Sa = arena_take<double>(ctx, sq);
     double* Va = arena_take<double>(ctx, sq);
@@ -782,10 +787,16 @@ extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_asc
     double* v = arena_take<double>(ctx, sizeof(double) * np);
     void* ws = arena_take<char>(ctx, wsb);
     ChunkRing ring;
+    int8_t* shifted[2] = {nullptr, nullptr};
+    int8_t* cs[2] = {nullptr, nullptr};
     if (streamed) {
         if ((rc = ring.init(ctx))) return rc;
         ring.buf[0] = arena_take<int8_t>(ctx, (size_t)Lc * np);
         ring.buf[1] = arena_take<int8_t>(ctx, (size_t)Lc * np);
+        for (int b = 0; b < 2 && use_i8; b++) {
+            shifted[b] = arena_take<int8_t>(ctx, (size_t)Lc * np);
+            cs[b] = arena_take<int8_t>(ctx, (size_t)Lc);
+        }
     }
     if ((rc = upload_square(ctx, inv_MMt_sqrt, n, np, Sa))) return rc;
     if ((rc = upload_square(ctx, dim_reduced_vara, n, np, Va))) return rc;
@@ -808,10 +819,27 @@ extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_asc
             Mt8 = tile;
         }
         if (use_i8) {
+            // re-centred image of the markers (kept with a resident file, rebuilt per chunk when streaming)
+            const int8_t* Ms = nullptr;
+            const int8_t* cv = nullptr;
+            if (streamed) {
+                const int b = (int)(ring.k & 1);
+                rc = eagle_dev_marker_shift(ctx, Mt8, nrp, n, np, ldm, shifted[b], cs[b], ctx->stream);
+                if (rc) return rc;
+                Ms = shifted[b]; cv = cs[b];
+            } else {
+                if (!g->dev_s) {
+                    HIPCHK(ctx, hipMalloc((void**)&g->dev_s, (size_t)g->rows_pad * g->ld));
+                    HIPCHK(ctx, hipMalloc((void**)&g->cshift, (size_t)g->rows_pad));
+                    rc = eagle_dev_marker_shift(ctx, g->dev, g->rows_pad, n, np, g->ld, g->dev_s, g->cshift, ctx->stream);
+                    if (rc) return rc;
+                }
+                Ms = g->dev_s; cv = g->cshift;
+            }
             // one pass over the genotypes gives a = Mt v and the diagonal term of vara; then the int8 MFMA kernel
             rc = eagle_dev_vara_i8_prepare(ctx, Mt8, nrp, np, ldm, Wu, nslices, ws, v, ctx->d_a + r0, ctx->stream);
             if (rc) return rc;
-            rc = eagle_dev_vara_i8_mfma(ctx, Mt8, nrp, np, ldm, nslices, ws, ctx->d_vara + r0, nullptr, ctx->stream);
+            rc = eagle_dev_vara_i8_mfma_shifted(ctx, Ms, cv, nrp, np, ldm, nslices, ws, ctx->d_vara + r0, nullptr, ctx->stream);
         } else {
             rc = eagle_dev_gemv_i8(ctx, Mt8, nrp, np, ldm, v, 1.0, ctx->d_a + r0, ctx->stream);
             if (rc) return rc;

@@ -23,6 +23,8 @@ struct GenoEntry {
     long rows = 0, cols = 0;          // logical tile held: all `rows` lines, first `cols` characters
     long rows_pad = 0, ld = 0;
     int8_t* dev = nullptr;
+    int8_t* dev_s = nullptr;    // re-centred image m - c_i (eagle_dev_marker_shift), made on the first digit-slice scan of the file
+    int8_t* cshift = nullptr;   // c_i per row
 };
 
 struct eagle_ctx {

@@ -282,6 +282,7 @@ struct VaraHdr {        // head of the workspace, written on the device, never r
     int pad;
     double bound;       // n_pad^2 * 2^(e+1-8S): absolute error bound of every vara_i
     double sumdiag;     // sum_k |Wu[k][k]|
+    double R;           // sum_{j<k} Wu[j][k] (the off-diagonal quadratic form of the all-ones vector)
 };
 
 __global__ __launch_bounds__(256) void k_absmax_offdiag(const double* __restrict__ x, long np, unsigned long long* __restrict__ bits) {
@@ -297,9 +298,17 @@ __global__ __launch_bounds__(256) void k_absmax_offdiag(const double* __restrict
     if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(bits, (unsigned long long)__double_as_longlong(m));
 }
 
-// One block: dW[k] = Wu[k][k] (contiguous copy), sumdiag in a fixed order, then the slice count.
-// forced = 0: smallest S in 3..7 whose bound n^2 * 2^(e+1-8S) is below 1e-9 of the typical vara, taken as
-// 0.5 * sum_k |W_kk| (the diagonal term of a marker with half of its genotypes non-zero); forced = 1..8: that S.
+// Digit-count rule (forced = 0).  The path's stated tolerance is 1e-6 relative on the score statistics; the digits get a
+// tenth of it: the smallest S whose WORST-CASE bound n^2 * 2^(e+1-8S) -- every truncation error aligned, a marker with n
+// non-zero entries -- is below 1e-7 of 0.5 * sum_k |W_kk|, the diagonal term of a marker with n/2 non-zero entries.
+// Per marker the bound is (sum_j |m'_ij|)^2 / 2 * 2^(e+1-8S) on the RE-CENTRED genotypes m' (k_marker_shift below), so it
+// scales with the square of the marker's non-majority count while its quadratic form scales with the count itself:
+// rare-variant markers, whose vara is far below the diagonal term of the raw g-1 coding, keep the same relative bound,
+// and monomorphic markers (vara = 0 up to fp64 noise in the reference too) take no digit error at all.
+// Measured errors sit three orders below the bound (C2, S = 4: bound 1.7e-8, largest error against an fp64 evaluation
+// 1.5e-11).  eagle_set_scan_slices forces more digits.
+#define VARA_DIGIT_BUDGET 1e-7
+// One block: dW[k] = Wu[k][k] (contiguous copy), sumdiag in a fixed order, then the slice count (forced = 1..8: that S).
 __global__ __launch_bounds__(256) void k_vara_prep(const double* __restrict__ Wu, long n_pad, int forced, VaraHdr* __restrict__ hdr,
                                                    double* __restrict__ dW) {
     double s = 0.0;
@@ -322,7 +331,7 @@ __global__ __launch_bounds__(256) void k_vara_prep(const double* __restrict__ Wu
         const double nn = (double)n_pad * (double)n_pad;
         int S = forced;
         if (S <= 0) {
-            const double target = 1e-9 * 0.5 * red[0];
+            const double target = VARA_DIGIT_BUDGET * 0.5 * red[0];
             S = 7;
             for (int c = 3; c <= 7; c++)
                 if (ldexp(nn, e + 1 - 8 * c) <= target) { S = c; break; }
@@ -358,6 +367,110 @@ __global__ __launch_bounds__(256) void k_slice_w(const double* __restrict__ Wu, 
             Bs[(long)s * np * np + (bk + r) * np + bj + tx] = (int8_t)d;
         }
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Marker re-centring.  The truncation of W to S digits costs every vara_i at most (sum_j |m_ij|)^2 times the last-digit
+// weight -- harmless next to the diagonal term of a marker with many non-zero genotypes, but a rare-variant marker is
+// almost the constant vector c (c = -1 in the g-1 coding), W annihilates constants when the model has an intercept, and
+// its true vara is far below its diagonal term.  So the digit kernel is fed m' = m - c_i 1 (c_i = the marker's majority
+// genotype, over the n real individuals only): rare variants become sparse rows, monomorphic ones vanish, and
+//   sum_{j<k} m_j m_k Wu_jk  =  sum_{j<k} m'_j m'_k Wu_jk  +  c_i (m^T rho)  -  c_i^2 R,
+//   rho_j = sum_{k>j} Wu_jk + sum_{k<j} Wu_kj,   R = sum_{j<k} Wu_jk = (1/2) sum_j rho_j,
+// with the two correction terms in fp64 (m^T rho is one more column of the genotype pass).  The digit error of marker i
+// is then bounded by (sum_j |m'_ij|)^2 / 2 * 2^(e+1-8S): it shrinks with the marker's own diagonal term.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_marker_shift(const int8_t* __restrict__ Mt8, long L_pad, int n, long ld, int8_t* __restrict__ Mt8s,
+                                                      int8_t* __restrict__ cshift) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per marker
+    if (row >= L_pad) return;
+    const int8_t* src = Mt8 + row * ld;
+    int neg = 0, pos = 0;
+    for (int j = lane * 16; j < n; j += 64 * 16) {
+        const i32x4 x = *(const i32x4*)(src + j);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const unsigned u = (unsigned)x[q];
+            // bytes are 0x00, 0x01, 0xFF; bytes at j >= n inside the last 16-byte group are padding zeros
+            neg += __builtin_popcount(u & 0x80808080u);
+            pos += __builtin_popcount(u & ~(u >> 7) & 0x01010101u);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { neg += __shfl_xor(neg, o); pos += __shfl_xor(pos, o); }
+    const int zer = n - neg - pos;
+    int c = 0;  // ties go to 0, then to -1: any fixed rule will do
+    if (neg > zer && neg >= pos) c = -1;
+    else if (pos > zer && pos > neg) c = 1;
+    if (lane == 0) cshift[row] = (int8_t)c;
+    int8_t* dst = Mt8s + row * ld;
+    for (int j = lane * 16; j < (int)ld; j += 64 * 16) {
+        i32x4 x = {0, 0, 0, 0};
+        if (j < n) {
+            x = *(const i32x4*)(src + j);
+            if (c != 0) {
+                union { i32x4 v; int8_t b[16]; } u;
+                u.v = x;
+#pragma unroll
+                for (int q = 0; q < 16; q++) u.b[q] = (j + q < n) ? (int8_t)(u.b[q] - c) : (int8_t)0;
+                x = u.v;
+            }
+        }
+        *(i32x4*)(dst + j) = x;
+    }
+}
+extern "C" int eagle_dev_marker_shift(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n, long n_pad, long ld, int8_t* Mt8s,
+                                      int8_t* cshift, void* stream) {
+    if (ld % 16 || n > n_pad || n_pad > ld || n <= 0) return eagle_fail(ctx, EAGLE_ERR_ARG, "marker_shift: layout contract violated");
+    if (L_pad <= 0) return EAGLE_OK;
+    hipLaunchKernelGGL(k_marker_shift, dim3((unsigned)((L_pad + 3) / 4)), dim3(256), 0, (hipStream_t)stream, Mt8, L_pad, (int)n, ld, Mt8s, cshift);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "k_marker_shift");
+    return EAGLE_OK;
+}
+
+// rowpart[j] = sum_{k>j} Wu[j][k] (one block per row, fixed tree order)
+__global__ __launch_bounds__(256) void k_rho_rows(const double* __restrict__ Wu, long np, double* __restrict__ rho) {
+    const long j = blockIdx.x;
+    double s = 0.0;
+    for (long k = j + 1 + threadIdx.x; k < np; k += 256) s += Wu[j * np + k];
+    __shared__ double red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) rho[j] = red[0];
+}
+// colpart[by][j] = sum over the 256 rows k of chunk `by` with k < j of Wu[k][j] (coalesced across the columns of a block)
+__global__ __launch_bounds__(256) void k_rho_cols(const double* __restrict__ Wu, long np, double* __restrict__ colpart) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x, k0 = (long)blockIdx.y * 256;
+    double s = 0.0;
+    if (k0 < j)
+        for (long k = k0; k < k0 + 256 && k < j; k++) s += Wu[k * np + j];
+    colpart[(long)blockIdx.y * np + j] = s;
+}
+// rho[j] += sum_by colpart[by][j];  R = (1/2) sum_j rho_j  (one block, fixed order)
+__global__ __launch_bounds__(1024) void k_rho_final(const double* __restrict__ colpart, long np, double* __restrict__ rho, VaraHdr* __restrict__ hdr) {
+    const int nchunk = (int)(np / 256);
+    double tot = 0.0;
+    for (long j = threadIdx.x; j < np; j += 1024) {
+        double s = rho[j];
+        for (int b = 0; b < nchunk; b++) s += colpart[(long)b * np + j];
+        rho[j] = s;
+        tot += s;
+    }
+    __shared__ double red[1024];
+    red[threadIdx.x] = tot;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) hdr->R = 0.5 * red[0];
 }
 
 struct VaraIt {  // position in a worker's flattened stage sequence: pair p, half (tile p, then tile nct-1-p), stage kt
@@ -471,7 +584,8 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8(const int8_t* __restrict__ M
 }
 
 __global__ __launch_bounds__(256) void k_vara_i8_finish(const long long* __restrict__ q, long Lp, const VaraHdr* __restrict__ hdr,
-                                                        const double* __restrict__ vdiag, double* __restrict__ vara) {
+                                                        const double* __restrict__ vdiag, const int8_t* __restrict__ cshift,
+                                                        const double* __restrict__ mrho, double* __restrict__ vara) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= Lp) return;
     int e = 0;
@@ -480,6 +594,8 @@ __global__ __launch_bounds__(256) void k_vara_i8_finish(const long long* __restr
     if (mx > 0.0) (void)frexp(mx, &e);
     double s = 0.0;
     for (int k = nslices - 1; k >= 0; k--) s += ldexp((double)q[(long)k * Lp + i], e + 2 - 8 * (k + 1));  // smallest first
+    const double c = cshift ? (double)cshift[i] : 0.0;  // re-centred marker: off(m) = off(m') + c m^T rho - c^2 R
+    if (c != 0.0) s += c * mrho[i] - c * c * hdr->R;
     vara[i] = vdiag[i] + s;  // diagonal term sum_k m_ik^2 W_kk (fp64) + exact-integer off-diagonal term
 }
 
@@ -488,13 +604,19 @@ __global__ void k_vara_i8_bound(const VaraHdr* __restrict__ hdr, double* __restr
     if (slices_out) *slices_out = hdr->S;
 }
 
-// workspace: [ VaraHdr (padded to 256) | q: Smax*L_pad int64 | dW: n_pad f64 | vdiag: L_pad f64 | Bs: Smax*n_pad*n_pad int8 ]
+// workspace: [ VaraHdr (padded to 256) | q: Smax*L_pad int64 | dW: n_pad f64 | vdiag: L_pad f64 | mrho: L_pad f64 | rho: n_pad f64 |
+//              column partials of rho: (n_pad/256 + 1) * n_pad f64 | Bs: Smax*n_pad*n_pad int8 ]
 #define VARA_SMAX_AUTO 7
 static int ws_smax(int nslices) { return nslices > 0 ? nslices : VARA_SMAX_AUTO; }
 static size_t ws_q_off() { return 256; }
 static size_t ws_dw_off(long L_pad, int smax) { return 256 + (size_t)smax * L_pad * 8; }
 static size_t ws_vd_off(long n_pad, long L_pad, int smax) { return ws_dw_off(L_pad, smax) + (size_t)n_pad * 8; }
-static size_t ws_bs_off(long n_pad, long L_pad, int smax) { return (ws_vd_off(n_pad, L_pad, smax) + (size_t)L_pad * 8 + 255) / 256 * 256; }
+static size_t ws_mr_off(long n_pad, long L_pad, int smax) { return ws_vd_off(n_pad, L_pad, smax) + (size_t)L_pad * 8; }           // m^T rho, L_pad f64
+static size_t ws_rho_off(long n_pad, long L_pad, int smax) { return ws_mr_off(n_pad, L_pad, smax) + (size_t)L_pad * 8; }          // rho, n_pad f64
+static size_t ws_cp_off(long n_pad, long L_pad, int smax) { return ws_rho_off(n_pad, L_pad, smax) + (size_t)n_pad * 8; }          // column partials
+static size_t ws_bs_off(long n_pad, long L_pad, int smax) {
+    return (ws_cp_off(n_pad, L_pad, smax) + (size_t)n_pad * (size_t)(n_pad / T8 + 1) * 8 + 255) / 256 * 256;
+}
 
 extern "C" int64_t eagle_vara_i8_workspace_bytes(long n_pad, long L_pad, int nslices) {
     const int smax = ws_smax(nslices);
@@ -504,8 +626,8 @@ extern "C" int64_t eagle_vara_i8_workspace_bytes(long n_pad, long L_pad, int nsl
 static int vara_i8_check(eagle_ctx* ctx, long L_pad, long n_pad, long ld, int nslices) {
     if (L_pad % T8 || n_pad % T8 || ld % 128 || n_pad > ld || nslices < 0 || nslices > 8 || (double)ld * T8 >= 2147483648.0)
         return eagle_fail(ctx, EAGLE_ERR_ARG, "vara_i8: layout contract violated (L_pad % 256, n_pad % 256, 0 <= nslices <= 8)");
-    // int32 tile row-sum: 64 columns per wave x |T*m| <= 128*n_pad each (accumulation across tiles is int64)
-    if (64.0 * 128.0 * (double)n_pad >= 2147483648.0)
+    // int32 tile row-sum: 64 columns per wave x |T*m'| <= 2*2*128*n_pad each, |m'| <= 2 (accumulation across tiles is int64)
+    if (64.0 * 512.0 * (double)n_pad >= 2147483648.0)
         return eagle_fail(ctx, EAGLE_ERR_ARG, "vara_i8: n too large for the int32 per-slice partial sums; use the fp64 kernel");
     return EAGLE_OK;
 }
@@ -530,6 +652,15 @@ extern "C" int eagle_dev_vara_i8_prepare(eagle_ctx* ctx, const int8_t* Mt8, long
     // one pass over the genotypes: a = Mt8 v (if asked for) and the diagonal term (a NULL a_out drops the a half)
     rc = eagle_dev_gemv2_i8(ctx, Mt8, L_pad, n_pad, ld, v ? v : dW, dW, 1.0, v ? a_out : nullptr, vdiag, stream);
     if (rc) return rc;
+    // correction terms of the re-centred markers: rho, R, and m^T rho for every marker (one more genotype pass)
+    double* mrho = (double*)((char*)ws + ws_mr_off(n_pad, L_pad, smax));
+    double* rho = (double*)((char*)ws + ws_rho_off(n_pad, L_pad, smax));
+    double* colpart = (double*)((char*)ws + ws_cp_off(n_pad, L_pad, smax));
+    hipLaunchKernelGGL(k_rho_rows, dim3((unsigned)n_pad), dim3(256), 0, s, Wu, n_pad, rho);
+    hipLaunchKernelGGL(k_rho_cols, dim3((unsigned)(n_pad / 256), (unsigned)(n_pad / 256)), dim3(256), 0, s, Wu, n_pad, colpart);
+    hipLaunchKernelGGL(k_rho_final, dim3(1), dim3(1024), 0, s, colpart, n_pad, rho, hdr);
+    rc = eagle_dev_gemv_i8(ctx, Mt8, L_pad, n_pad, ld, rho, 1.0, mrho, stream);
+    if (rc) return rc;
     dim3 g2((unsigned)(n_pad / 32), (unsigned)(n_pad / 32));
     hipLaunchKernelGGL(k_slice_w, g2, dim3(256), 0, s, Wu, n_pad, hdr, Bs);
     e = hipGetLastError();
@@ -538,8 +669,10 @@ extern "C" int eagle_dev_vara_i8_prepare(eagle_ctx* ctx, const int8_t* Mt8, long
 }
 
 // Phase 2: the int8 MFMA kernel over all (marker tile, slice) workers + the S-term finish.
-extern "C" int eagle_dev_vara_i8_mfma(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, int nslices, void* ws,
-                                      double* vara_out, double* err_bound_dev, void* stream) {
+// Mt8s / cshift: the re-centred genotype image and the per-marker shifts of eagle_dev_marker_shift (prepare ran on the
+// original image); cshift == NULL: Mt8s is the original image and no correction applies.
+extern "C" int eagle_dev_vara_i8_mfma_shifted(eagle_ctx* ctx, const int8_t* Mt8s, const int8_t* cshift, long L_pad, long n_pad, long ld,
+                                              int nslices, void* ws, double* vara_out, double* err_bound_dev, void* stream) {
     int rc = vara_i8_check(ctx, L_pad, n_pad, ld, nslices);
     if (rc) return rc;
     if (L_pad == 0) return EAGLE_OK;
@@ -548,15 +681,20 @@ extern "C" int eagle_dev_vara_i8_mfma(eagle_ctx* ctx, const int8_t* Mt8, long L_
     VaraHdr* hdr = (VaraHdr*)ws;
     long long* q = (long long*)((char*)ws + ws_q_off());
     double* vdiag = (double*)((char*)ws + ws_vd_off(n_pad, L_pad, smax));
+    double* mrho = (double*)((char*)ws + ws_mr_off(n_pad, L_pad, smax));
     int8_t* Bs = (int8_t*)((char*)ws + ws_bs_off(n_pad, L_pad, smax));
     const int ntm = (int)(L_pad / T8);
     const int groups = (ntm + 7) / 8;
-    hipLaunchKernelGGL(k_vara_i8, dim3((unsigned)(groups * 8 * smax)), dim3(512), 0, s, Mt8, ld, ntm, Bs, n_pad, hdr, q, L_pad);
-    hipLaunchKernelGGL(k_vara_i8_finish, dim3((unsigned)((L_pad + 255) / 256)), dim3(256), 0, s, q, L_pad, hdr, vdiag, vara_out);
+    hipLaunchKernelGGL(k_vara_i8, dim3((unsigned)(groups * 8 * smax)), dim3(512), 0, s, Mt8s, ld, ntm, Bs, n_pad, hdr, q, L_pad);
+    hipLaunchKernelGGL(k_vara_i8_finish, dim3((unsigned)((L_pad + 255) / 256)), dim3(256), 0, s, q, L_pad, hdr, vdiag, cshift, mrho, vara_out);
     if (err_bound_dev) hipLaunchKernelGGL(k_vara_i8_bound, dim3(1), dim3(1), 0, s, hdr, err_bound_dev, (int*)nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "vara_i8_mfma");
     return EAGLE_OK;
+}
+extern "C" int eagle_dev_vara_i8_mfma(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, int nslices, void* ws,
+                                      double* vara_out, double* err_bound_dev, void* stream) {
+    return eagle_dev_vara_i8_mfma_shifted(ctx, Mt8, nullptr, L_pad, n_pad, ld, nslices, ws, vara_out, err_bound_dev, stream);
 }
 
 extern "C" int eagle_dev_vara_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu,
@@ -652,7 +790,7 @@ __global__ __launch_bounds__(256) void k_vara_prep6(const double* __restrict__ W
         const double nn = (double)n_pad * (double)n_pad;
         int S = forced;
         if (S <= 0) {
-            const double target = 1e-9 * 0.5 * red[0];
+            const double target = VARA_DIGIT_BUDGET * 0.5 * red[0];
             S = VARA6_SMAX_AUTO;
             for (int c = 4; c <= VARA6_SMAX_AUTO; c++)
                 if (ldexp(nn, e - 5 * c) <= target) { S = c; break; }

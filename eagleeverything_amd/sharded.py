@@ -108,6 +108,7 @@ class DeviceShard:
         self.ws = None
         self._ws_mode = None
         self.Mt4 = None
+        self.Mt8s = self.cshift = None
         self.mode = 0
         self.nslices = 0  # 0 = chosen by the library from its error bound
 
@@ -232,6 +233,15 @@ class DeviceShard:
             self._ws_mode = self.mode
         return self.ws
 
+    def shifted_image(self):
+        """(Mt8s, cshift): the markers re-centred on their majority genotype, made once per shard for the digit-slice kernel."""
+        if self.Mt8s is None:
+            self.Mt8s = self.torch.empty_like(self.Mt8)
+            self.cshift = self.torch.empty(self.Lp, dtype=self.torch.int8, device=self.dev)
+            self._check(self.L.eagle_dev_marker_shift(self.ctx, self.Mt8.data_ptr(), self.Lp, self.n, self.np_, self.np_,
+                                                      self.Mt8s.data_ptr(), self.cshift.data_ptr(), self._stream()))
+        return self.Mt8s, self.cshift
+
     def fp4_image(self):
         """Mt4: the genotypes as fp4 (two per byte), made once per shard for the fp4 x fp6 vara kernel (mode 2)."""
         if self.Mt4 is None:
@@ -258,12 +268,15 @@ class DeviceShard:
                                                       self.np_, self.nslices, self._ws().data_ptr(), self.vara.data_ptr(), None,
                                                       self._stream()))
         else:
-            self._check(self.L.eagle_dev_vara_i8_mfma(self.ctx, self.Mt8.data_ptr(), self.Lp, self.np_, self.np_, self.nslices,
-                                                      self._ws().data_ptr(), self.vara.data_ptr(), None, self._stream()))
+            Ms, cs = self.shifted_image()
+            self._check(self.L.eagle_dev_vara_i8_mfma_shifted(self.ctx, Ms.data_ptr(), cs.data_ptr(), self.Lp, self.np_, self.np_,
+                                                              self.nslices, self._ws().data_ptr(), self.vara.data_ptr(), None,
+                                                              self._stream()))
 
     def vara_i8_info(self):
         """(slices used, absolute error bound, max |off-diagonal W|) of the last int8-slice vara launch (synchronises)."""
         h = self.ws[:32].cpu().numpy().tobytes()
+        self.last_sumdiag = float(np.frombuffer(h[24:32], dtype=np.float64)[0])  # sum_k |W_kk|
         return (int(np.frombuffer(h[8:12], dtype=np.int32)[0]), float(np.frombuffer(h[16:24], dtype=np.float64)[0]),
                 float(np.frombuffer(h[0:8], dtype=np.float64)[0]))
 

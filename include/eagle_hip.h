@@ -59,7 +59,9 @@ int eagle_device_info(eagle_ctx* ctx, char* arch_out, int arch_len, int* cu_coun
 /* vara kernel: 1 (default) = exact int8 digit slices of W on v_mfma_i32_32x32x32_i8, 0 = fp64 MFMA
  * (v_mfma_f64_16x16x4_f64; also taken automatically when n is too large for the int32 tile sums).
  * eagle_set_scan_slices: S = 1..8 base-256 digits of the off-diagonal part of W, or 0 (default) = chosen per call:
- * the smallest S in 3..7 whose bound is below 1e-9 of the typical vara (0.5 * sum_k |W_kk|).  The diagonal term
+ * the smallest S in 3..7 whose worst-case bound is below 1e-7 of 0.5 * sum_k |W_kk| -- a tenth of the 1e-6 relative
+ * tolerance of this path, relative to the smallest diagonal term a marker can have (at least half of its genotypes are
+ * non-zero in the g-1 coding); measured errors are ~1000x below the bound.  The diagonal term
  * sum_k m_ik^2 W_kk is evaluated in fp64; every vara_i then differs from the exact m_i^T W m_i by at most
  * (sum_j |m_ij|)^2 * 2^(e+1-8S), max_{j!=k} |W_jk + W_kj| < 2^e, plus fp64 rounding of an n-term and an S-term sum. */
 int eagle_set_scan_mode(eagle_ctx* ctx, int mode);
@@ -240,12 +242,21 @@ int eagle_dev_vara_i8_prepare(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, lon
                               int nslices, void* ws, const double* v, double* a_out, void* stream);
 int eagle_dev_vara_i8_mfma(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, int nslices, void* ws,
                            double* vara_out, double* err_bound_dev, void* stream);
+/* Re-centred markers for the digit-slice kernel: Mt8s[i][j] = Mt8[i][j] - c_i for the n real individuals (padding stays
+ * zero), c_i in {-1,0,+1} = the majority genotype of marker i, cshift[i] = c_i.  eagle_dev_vara_i8_mfma_shifted runs
+ * the MFMA kernel on Mt8s (rare-variant markers become sparse rows, so their truncation error bound
+ * (sum_j |m'_ij|)^2 / 2 * 2^(e+1-8S) shrinks with their own diagonal term) and adds c_i m_i^T rho - c_i^2 R in fp64;
+ * prepare (always on the ORIGINAL image) has left rho, R and m^T rho in the workspace. */
+int eagle_dev_marker_shift(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n, long n_pad, long ld, int8_t* Mt8s,
+                           int8_t* cshift, void* stream);
+int eagle_dev_vara_i8_mfma_shifted(eagle_ctx* ctx, const int8_t* Mt8s, const int8_t* cshift, long L_pad, long n_pad, long ld,
+                                   int nslices, void* ws, double* vara_out, double* err_bound_dev, void* stream);
 int eagle_dev_vara_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu,
                       int nslices, void* ws, double* vara_out, double* err_bound_dev, void* stream);
 /* The same quadratic form on the block-scaled matrix path (v_mfma_scale_f32_32x32x64_f8f6f4): genotypes as fp4, balanced
  * base-33 digits of Wu as fp6 (every integer in [-16,16] is an e2m3 number / 8), exact fp32 sums, twice the MAC rate of
  * the int8 instruction.  Mt4: [L_pad][n_pad/2] bytes made once per genotype matrix by eagle_dev_pack_fp4 (two genotypes
- * per byte).  nslices: 0 = automatic (same 1e-9 criterion), 1..12 = fixed; absolute error bound n_pad^2 * 2^(e-5S).
+ * per byte).  nslices: 0 = automatic (same 1e-7 worst-case criterion), 1..12 = fixed; absolute error bound n_pad^2 * 2^(e-5S).
  * The workspace head has the layout of the int8 one ({max|offdiag|; S; f; bound; sum|diag|}). */
 int64_t eagle_vara_f6_workspace_bytes(long n_pad, long L_pad, int nslices);
 int eagle_dev_pack_fp4(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, void* Mt4, void* stream);

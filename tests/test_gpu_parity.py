@@ -13,7 +13,9 @@ from eagleeverything_amd import synth
 
 pytestmark = pytest.mark.gpu
 NA = np.nan
-RTOL = 1e-9
+RTOL = 1e-9        # a, and vara from the fp64 MFMA kernel (mode 0)
+RTOL_DIGITS = 1e-7  # vara from the digit-slice kernels: the library's worst-case digit budget, a tenth of the 1e-6 relative
+                    # tolerance BASELINE.json's north_star states for the score statistics (measured errors are far smaller)
 
 
 @pytest.fixture(scope="module")
@@ -114,17 +116,18 @@ def test_scan_matches_oracle(case, mode, files, api, oracle, request):
     # markers that are constant over individuals have vara == 0 up to rounding noise (X holds the intercept):
     # an absolute floor of 1e-12 * max|vara| keeps those out of the relative comparison
     vs = np.abs(ref["vara"]).max()
-    np.testing.assert_allclose(res["vara"].ravel(), ref["vara"].ravel(), rtol=RTOL, atol=1e-12 * vs)
-    np.testing.assert_allclose(res["vara"].ravel(), g["vara"], rtol=RTOL, atol=1e-12 * vs)  # golden (numpy restatement)
+    rt = RTOL_DIGITS if mode == 1 else RTOL
+    np.testing.assert_allclose(res["vara"].ravel(), ref["vara"].ravel(), rtol=rt, atol=1e-12 * vs)
+    np.testing.assert_allclose(res["vara"].ravel(), g["vara"], rtol=rt, atol=1e-12 * vs)  # golden (numpy restatement)
     tsq_ref, idx_ref, mx_ref = oracle.tsq_argmax(ref["a"], ref["vara"])
     idx, mx, near = api.last_scan_argmax()
     assert idx == idx_ref == int(g["argmax"])
-    np.testing.assert_allclose(mx, mx_ref, rtol=1e-8)
+    np.testing.assert_allclose(mx, mx_ref, rtol=2 * rt)
     # identical marker columns (perfect LD) tie exactly; the first one is selected (find_qtl.R:80)
     assert near == int(np.sum(tsq_ref >= mx_ref * (1 - 1e-9)))
     # masked rows: a = vara = 0 there, tsq NaN there and ignored by the arg-max
     resm = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], g["sel_masked"], g["S"], g["V"], 8.0, (L, n), g["ahat"])
-    np.testing.assert_allclose(resm["vara"].ravel(), g["vara_masked"], rtol=RTOL, atol=1e-12 * vs)
+    np.testing.assert_allclose(resm["vara"].ravel(), g["vara_masked"], rtol=rt, atol=1e-12 * vs)
     for s in g["sel_masked"].astype(int):
         assert resm["a"][s, 0] == 0.0 and resm["vara"][s, 0] == 0.0
     idx, _, _ = api.last_scan_argmax()
@@ -219,7 +222,7 @@ def test_big_scan(big, api, oracle):
     res = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat)
     a_ref, v_ref = oracle.scan_from_i8(Mt8, S, V, ahat)
     _close(res["a"], a_ref)
-    np.testing.assert_allclose(res["vara"].ravel(), v_ref, rtol=RTOL)
+    np.testing.assert_allclose(res["vara"].ravel(), v_ref, rtol=RTOL_DIGITS)
     # second call hits the HBM-resident tile and is bit-identical (deterministic reduction order)
     res2 = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat)
     np.testing.assert_array_equal(res["a"], res2["a"])
@@ -255,11 +258,12 @@ def test_big_scan_int8_slices_match_fp64_kernel(big, api, oracle):
         assert np.all(np.abs(rs["vara"].ravel() - v_ref) <= bound + 1e-9 * np.abs(v_ref)), S_
     api.set_scan_slices(0)  # automatic choice must stay inside the tolerance by a wide margin
     ra = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat)
-    np.testing.assert_allclose(ra["vara"].ravel(), v_ref, rtol=1e-8)
+    np.testing.assert_allclose(ra["vara"].ravel(), v_ref, rtol=RTOL_DIGITS)
     api.set_scan_slices(0)
     np.testing.assert_array_equal(r1["vara"], r1b["vara"])  # integer atomics: bitwise reproducible
-    np.testing.assert_allclose(r1["vara"].ravel(), v_ref, rtol=RTOL)
-    np.testing.assert_allclose(r1["vara"].ravel(), r0["vara"].ravel(), rtol=RTOL)
+    np.testing.assert_allclose(r0["vara"].ravel(), v_ref, rtol=RTOL)
+    np.testing.assert_allclose(r1["vara"].ravel(), v_ref, rtol=RTOL_DIGITS)
+    np.testing.assert_allclose(r1["vara"].ravel(), r0["vara"].ravel(), rtol=RTOL_DIGITS)
     np.testing.assert_array_equal(r1["a"], r0["a"])
     _, idx_ref, _ = oracle.tsq_argmax(a_ref, v_ref)
     assert idx1 == idx_ref
@@ -279,7 +283,7 @@ def test_scan_nonsymmetric_operands(big, api, oracle, mode, request):
     a_ref, v_ref = oracle.scan_from_i8(Mt8[:4096], S2, V2, ahat)
     res = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S2, V2, 8.0, (L, n), ahat)
     _close(res["a"][:4096], a_ref)
-    np.testing.assert_allclose(res["vara"].ravel()[:4096], v_ref, rtol=1e-8)
+    np.testing.assert_allclose(res["vara"].ravel()[:4096], v_ref, rtol=RTOL_DIGITS)
 
 
 def test_streamed_paths_match_resident(big, api, oracle, monkeypatch):
@@ -340,7 +344,7 @@ def test_large_n_device_path(api, oracle):
         sh.scan()
         torch.cuda.synchronize()
         np.testing.assert_allclose(sh.a[:384].cpu().numpy(), a_ref, rtol=1e-9, atol=1e-12 * np.abs(a_ref).max())
-        np.testing.assert_allclose(sh.vara[:384].cpu().numpy(), v_ref, rtol=1e-9)
+        np.testing.assert_allclose(sh.vara[:384].cpu().numpy(), v_ref, rtol=RTOL_DIGITS if mode else RTOL)
     # MM^T: exact trace (sum of squares) and symmetry at this size
     c32 = sh.mmt_partial()
     MMt, mx = sh.mmt_finish(c32)
@@ -352,6 +356,55 @@ def test_large_n_device_path(api, oracle):
     ref_cols = Mt.double().T @ Mt[:, cols].double()
     assert torch.equal(MMt[:, cols], ref_cols)
     assert float(mx) == float(MMt.max())
+
+
+def test_vara_rare_variants_and_monomorphic_markers(api, oracle):
+    """Markers that are almost constant over the individuals, against a W that annihilates constants (a model with an
+    intercept): their vara is orders of magnitude below the diagonal term of the raw g-1 coding.  The digit-slice kernel
+    works on the re-centred genotypes, so the relative budget (1e-7) holds for them too, with the automatic digit count."""
+    import torch
+    from eagleeverything_amd.sharded import DeviceShard
+    n, L = 700, 4096
+    rng = np.random.default_rng(17)
+    maf = np.concatenate([np.zeros(64), rng.uniform(0.002, 0.02, 2048), rng.uniform(0.05, 0.5, L - 64 - 2048)])
+    g = rng.binomial(2, maf[:, None], size=(L, n)).astype(np.int8)
+    flip = rng.random(L) < 0.5           # half of the files code the common allele as 2
+    g[flip] = 2 - g[flip]
+    Mt8 = (g - 1).astype(np.int8)
+    sh = DeviceShard(n, L)
+    sh.Mt8.zero_()
+    sh.Mt8[:L, :n] = torch.from_numpy(Mt8).to(sh.dev)
+    A = rng.standard_normal((n, 40)) / 8.0
+    V0 = np.eye(n) + A @ A.T
+    P1 = np.eye(n) - np.ones((n, n)) / n
+    V = P1 @ V0 @ P1                     # V 1 = 0
+    S = 0.7 * np.eye(n)
+    ahat = rng.standard_normal(n)
+    sh.set_operands(S, V, ahat)
+    a_ref, v_ref = oracle.scan_from_i8(Mt8, S, V, ahat)
+    sh.mode = 1
+    sh.scan()
+    torch.cuda.synchronize()
+    used, bound, _ = sh.vara_i8_info()
+    vara = sh.vara[:L].cpu().numpy()
+    cs = sh.cshift[:L].cpu().numpy()
+    assert set(np.unique(cs)) == {-1, 0, 1}
+    typical = np.median(v_ref[maf > 0.05])
+    mono = (Mt8 == Mt8[:, :1]).all(axis=1)   # includes rare markers that drew no minor allele
+    assert mono.sum() >= 64
+    assert np.all(np.abs(vara[mono]) <= 1e-10 * typical) and np.all(np.abs(v_ref[mono]) <= 1e-10 * typical)
+    rare = (maf > 0) & (maf <= 0.02) & ~mono
+    assert v_ref[rare].max() < 0.2 * typical                       # far below the common markers
+    np.testing.assert_allclose(vara[~mono], v_ref[~mono], rtol=RTOL_DIGITS)
+    np.testing.assert_allclose(sh.a[:L].cpu().numpy(), a_ref, rtol=1e-9, atol=1e-12 * np.abs(a_ref).max())
+    # the same kernel on the raw coding (no re-centring) stays inside the absolute bound, but loses the rare markers' relative accuracy
+    sh.vara_prepare()                    # zeroes the integer accumulators again
+    sh._check(sh.L.eagle_dev_vara_i8_mfma(sh.ctx, sh.Mt8.data_ptr(), sh.Lp, sh.np_, sh.np_, sh.nslices, sh._ws().data_ptr(),
+                                          sh.vara.data_ptr(), None, sh._stream()))
+    torch.cuda.synchronize()
+    raw = sh.vara[:L].cpu().numpy()
+    assert np.abs(raw - v_ref).max() <= bound
+    assert np.abs(raw - v_ref)[rare].max() >= np.abs(vara - v_ref)[rare].max()
 
 
 def test_vara_fp4_fp6_engine(api, oracle):
@@ -374,7 +427,7 @@ def test_vara_fp4_fp6_engine(api, oracle):
     sh.scan()
     torch.cuda.synchronize()
     first = sh.vara[:L].cpu().numpy()
-    np.testing.assert_allclose(first, v_ref, rtol=1e-9)
+    np.testing.assert_allclose(first, v_ref, rtol=RTOL_DIGITS)
     np.testing.assert_allclose(sh.a[:L].cpu().numpy(), a_ref, rtol=1e-9, atol=1e-12 * np.abs(a_ref).max())
     sh.scan()
     torch.cuda.synchronize()
@@ -411,7 +464,7 @@ def test_config_C3_shape_single_gpu(api, oracle):
     Mt_s = sh.Mt8[rows][:, :n].cpu().numpy()
     a_ref, v_ref = oracle.scan_from_i8(Mt_s, S.cpu().numpy(), V.cpu().numpy(), ahat.cpu().numpy())
     np.testing.assert_allclose(sh.a[rows].cpu().numpy(), a_ref, rtol=1e-9, atol=1e-12 * np.abs(a_ref).max())
-    np.testing.assert_allclose(sh.vara[rows].cpu().numpy(), v_ref, rtol=1e-9)
+    np.testing.assert_allclose(sh.vara[rows].cpu().numpy(), v_ref, rtol=RTOL_DIGITS)
     tsq = sh.a[:L] ** 2 / sh.vara[:L]
     tsqmax, gidx, near = sh.best()
     assert gidx == int(torch.argmax(tsq)) and tsqmax == float(tsq.max())
