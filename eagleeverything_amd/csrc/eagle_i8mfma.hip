@@ -649,17 +649,15 @@ extern "C" int eagle_dev_vara_i8_prepare(eagle_ctx* ctx, const int8_t* Mt8, long
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "vara_i8 memset");
     hipLaunchKernelGGL(k_absmax_offdiag, dim3(1024), dim3(256), 0, s, Wu, n_pad, (unsigned long long*)&hdr->maxabs_off);
     hipLaunchKernelGGL(k_vara_prep, dim3(1), dim3(256), 0, s, Wu, n_pad, nslices, hdr, dW);
-    // one pass over the genotypes: a = Mt8 v (if asked for) and the diagonal term (a NULL a_out drops the a half)
-    rc = eagle_dev_gemv2_i8(ctx, Mt8, L_pad, n_pad, ld, v ? v : dW, dW, 1.0, v ? a_out : nullptr, vdiag, stream);
-    if (rc) return rc;
-    // correction terms of the re-centred markers: rho, R, and m^T rho for every marker (one more genotype pass)
+    // correction terms of the re-centred markers: rho and R from Wu, m^T rho from the genotype pass
     double* mrho = (double*)((char*)ws + ws_mr_off(n_pad, L_pad, smax));
     double* rho = (double*)((char*)ws + ws_rho_off(n_pad, L_pad, smax));
     double* colpart = (double*)((char*)ws + ws_cp_off(n_pad, L_pad, smax));
     hipLaunchKernelGGL(k_rho_rows, dim3((unsigned)n_pad), dim3(256), 0, s, Wu, n_pad, rho);
     hipLaunchKernelGGL(k_rho_cols, dim3((unsigned)(n_pad / 256), (unsigned)(n_pad / 256)), dim3(256), 0, s, Wu, n_pad, colpart);
     hipLaunchKernelGGL(k_rho_final, dim3(1), dim3(1024), 0, s, colpart, n_pad, rho, hdr);
-    rc = eagle_dev_gemv_i8(ctx, Mt8, L_pad, n_pad, ld, rho, 1.0, mrho, stream);
+    // ONE pass over the genotypes: a = Mt8 v (if asked for; a NULL a_out drops it), the diagonal term, and m^T rho
+    rc = eagle_dev_gemv3_i8(ctx, Mt8, L_pad, n_pad, ld, v ? v : dW, dW, rho, 1.0, v ? a_out : nullptr, vdiag, mrho, stream);
     if (rc) return rc;
     dim3 g2((unsigned)(n_pad / 32), (unsigned)(n_pad / 32));
     hipLaunchKernelGGL(k_slice_w, g2, dim3(256), 0, s, Wu, n_pad, hdr, Bs);

@@ -20,6 +20,8 @@ void* eagle_ctx_scratch(eagle_ctx* ctx);
 void* eagle_ctx_f4_buffer(eagle_ctx* ctx, size_t bytes);
 int eagle_dev_gemv2_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* v, const double* w,
                        double scale, double* out_a, double* out_d, void* stream);
+int eagle_dev_gemv3_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* v, const double* w,
+                       const double* x, double scale, double* out_a, double* out_d, double* out_x, void* stream);
 int eagle_dev_extract_col(eagle_ctx* ctx, const int8_t* M8, long n, long ld, long col, int* out, void* stream);
 #ifdef __cplusplus
 }

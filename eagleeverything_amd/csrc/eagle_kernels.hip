@@ -640,20 +640,22 @@ extern "C" int eagle_dev_colgemv(eagle_ctx* ctx, const double* At, long n, long 
 // n_pad = 10240 fits the 160 KiB exactly).
 // ------------------------------------------------------------------------------------------------
 #define GV_MAXN 10240
-__global__ __launch_bounds__(1024) void k_slice_vec(const double* __restrict__ v, const double* __restrict__ w, int n_pad,
-                                                    int8_t* __restrict__ B, int* __restrict__ exps) {
-    __shared__ double red[2][16];
-    __shared__ int ex[2];
+// B rows: 0..7 digits of v, 8..15 digits of w, and (x != NULL) 16..23 digits of a third vector x, 24..31 zero.
+__global__ __launch_bounds__(1024) void k_slice_vec(const double* __restrict__ v, const double* __restrict__ w, const double* __restrict__ x,
+                                                    int n_pad, int8_t* __restrict__ B, int* __restrict__ exps) {
+    __shared__ double red[3][16];
+    __shared__ int ex[3];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    double mv = 0.0, mw = 0.0;
+    double mv = 0.0, mw = 0.0, mx = 0.0;
     for (int k = t; k < n_pad; k += 1024) {
         mv = fmax(mv, fabs(v[k]));
         if (w) mw = fmax(mw, fabs(w[k]));
+        if (x) mx = fmax(mx, fabs(x[k]));
     }
-    for (int o = 32; o > 0; o >>= 1) { mv = fmax(mv, __shfl_xor(mv, o)); mw = fmax(mw, __shfl_xor(mw, o)); }
-    if (lane == 0) { red[0][wv] = mv; red[1][wv] = mw; }
+    for (int o = 32; o > 0; o >>= 1) { mv = fmax(mv, __shfl_xor(mv, o)); mw = fmax(mw, __shfl_xor(mw, o)); mx = fmax(mx, __shfl_xor(mx, o)); }
+    if (lane == 0) { red[0][wv] = mv; red[1][wv] = mw; red[2][wv] = mx; }
     __syncthreads();
-    if (t < 2) {
+    if (t < 3) {
         double m = 0.0;
         for (int i = 0; i < 16; i++) m = fmax(m, red[t][i]);
         int e = 0;
@@ -662,11 +664,12 @@ __global__ __launch_bounds__(1024) void k_slice_vec(const double* __restrict__ v
         exps[t] = e;
     }
     __syncthreads();
-    for (int idx = t; idx < 2 * n_pad; idx += 1024) {
-        const int which = idx >= n_pad, k = idx - which * n_pad;
+    for (int idx = t; idx < (x ? 4 : 2) * n_pad; idx += 1024) {
+        const int which = idx / n_pad, k = idx - which * n_pad;
         long long Q = 0;
-        if (!which) Q = llrint(ldexp(v[k], 62 - ex[0]));
-        else if (w) Q = llrint(ldexp(w[k], 62 - ex[1]));
+        if (which == 0) Q = llrint(ldexp(v[k], 62 - ex[0]));
+        else if (which == 1) { if (w) Q = llrint(ldexp(w[k], 62 - ex[1])); }
+        else if (which == 2) Q = llrint(ldexp(x[k], 62 - ex[2]));
 #pragma unroll
         for (int s = 0; s < 8; s++) {
             const long long d = ((Q + 128) & 255) - 128;
@@ -678,25 +681,28 @@ __global__ __launch_bounds__(1024) void k_slice_vec(const double* __restrict__ v
 
 typedef int gv_i32x4 __attribute__((ext_vector_type(4)));
 #define GV_U 8  /* 16-byte loads per lane in flight: 8 KiB per wave, 128 KiB per CU */
-template <bool SQ>
+// X3: a third vector x (digit rows 16..23 of B, a second 16-row LDS image): out_x = Mt8 x in the same sweep (n_pad <= 5120).
+template <bool SQ, bool X3>
 __global__ __launch_bounds__(1024) void k_gemv_mfma(const int8_t* __restrict__ Mt8, long L_pad, int n_pad, long ld,
                                                     const int8_t* __restrict__ B, const int* __restrict__ exps, double scale,
-                                                    double* __restrict__ out_a, double* __restrict__ out_d, int accumulate) {
-    extern __shared__ __attribute__((aligned(16))) int8_t lB[];  // [16][n_pad], chunk c of row r stored at chunk c ^ r
+                                                    double* __restrict__ out_a, double* __restrict__ out_d, double* __restrict__ out_x,
+                                                    int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) int8_t lB[];  // [16 or 32][n_pad], chunk c of row r stored at chunk c ^ (r & 15)
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int nchunk = n_pad >> 4;
-    for (int idx = t; idx < 16 * nchunk; idx += 1024) {
+    for (int idx = t; idx < (X3 ? 32 : 16) * nchunk; idx += 1024) {
         const int r = idx / nchunk, c = idx - r * nchunk;
-        *(gv_i32x4*)(lB + (long)r * n_pad + ((c ^ r) << 4)) = *(const gv_i32x4*)(B + (long)r * n_pad + (c << 4));
+        *(gv_i32x4*)(lB + (long)r * n_pad + ((c ^ (r & 15)) << 4)) = *(const gv_i32x4*)(B + (long)r * n_pad + (c << 4));
     }
     __syncthreads();
     const int r = lane & 15, q = lane >> 4;
     const int8_t* brow = lB + (long)r * n_pad;
-    const double sa = scale * ldexp(1.0, exps[0] - 62), sd = ldexp(1.0, exps[1] - 62);
+    const int8_t* brow2 = lB + (long)(16 + r) * n_pad;
+    const double sa = scale * ldexp(1.0, exps[0] - 62), sd = ldexp(1.0, exps[1] - 62), sx = X3 ? ldexp(1.0, exps[2] - 62) : 0.0;
     const long ngroups = L_pad >> 4;
     for (long g = (long)blockIdx.x * 16 + wv; g < ngroups; g += (long)gridDim.x * 16) {
         const int8_t* ap = Mt8 + (g * 16 + r) * ld + (q << 4);
-        gv_i32x4 accA = {0, 0, 0, 0}, accD = {0, 0, 0, 0};
+        gv_i32x4 accA = {0, 0, 0, 0}, accD = {0, 0, 0, 0}, accX = {0, 0, 0, 0};
         const int nsteps = n_pad >> 6;  // n_pad % 256 == 0 in every caller: a multiple of 4
         for (int st = 0; st < nsteps; st += GV_U) {
             gv_i32x4 a[GV_U], b[GV_U];
@@ -712,6 +718,10 @@ __global__ __launch_bounds__(1024) void k_gemv_mfma(const int8_t* __restrict__ M
                 if (SQ) {
                     const gv_i32x4 a2 = a[u] & (gv_i32x4){0x01010101, 0x01010101, 0x01010101, 0x01010101};
                     accD = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b[u], accD, 0, 0, 0);
+                }
+                if (X3) {
+                    const gv_i32x4 b2 = st + u < nsteps ? *(const gv_i32x4*)(brow2 + (((4 * (st + u) + q) ^ r) << 4)) : (gv_i32x4){0, 0, 0, 0};
+                    accX = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[u], b2, accX, 0, 0, 0);
                 }
             }
         }
@@ -729,43 +739,64 @@ __global__ __launch_bounds__(1024) void k_gemv_mfma(const int8_t* __restrict__ M
                 if (r == 0) { if (out_a) out_a[row] = accumulate ? out_a[row] + sa * x : sa * x; }
                 else if (SQ) out_d[row] = accumulate ? out_d[row] + sd * x : sd * x;
             }
+            if (X3) {  // cols 0..7 of accX: the digits of the third vector
+                const long long vx = (r < 8) ? (long long)accX[e] : 0;
+                long long hx = s >= 4 ? vx << (8 * (s - 4)) : 0, lx = s < 4 ? vx << (8 * s) : 0;
+#pragma unroll
+                for (int o = 1; o < 8; o <<= 1) { hx += __shfl_xor(hx, o); lx += __shfl_xor(lx, o); }
+                if (r == 0) out_x[g * 16 + 4 * q + e] = sx * ((double)hx * 4294967296.0 + (double)lx);
+            }
         }
     }
 }
 
-// a = scale * Mt8 v and d_i = sum_j Mt8[i][j]^2 w[j] in one pass over the genotypes (w may be NULL: a only; out_a may be
-// NULL: d only).
-// Individuals beyond GV_MAXN columns are taken in further sweeps of GV_MAXN columns that add into the outputs.
-extern "C" int eagle_dev_gemv2_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* v,
-                                  const double* w, double scale, double* out_a, double* out_d, void* stream) {
+// a = scale * Mt8 v, d_i = sum_j Mt8[i][j]^2 w[j] and (x != NULL) out_x = Mt8 x in one pass over the genotypes (w may be
+// NULL: no d; out_a may be NULL: no a).  Individuals beyond GV_MAXN columns are taken in further sweeps of GV_MAXN columns
+// that add into the outputs; the third vector rides along only while both LDS images fit (n_pad <= 5120), else it takes
+// a sweep of its own.
+extern "C" int eagle_dev_gemv3_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* v,
+                                  const double* w, const double* x, double scale, double* out_a, double* out_d, double* out_x, void* stream) {
     if (L_pad % 16 || n_pad % 256 || ld % 16 || n_pad > ld) return eagle_fail(ctx, EAGLE_ERR_ARG, "gemv_i8: layout contract violated (L_pad % 16, n_pad % 256, ld % 16)");
     if (L_pad == 0 || n_pad == 0) return EAGLE_OK;
     if (!ctx->gemv_ws) {
-        hipError_t e = hipMalloc(&ctx->gemv_ws, 16 * GV_MAXN + 256);
+        hipError_t e = hipMalloc(&ctx->gemv_ws, 32 * GV_MAXN + 256);
         if (e != hipSuccess) return eagle_fail_hip(ctx, e, "gemv workspace");
     }
     int8_t* B = (int8_t*)ctx->gemv_ws;
-    int* exps = (int*)(B + 16 * GV_MAXN);
+    int* exps = (int*)(B + 32 * GV_MAXN);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_gemv_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemv_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)k_gemv_mfma<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemv_mfma<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemv_mfma<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return eagle_fail_hip(ctx, e, "hipFuncSetAttribute");
         attr_done = true;
     }
     long blocks = 256;
     const long groups = L_pad / 16;
     if (blocks > (groups + 15) / 16) blocks = (groups + 15) / 16;
+    if (x && w && n_pad <= 5120) {
+        hipLaunchKernelGGL(k_slice_vec, dim3(1), dim3(1024), 0, (hipStream_t)stream, v, w, x, (int)n_pad, B, exps);
+        hipLaunchKernelGGL((k_gemv_mfma<true, true>), dim3((unsigned)blocks), dim3(1024), (size_t)32 * n_pad, (hipStream_t)stream, Mt8, L_pad, (int)n_pad,
+                           ld, B, exps, scale, out_a, out_d, out_x, 0);
+        LAUNCH_CHECK(ctx);
+        return EAGLE_OK;
+    }
     for (long k0 = 0; k0 < n_pad; k0 += GV_MAXN) {
         const int nk = (int)(n_pad - k0 < GV_MAXN ? n_pad - k0 : GV_MAXN);
-        hipLaunchKernelGGL(k_slice_vec, dim3(1), dim3(1024), 0, (hipStream_t)stream, v + k0, w ? w + k0 : nullptr, nk, B, exps);
-        if (w) hipLaunchKernelGGL(k_gemv_mfma<true>, dim3((unsigned)blocks), dim3(1024), (size_t)16 * nk, (hipStream_t)stream, Mt8 + k0, L_pad, nk, ld,
-                                  B, exps, scale, out_a, out_d, k0 > 0);
-        else hipLaunchKernelGGL(k_gemv_mfma<false>, dim3((unsigned)blocks), dim3(1024), (size_t)16 * nk, (hipStream_t)stream, Mt8 + k0, L_pad, nk, ld,
-                                B, exps, scale, out_a, out_d, k0 > 0);
+        hipLaunchKernelGGL(k_slice_vec, dim3(1), dim3(1024), 0, (hipStream_t)stream, v + k0, w ? w + k0 : nullptr, (const double*)nullptr, nk, B, exps);
+        if (w) hipLaunchKernelGGL((k_gemv_mfma<true, false>), dim3((unsigned)blocks), dim3(1024), (size_t)16 * nk, (hipStream_t)stream, Mt8 + k0, L_pad, nk, ld,
+                                  B, exps, scale, out_a, out_d, (double*)nullptr, k0 > 0);
+        else hipLaunchKernelGGL((k_gemv_mfma<false, false>), dim3((unsigned)blocks), dim3(1024), (size_t)16 * nk, (hipStream_t)stream, Mt8 + k0, L_pad, nk, ld,
+                                B, exps, scale, out_a, out_d, (double*)nullptr, k0 > 0);
     }
     LAUNCH_CHECK(ctx);
+    if (x) return eagle_dev_gemv3_i8(ctx, Mt8, L_pad, n_pad, ld, x, nullptr, nullptr, 1.0, out_x, nullptr, nullptr, stream);
     return EAGLE_OK;
+}
+extern "C" int eagle_dev_gemv2_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* v,
+                                  const double* w, double scale, double* out_a, double* out_d, void* stream) {
+    return eagle_dev_gemv3_i8(ctx, Mt8, L_pad, n_pad, ld, v, w, nullptr, scale, out_a, out_d, nullptr, stream);
 }
 
 extern "C" int eagle_dev_gemv_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* v,
