@@ -135,6 +135,7 @@ extern "C" void eagle_close(eagle_ctx* ctx) {
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->gemv_ws) (void)hipFree(ctx->gemv_ws);
     if (ctx->f4_buf) (void)hipFree(ctx->f4_buf);
+    if (ctx->gemm_scratch) (void)hipFree(ctx->gemm_scratch);
     for (int b = 0; b < 2; b++) { if (ctx->stage_pin[b]) (void)hipHostFree(ctx->stage_pin[b]); if (ctx->stage_raw[b]) (void)hipFree(ctx->stage_raw[b]); }
     (void)hipStreamDestroy(ctx->stream);
     if (ctx->load_stream) (void)hipStreamDestroy(ctx->load_stream);

@@ -43,6 +43,7 @@ struct eagle_ctx {
     void* d_scratch = nullptr;
     void* arena = nullptr; size_t arena_cap = 0, arena_off = 0;  // grow-only device workspace reused across calls
     void* f4_buf = nullptr; size_t f4_cap = 0;  // fp4 image of the tile eagle_dev_mmt_accumulate is working on
+    void* gemm_scratch = nullptr; size_t gemm_scratch_cap = 0;  // split-K partial tiles of the fp64 GEMM's last wave
     void* gemv_ws = nullptr;  // 16 digit-slice rows of the GEMV vectors + their exponents (k_gemv_mfma)
     void* stage_pin[2] = {nullptr, nullptr}; void* stage_raw[2] = {nullptr, nullptr}; size_t stage_cap = 0;  // tile streamer
     char arch[64] = {0};

@@ -572,20 +572,156 @@ extern "C" int eagle_dev_mmt_normalise(eagle_ctx* ctx, double* MMt, long n, long
     return EAGLE_OK;
 }
 
-extern "C" int eagle_dev_gemm_f64(eagle_ctx* ctx, const double* A, const double* B, double* C, long np, void* stream) {
-    if (np % GF_T || np <= 0) return eagle_fail(ctx, EAGLE_ERR_ARG, "gemm_f64: size must be a multiple of 128");
-    dim3 grid((unsigned)(np / GF_T), (unsigned)(np / GF_T));
-    hipLaunchKernelGGL((k_gemm_f64<0, 0>), grid, dim3(256), 0, (hipStream_t)stream, (const void*)A, np, B, np, C, np,
-                       (int)(np / GF_T), np, (const int*)nullptr);
+// ------------------------------------------------------------------------------------------------
+// C = A * B over a LIST of 128 x 128 output tiles, with the last partial wave of workgroups split along K.
+// 512 workgroups are resident (2 per CU); 1600 tiles (np = 5120) are 3.125 waves, so a plain grid leaves 7/8 of the chip
+// idle through a fourth wave.  The first floor(T/512)*512 tiles run whole; each remaining tile is cut into `split` K
+// ranges whose partial tiles go to a scratch buffer and are added in a fixed order by k_gemm_f64_tail (deterministic).
+// skip_if / skip_val: the whole launch is dropped on the device when *skip_if == skip_val (the lower-triangle launch of
+// a product the symmetry check found symmetric).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_gemm_f64_list(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
+                                                          double* __restrict__ C, long ldc, long K, const int* __restrict__ tiles, int n_main,
+                                                          int split, double* __restrict__ scratch, const int* __restrict__ skip_if, int skip_val) {
+    __shared__ __attribute__((aligned(16))) double lds[2][GF_LDSA_DOUBLES + GF_LDSB_DOUBLES];
+    if (skip_if && *skip_if == skip_val) return;
+    const int b = blockIdx.x;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
+    const int i16 = lane & 15, g = lane >> 4;
+    const long nkb_all = K / GF_BK;
+    int tile;
+    long kb0 = 0, kb1 = nkb_all;
+    double* out;
+    long ldo;
+    if (b < n_main) {
+        tile = tiles[b];
+        out = nullptr; ldo = ldc;
+    } else {
+        const int u = b - n_main, tt = u / split, ks = u - tt * split;
+        tile = tiles[n_main + tt];
+        kb0 = nkb_all * ks / split;
+        kb1 = nkb_all * (ks + 1) / split;
+        out = scratch + (long)u * (GF_T * GF_T);
+        ldo = GF_T;
+    }
+    const long row0 = (long)(tile >> 16) * GF_T, col0 = (long)(tile & 0xffff) * GF_T;
+    const void* Ablk = (const void*)(A + row0 * lda);
+    const double* Bblk = B + col0;
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < 4; n++) acc[m][n] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    GfStage<0> st;
+    gf_load<0>(st, Ablk, lda, Bblk, ldb, kb0 * GF_BK, t);
+    gf_store<0>(st, lds[0], lds[0] + GF_LDSA_DOUBLES, t);
+    __syncthreads();
+    int cur = 0;
+    for (long kb = kb0; kb < kb1; kb++) {
+        const bool more = kb + 1 < kb1;
+        if (more) gf_load<0>(st, Ablk, lda, Bblk, ldb, (kb + 1) * GF_BK, t);
+        gf_compute<0>(acc, lds[cur], lds[cur] + GF_LDSA_DOUBLES, wr, wc, lane);
+        if (more) gf_store<0>(st, lds[cur ^ 1], lds[cur ^ 1] + GF_LDSA_DOUBLES, t);
+        __syncthreads();
+        cur ^= 1;
+    }
+    double* dst = out ? out : C + row0 * ldc + col0;
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < 4; n++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) dst[(long)(wr * 64 + m * 16 + g + 4 * q) * ldo + wc * 64 + n * 16 + i16] = acc[m][n][q];
+}
+__global__ __launch_bounds__(256) void k_gemm_f64_tail(const double* __restrict__ scratch, const int* __restrict__ tail_tiles, int split,
+                                                       double* __restrict__ C, long ldc, const int* __restrict__ skip_if, int skip_val) {
+    if (skip_if && *skip_if == skip_val) return;
+    const int tile = tail_tiles[blockIdx.x >> 4], part = blockIdx.x & 15;  // 16 workgroups per tile, 8 rows each
+    double* dst = C + (long)(tile >> 16) * GF_T * ldc + (long)(tile & 0xffff) * GF_T;
+    const double* src = scratch + (long)(blockIdx.x >> 4) * split * (GF_T * GF_T);
+    for (int e = part * 1024 + threadIdx.x; e < (part + 1) * 1024; e += 256) {
+        double s = src[e];
+        for (int k = 1; k < split; k++) s += src[(long)k * (GF_T * GF_T) + e];  // ascending K: fixed order
+        dst[(long)(e >> 7) * ldc + (e & 127)] = s;
+    }
+}
+
+// device tile lists, cached per (device, tiles per side, kind): 0 = all tiles, 1 = row tile <= column tile, 2 = row tile > column tile
+#include <map>
+#include <tuple>
+#include <vector>
+static std::map<std::tuple<int, int, int>, std::pair<int*, long>> g_gemm_lists;
+static int gemm_tile_list(eagle_ctx* ctx, int nt, int kind, const int** out, long* count) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    auto key = std::make_tuple(dev, nt, kind);
+    auto it = g_gemm_lists.find(key);
+    if (it != g_gemm_lists.end()) { *out = it->second.first; *count = it->second.second; return EAGLE_OK; }
+    std::vector<int> h;
+    for (int i = 0; i < nt; i++)      // row tile outer: consecutive workgroups share an A row panel (measured 4 % faster than column-major)
+        for (int j = 0; j < nt; j++)
+            if (kind == 0 || (kind == 1 && i <= j) || (kind == 2 && i > j)) h.push_back((i << 16) | j);
+    int* d = nullptr;
+    if (!h.empty()) {
+        hipError_t e = hipMalloc((void**)&d, h.size() * sizeof(int));
+        if (e != hipSuccess) return eagle_fail_hip(ctx, e, "gemm tile list alloc");
+        e = hipMemcpy(d, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(d); return eagle_fail_hip(ctx, e, "gemm tile list copy"); }
+    }
+    g_gemm_lists[key] = std::make_pair(d, (long)h.size());
+    *out = d;
+    *count = (long)h.size();
+    return EAGLE_OK;
+}
+
+static int gemm_f64_tiles(eagle_ctx* ctx, const double* A, const double* B, double* C, long np, int kind, const int* skip_if, int skip_val,
+                          void* stream) {
+    if (np % GF_T || np <= 0 || np / GF_T > 65535) return eagle_fail(ctx, EAGLE_ERR_ARG, "gemm_f64: size must be a multiple of 128");
+    const int* tiles = nullptr;
+    long count = 0;
+    int rc = gemm_tile_list(ctx, (int)(np / GF_T), kind, &tiles, &count);
+    if (rc || count == 0) return rc;
+    const long slots = 2L * (ctx->cu_count > 0 ? ctx->cu_count : 256);  // resident workgroups (2 per CU)
+    const long n_main = count / slots * slots, tail = count - n_main;
+    const long nkb = np / GF_BK;
+    int split = 1;
+    if (tail > 0) {
+        double best = 1.0;
+        for (int sp = 2; sp <= 8; sp++) {
+            if (nkb / sp < 8 || (double)tail * sp * GF_T * GF_T * 8.0 > 160e6) break;
+            const double cost = (double)((tail * sp + slots - 1) / slots) / sp;
+            if (cost < best - 1e-9) { best = cost; split = sp; }
+        }
+    }
+    double* scratch = nullptr;
+    if (split > 1) {
+        const size_t need = (size_t)tail * split * GF_T * GF_T * sizeof(double);
+        if (need > ctx->gemm_scratch_cap) {
+            if (ctx->gemm_scratch) { (void)hipStreamSynchronize((hipStream_t)stream); (void)hipFree(ctx->gemm_scratch); ctx->gemm_scratch = nullptr; ctx->gemm_scratch_cap = 0; }
+            hipError_t e = hipMalloc(&ctx->gemm_scratch, need);
+            if (e != hipSuccess) return eagle_fail_hip(ctx, e, "gemm scratch");
+            ctx->gemm_scratch_cap = need;
+        }
+        scratch = (double*)ctx->gemm_scratch;
+    }
+    const long blocks = split > 1 ? n_main + tail * split : count;
+    hipLaunchKernelGGL(k_gemm_f64_list, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, A, np, B, np, C, np, np, tiles,
+                       (int)(split > 1 ? n_main : count), split, scratch, skip_if, skip_val);
+    if (split > 1)
+        hipLaunchKernelGGL(k_gemm_f64_tail, dim3((unsigned)(tail * 16)), dim3(256), 0, (hipStream_t)stream, scratch, tiles + n_main, split, C, np, skip_if,
+                           skip_val);
     LAUNCH_CHECK(ctx);
     return EAGLE_OK;
 }
-static int gemm_f64_upper(eagle_ctx* ctx, const double* A, const double* B, double* C, long np, const int* flag, void* stream) {
-    dim3 grid((unsigned)(np / GF_T), (unsigned)(np / GF_T));
-    hipLaunchKernelGGL((k_gemm_f64<0, 0>), grid, dim3(256), 0, (hipStream_t)stream, (const void*)A, np, B, np, C, np,
-                       (int)(np / GF_T), np, flag);
-    LAUNCH_CHECK(ctx);
-    return EAGLE_OK;
+
+extern "C" int eagle_dev_gemm_f64(eagle_ctx* ctx, const double* A, const double* B, double* C, long np, void* stream) {
+    return gemm_f64_tiles(ctx, A, B, C, np, 0, nullptr, 0, stream);
+}
+// Upper tiles always; the lower ones only when *sym == 0 (k_fold_upper then takes both halves from memory).
+static int gemm_f64_upper(eagle_ctx* ctx, const double* A, const double* B, double* C, long np, const int* sym, void* stream) {
+    int rc = gemm_f64_tiles(ctx, A, B, C, np, 1, nullptr, 0, stream);
+    if (rc) return rc;
+    return gemm_f64_tiles(ctx, A, B, C, np, 2, sym, 1, stream);
 }
 
 extern "C" int eagle_dev_scan_operands(eagle_ctx* ctx, const double* Sa, const double* Va, const double* ahat, long n,
