@@ -183,7 +183,7 @@ def main():
     ev_gemv = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i=None):
-        sh.scan_operands()
+        sh.scan_operands(coll)  # N > 1: each rank computes 1/N of W's rows, one all-gather (N = 1: the whole of it)
         if i is not None:
             ev_gemv[i][0].record()
         if sh.mode == 0:

@@ -58,6 +58,9 @@ SIGNATURES = {
     "eagle_dev_mmt_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_void_p,
                                        C.c_void_p]),
     "eagle_dev_mmt_normalise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_void_p]),
+    "eagle_dev_scan_operands_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_long,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eagle_dev_fold_upper": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]),
     "eagle_dev_scan_operands": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_long,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "eagle_dev_gemv_i8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_double,

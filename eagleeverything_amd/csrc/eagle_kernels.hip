@@ -650,15 +650,16 @@ __global__ __launch_bounds__(256) void k_gemm_f64_tail(const double* __restrict_
 #include <map>
 #include <tuple>
 #include <vector>
-static std::map<std::tuple<int, int, int>, std::pair<int*, long>> g_gemm_lists;
-static int gemm_tile_list(eagle_ctx* ctx, int nt, int kind, const int** out, long* count) {
+static std::map<std::tuple<int, int, int, int, int>, std::pair<int*, long>> g_gemm_lists;
+// kind: 0 = all tiles, 1 = row tile <= column tile, 2 = row tile > column tile; restricted to row tiles [rt0, rt1)
+static int gemm_tile_list(eagle_ctx* ctx, int nt, int kind, int rt0, int rt1, const int** out, long* count) {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    auto key = std::make_tuple(dev, nt, kind);
+    auto key = std::make_tuple(dev, nt, kind, rt0, rt1);
     auto it = g_gemm_lists.find(key);
     if (it != g_gemm_lists.end()) { *out = it->second.first; *count = it->second.second; return EAGLE_OK; }
     std::vector<int> h;
-    for (int i = 0; i < nt; i++)      // row tile outer: consecutive workgroups share an A row panel (measured 4 % faster than column-major)
+    for (int i = rt0; i < rt1; i++)   // row tile outer: consecutive workgroups share an A row panel (measured 4 % faster than column-major)
         for (int j = 0; j < nt; j++)
             if (kind == 0 || (kind == 1 && i <= j) || (kind == 2 && i > j)) h.push_back((i << 16) | j);
     int* d = nullptr;
@@ -675,11 +676,12 @@ static int gemm_tile_list(eagle_ctx* ctx, int nt, int kind, const int** out, lon
 }
 
 static int gemm_f64_tiles(eagle_ctx* ctx, const double* A, const double* B, double* C, long np, int kind, const int* skip_if, int skip_val,
-                          void* stream) {
+                          void* stream, int rt0 = 0, int rt1 = -1) {
     if (np % GF_T || np <= 0 || np / GF_T > 65535) return eagle_fail(ctx, EAGLE_ERR_ARG, "gemm_f64: size must be a multiple of 128");
     const int* tiles = nullptr;
     long count = 0;
-    int rc = gemm_tile_list(ctx, (int)(np / GF_T), kind, &tiles, &count);
+    if (rt1 < 0) rt1 = (int)(np / GF_T);
+    int rc = gemm_tile_list(ctx, (int)(np / GF_T), kind, rt0, rt1, &tiles, &count);
     if (rc || count == 0) return rc;
     const long slots = 2L * (ctx->cu_count > 0 ? ctx->cu_count : 256);  // resident workgroups (2 per CU)
     const long n_main = count / slots * slots, tail = count - n_main;
@@ -745,6 +747,35 @@ extern "C" int eagle_dev_scan_operands(eagle_ctx* ctx, const double* Sa, const d
     rc = gemm_f64_upper(ctx, tmp, Sa, Wu_out, n_pad, sym, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(k_fold_upper, g32, dim3(256), 0, s, Wu_out, n_pad, sym);
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+
+// The same operands with the n^3 work shared between ranks (marker-sharded multi-GPU run): this call computes v = S a_hat
+// and only the rows [row0, row1) (multiples of 128) of W^T's row-major image -- Xt rows = Sa rows * Va, Wt rows = Xt rows * Sa --
+// into Wt_out[row0.., :], full rows, no symmetry shortcut.  The caller all-gathers the row blocks and then folds the
+// complete image with eagle_dev_fold_upper.
+extern "C" int eagle_dev_scan_operands_rows(eagle_ctx* ctx, const double* Sa, const double* Va, const double* ahat, long n, long n_pad,
+                                            long row0, long row1, double* v_out, double* Wt_out, double* tmp, void* stream) {
+    if (n_pad % GF_T || n > n_pad || row0 % GF_T || row1 % GF_T || row0 < 0 || row1 > n_pad || row0 >= row1)
+        return eagle_fail(ctx, EAGLE_ERR_ARG, "scan_operands_rows: bad padding or row block");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(v_out, 0, sizeof(double) * n_pad, s);
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "scan_operands memset");
+    hipLaunchKernelGGL(k_colgemv, dim3((unsigned)(n_pad / 64)), dim3(256), 0, s, Sa, n, n_pad, ahat, v_out);
+    LAUNCH_CHECK(ctx);
+    const int rt0 = (int)(row0 / GF_T), rt1 = (int)(row1 / GF_T);
+    int rc = gemm_f64_tiles(ctx, Sa, Va, tmp, n_pad, 0, nullptr, 0, stream, rt0, rt1);
+    if (rc) return rc;
+    return gemm_f64_tiles(ctx, tmp, Sa, Wt_out, n_pad, 0, nullptr, 0, stream, rt0, rt1);
+}
+// In-place fold of a COMPLETE W image: Wu[j][k] = W[j][k] + W[k][j] (j<k), W[k][k], 0 below.
+extern "C" int eagle_dev_fold_upper(eagle_ctx* ctx, double* W, long n_pad, void* stream) {
+    if (n_pad % 32) return eagle_fail(ctx, EAGLE_ERR_ARG, "fold_upper: bad padding");
+    int* sym = (int*)eagle_ctx_scratch(ctx);
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, (hipStream_t)stream, sym, 0);
+    dim3 g32((unsigned)(n_pad / 32), (unsigned)(n_pad / 32));
+    hipLaunchKernelGGL(k_fold_upper, g32, dim3(256), 0, (hipStream_t)stream, W, n_pad, sym);
     LAUNCH_CHECK(ctx);
     return EAGLE_OK;
 }

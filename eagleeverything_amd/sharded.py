@@ -52,6 +52,19 @@ class Collectives:
             self._staged(c32, lambda x: self.dist.all_reduce(x, op=self.dist.ReduceOp.SUM))
         return c32
 
+    def all_gather_rows(self, full, mine):
+        """full (world * rows x cols, contiguous) <- the ranks' row blocks `mine` (rows x cols), in rank order."""
+        if self.world == 1:
+            return full
+        if self.via_host and full.is_cuda:
+            import torch
+            parts = [torch.empty(mine.shape, dtype=mine.dtype) for _ in range(self.world)]
+            self.dist.all_gather(parts, mine.cpu())
+            full.copy_(torch.cat(parts, dim=0))
+        else:
+            self.dist.all_gather_into_tensor(full, mine)
+        return full
+
     def broadcast_(self, t, src=0):
         if self.world > 1:
             self._staged(t, lambda x: self.dist.broadcast(x, src=src))
@@ -215,7 +228,22 @@ class DeviceShard:
         self.ws = None
         self.torch.cuda.empty_cache()
 
-    def scan_operands(self):
+    def scan_operands(self, coll=None):
+        """v = S a_hat and Wu = fold(S V S).  With a Collectives of world > 1 whose size divides the 128-row tiles of W, the
+        n^3 work is shared: every rank computes its row block of the W^T image, one all-gather completes it (the
+        replicated computation is the fallback)."""
+        world = coll.world if coll is not None else 1
+        nt = self.np_ // 128
+        if world > 1 and nt % world == 0:
+            rows = self.np_ // world
+            r0 = coll.rank * rows
+            self._check(self.L.eagle_dev_scan_operands_rows(self.ctx, self.Sa.data_ptr(), self.Va.data_ptr(), self.ahat.data_ptr(),
+                                                            self.n, self.np_, r0, r0 + rows, self.v.data_ptr(), self.Wu.data_ptr(),
+                                                            self.tmp.data_ptr(), self._stream()))
+            mine = self.Wu[r0:r0 + rows].clone()
+            coll.all_gather_rows(self.Wu, mine)
+            self._check(self.L.eagle_dev_fold_upper(self.ctx, self.Wu.data_ptr(), self.np_, self._stream()))
+            return
         self._check(self.L.eagle_dev_scan_operands(self.ctx, self.Sa.data_ptr(), self.Va.data_ptr(), self.ahat.data_ptr(),
                                                    self.n, self.np_, self.v.data_ptr(), self.Wu.data_ptr(),
                                                    self.tmp.data_ptr(), self._stream()))
@@ -284,9 +312,9 @@ class DeviceShard:
         self._check(self.L.eagle_dev_tsq_argmax(self.ctx, self.a.data_ptr(), self.vara.data_ptr(), self.Lloc, None,
                                                 self._best.data_ptr(), self._scratch.data_ptr(), self._stream()))
 
-    def scan(self):
+    def scan(self, coll=None):
         """calculate_a_and_vara_rcpp.cpp:90-112 + find_qtl.R:71-83 on this shard, all on the current stream."""
-        self.scan_operands()
+        self.scan_operands(coll)
         if self.mode == 0:
             self.gemv_a()
         else:

@@ -220,6 +220,11 @@ int eagle_dev_mmt_normalise(eagle_ctx* ctx, double* MMt, long n, long ld, const 
  * tmp: n_pad*n_pad doubles of scratch. */
 int eagle_dev_scan_operands(eagle_ctx* ctx, const double* Sa, const double* Va, const double* ahat, long n,
                             long n_pad, double* v_out, double* Wu_out, double* tmp, void* stream);
+/* Marker-sharded runs share the n^3 part: each rank computes v and the rows [row0, row1) (multiples of 128) of the W^T
+ * image (full rows), the row blocks are all-gathered, and eagle_dev_fold_upper folds the complete image in place. */
+int eagle_dev_scan_operands_rows(eagle_ctx* ctx, const double* Sa, const double* Va, const double* ahat, long n, long n_pad,
+                                 long row0, long row1, double* v_out, double* Wt_out, double* tmp, void* stream);
+int eagle_dev_fold_upper(eagle_ctx* ctx, double* W, long n_pad, void* stream);
 /* a_i = scale * sum_j Mt8[i][j] v[j] for L_pad rows: calculate_a_and_vara_rcpp.cpp:91, calculate_reduced_a_rcpp.cpp:83-84.
  * HBM-bound pass on the int8 MFMA (v as 8 exact base-256 digit rows, int32 sums, one rounding per output).
  * L_pad % 16 == 0, n_pad % 256 == 0, ld % 16 == 0. */

@@ -52,6 +52,13 @@ def _worker(rank, world, port, case, out_dir):
         sel, best = coll.best_marker(mx, gidx0)
         assert sel == int(g["argmax"]), (sel, int(g["argmax"]))
         np.testing.assert_allclose(best, float(g["tsqmax"]), rtol=1e-9)
+        # shared W: every rank computes its row block of S V S, one all-gather completes the image
+        W = g["S"] @ (g["V"] @ g["S"])
+        rows = 64
+        full = torch.zeros((world * rows, 32), dtype=torch.float64)
+        mine = torch.from_numpy(W[rank * rows:(rank + 1) * rows, :32].copy())
+        coll.all_gather_rows(full, mine)
+        assert np.array_equal(full.numpy(), W[:world * rows, :32])
         # tie across shards: both shards report the same maximum -> the smaller global index wins
         sel2, _ = coll.best_marker(5.0, 100 + 50 * (world - 1 - rank))
         assert sel2 == 101
