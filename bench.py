@@ -200,6 +200,16 @@ def main():
         tsqmax, gidx, near = sh.best()
         return coll.best_marker(tsqmax, gidx, device=dev)
 
+    if world > 1:
+        # pre-flight of the shared-W collective (every rank takes the same branch: the failure of a collective is symmetric);
+        # the replicated computation of W is the fallback and is reported in config.parallelism
+        try:
+            sel = step()
+            torch.cuda.synchronize(dev)
+        except Exception as exc:  # noqa: BLE001
+            if rank == 0:
+                print("bench.py: shared-W all-gather failed (%s); every rank computes W itself" % exc, file=sys.stderr)
+            sh.share_w = False
     for _ in range(args.warmup):
         sel = step()
     barrier()
@@ -307,7 +317,8 @@ def main():
             "config": {"workload": "synthetic %d individuals x %d SNPs per GPU (HWE genotypes, int8 resident in HBM), "
                                    "single trait, full calculate_a_and_vara pass + tsq arg-max" % (n, Lloc),
                        "n": n, "markers_per_gpu": Lloc, "markers_total": Ltot,
-                       "parallelism": "marker-shard x%d" % world + (" (REHEARSAL: gloo, ranks share one card)" if backend == "gloo" and world > 1 else ""),
+                       "parallelism": "marker-shard x%d" % world + (", W rows 1/%d per rank + all-gather" % world if world > 1 and sh.share_w and (sh.np_ // 128) % world == 0 else "")
+                                      + (" (REHEARSAL: gloo, ranks share one card)" if backend == "gloo" and world > 1 else ""),
                        "scan_mode": args.mode, "slices": S_used, "vara_abs_error_bound": vara_bound,
                        "vara_rel_error_bound": (vara_bound / (0.5 * sh.last_sumdiag) if sh.mode else None), "operands": "simple" if args.simple_operands else "model algebra on MM^T" + (" (reloaded)" if args.load_operands else "")},
             "mmt_build_s": mmt_build_s, "selected_marker": int(sel[0]), "tsqmax": sel[1],

@@ -122,6 +122,7 @@ class DeviceShard:
         self._ws_mode = None
         self.Mt4 = None
         self.Mt8s = self.cshift = None
+        self.share_w = True  # multi-rank runs split the n^3 part of the scan operands (scan_operands)
         self.mode = 0
         self.nslices = 0  # 0 = chosen by the library from its error bound
 
@@ -234,7 +235,7 @@ class DeviceShard:
         replicated computation is the fallback)."""
         world = coll.world if coll is not None else 1
         nt = self.np_ // 128
-        if world > 1 and nt % world == 0:
+        if world > 1 and nt % world == 0 and self.share_w:
             rows = self.np_ // world
             r0 = coll.rank * rows
             self._check(self.L.eagle_dev_scan_operands_rows(self.ctx, self.Sa.data_ptr(), self.Va.data_ptr(), self.ahat.data_ptr(),
