@@ -255,7 +255,7 @@ def main():
         tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["k_vara_i8"]
         if sh.mode == 1 and tr["config"] == {"n": n, "markers": Lloc, "slices": S_used}:
             roof["traffic"] = tr["hbm_side_bytes"]
-            roof["traffic_unit"] = "bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r01_rocprof_final4"
+            roof["traffic_unit"] = "bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r01_rocprof_final5"
             roof["algorithmic_bytes"] = float(Lp) * np_ + float(S_used) * np_ * np_ / 2
             roof["l2_hit_rate"] = tr["TCC_hit_rate"]
     except Exception:

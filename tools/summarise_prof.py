@@ -19,6 +19,10 @@ def find(pattern):
 def short(name):
     for k in OURS:
         if k in name:
+            if "k_gemm_f64_list" in name:
+                return "k_gemm_f64_list"
+            if "k_gemm_f64_tail" in name:
+                return "k_gemm_f64_tail"
             if "k_gemm_f64" in name:
                 return "k_gemm_f64<i8A,rowdot>" if "Li1ELi1E" in name or "<1, 1>" in name else "k_gemm_f64<f64A,store>"
             if k == "k_vara_i8" and "finish" in name:
