@@ -770,7 +770,8 @@ extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_asc
     const int nslices = ctx->scan_slices;
     GenoEntry* g = nullptr;
     rc = get_resident(ctx, f_name_ascii, L, n, max_memory_in_Gbytes, host_threads(), &g,
-                      4 * sq + (use_i8 ? (size_t)eagle_vara_i8_workspace_bytes(np, Lp, nslices) : 0) + ((size_t)1 << 30));
+                      4 * sq + (use_i8 ? (size_t)eagle_vara_i8_workspace_bytes(np, Lp, nslices) + (size_t)Lp * np + Lp : 0) +
+                          ((size_t)1 << 30));  // operands, digit workspace, the re-centred image of the file
     if (rc < 0) return rc;
     const bool streamed = (rc == EAGLE_STREAM);
     const long Lc = streamed ? stream_chunk_rows(np, Lp) : Lp;  // marker rows per pass
