@@ -497,7 +497,12 @@ __device__ __forceinline__ void vit_advance(VaraIt& it, int nct, int npair) {
 
 __global__ __launch_bounds__(512, 2) void k_vara_i8(const int8_t* __restrict__ Mt8, long ld, int ntm, const int8_t* __restrict__ Bs,
                                                     long np, const VaraHdr* __restrict__ hdr, long long* __restrict__ q, long Lp) {
-    __shared__ __attribute__((aligned(1024))) int8_t lds[2][2][TILE_BYTES];
+    // LDS: genotype (A) stages in a ring of THREE, W-digit (B) stages in a ring of two = 160 KiB.  The third A buffer is
+    // what lets the tile epilogue read its genotype bytes from LDS: a tile's 256 output columns are exactly the genotype
+    // columns of its last two K stages, and with three buffers both are still there when the last MFMA has retired.
+    extern __shared__ __attribute__((aligned(1024))) int8_t ldsv[];
+    int8_t* const ldsA0 = ldsv;
+    int8_t* const ldsB0 = ldsv + 3 * TILE_BYTES;
     // XCD-aware placement (speed only): b -> (xcd, slot); slot -> (marker tile within the XCD's sequence, worker)
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
@@ -527,33 +532,49 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8(const int8_t* __restrict__ M
     const int col = lane & 31, hrow = 4 * (lane >> 5);
     const int xsel = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
 
-    t8_stage(rsA, lnA, ldi, nxt.kt * BK8, lds[0][0], w);
-    t8_stage(t8_rsrc(Bsl + (long)nxt.ct * T8 * np, npi), lnB, npi, nxt.kt * BK8, lds[0][1], w);
+    // epilogue addressing: lane (col = l&31, h = l>>5) of wave (wr, wc) wants byte (row, colT) of a 128-column A stage,
+    // row = wr*128 + m*32 + rx + 4h (rx = (x&3) + 8(x>>2)), colT = (wc&1)*64 + col (+32 for the second MFMA tile); the
+    // stage image stores 16-byte chunk c of a row at chunk c ^ ((row>>1)&7), and ((rx + 4h)>>1)&7 = base_x ^ 2h with
+    // base_x in {0,1,4,5} (disjoint bits), so the byte sits at rowpart + (laneP ^ (base_x << 4)): four per-lane address
+    // registers per column and compile-time offsets cover all 128 reads.
+    const int colT = (wc & 1) * 64 + col;
+    const int laneP = (wr * 128 + hrow) * BK8 + (((colT >> 4) ^ (2 * (lane >> 5))) << 4) + (colT & 15);
+    int pe0[4], pe1[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int bx = ((k & 1) | ((k & 2) << 1)) << 4;  // base_x << 4 for base_x = 0, 1, 4, 5
+        pe0[k] = laneP ^ bx;
+        pe1[k] = pe0[k] ^ 32;                              // second column tile: chunk + 2
+    }
+
+    t8_stage(rsA, lnA, ldi, nxt.kt * BK8, ldsA0, w);
+    t8_stage(t8_rsrc(Bsl + (long)nxt.ct * T8 * np, npi), lnB, npi, nxt.kt * BK8, ldsB0, w);
     vit_advance(nxt, nct, npair);
     __syncthreads();
-    int buf = 0;
+    int ia = 0, ib = 0;  // ring positions of the stage being computed
     while (cur.valid) {
+        const int ian = ia == 2 ? 0 : ia + 1;
         if (nxt.valid) {
-            t8_stage(rsA, lnA, ldi, nxt.kt * BK8, lds[buf ^ 1][0], w);
-            t8_stage(t8_rsrc(Bsl + (long)nxt.ct * T8 * np, npi), lnB, npi, nxt.kt * BK8, lds[buf ^ 1][1], w);
+            t8_stage(rsA, lnA, ldi, nxt.kt * BK8, ldsA0 + ian * TILE_BYTES, w);
+            t8_stage(t8_rsrc(Bsl + (long)nxt.ct * T8 * np, npi), lnB, npi, nxt.kt * BK8, ldsB0 + (ib ^ 1) * TILE_BYTES, w);
             vit_advance(nxt, nct, npair);
         }
-        t8_compute(acc, lds[buf][0], lds[buf][1], wr, wc, lane);
+        t8_compute(acc, ldsA0 + ia * TILE_BYTES, ldsB0 + ib * TILE_BYTES, wr, wc, lane);
         if (cur.kt == cur.nk - 1) {
-            // tile done: v[x] = sum over this lane's 2 columns of T[row][col] * m[row][col]
-            // (m from global: these genotype bytes were just streamed as the A operand, L2-resident)
-            // one per-lane VGPR offset + scalar offsets through the A-tile descriptor (no 64-bit row pointers)
-            const int mvoff = (wr * 128 + hrow) * ldi + wc * 64 + col;
-            const int msoff = cur.ct * T8;
+            // tile done: v[x] = sum over this lane's 2 columns of T[row][col] * m[row][col]; the genotype bytes of columns
+            // 0..127 of the tile are the A stage before this one (waves wc = 0, 1), those of 128..255 this one (wc = 2, 3)
+            const int8_t* mst = ldsA0 + ((wc & 2) ? ia : (ia == 0 ? 2 : ia - 1)) * TILE_BYTES;
             const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 int v16[16], v8[8], v4[4], v2[2];
 #pragma unroll
                 for (int x = 0; x < 16; x++) {
-                    const int so = (m * 32 + (x & 3) + 8 * (x >> 2)) * ldi + msoff;
-                    const int m0 = (int)(int8_t)__builtin_amdgcn_raw_buffer_load_b8(rsA, mvoff, so, 0);
-                    const int m1 = (int)(int8_t)__builtin_amdgcn_raw_buffer_load_b8(rsA, mvoff, so + 32, 0);
+                    const int rx = (x & 3) + 8 * (x >> 2);
+                    const int k = ((rx >> 1) & 1) | (((rx >> 1) & 4) >> 1);  // index of base_x = (rx>>1)&7 in {0,1,4,5}
+                    const int off = (m * 32 + rx) * BK8;
+                    const int m0 = (int)mst[pe0[k] + off];
+                    const int m1 = (int)mst[pe1[k] + off];
                     v16[x] = acc[m][0][x] * m0 + acc[m][1][x] * m1;
                     acc[m][0][x] = 0;
                     acc[m][1][x] = 0;
@@ -574,7 +595,8 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8(const int8_t* __restrict__ M
             cur.kt++;
         }
         __syncthreads();
-        buf ^= 1;
+        ia = ian;
+        ib ^= 1;
     }
     // this worker's slice is complete: add into q[slice][row] (int64 atomics: exact, order independent)
     long long* qs = q + (long)sl * Lp + (long)mt * T8 + wr * 128 + hrow + (xsel & 3) + 8 * (xsel >> 2);
@@ -683,7 +705,13 @@ extern "C" int eagle_dev_vara_i8_mfma_shifted(eagle_ctx* ctx, const int8_t* Mt8s
     int8_t* Bs = (int8_t*)((char*)ws + ws_bs_off(n_pad, L_pad, smax));
     const int ntm = (int)(L_pad / T8);
     const int groups = (ntm + 7) / 8;
-    hipLaunchKernelGGL(k_vara_i8, dim3((unsigned)(groups * 8 * smax)), dim3(512), 0, s, Mt8s, ld, ntm, Bs, n_pad, hdr, q, L_pad);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t ea = hipFuncSetAttribute((const void*)k_vara_i8, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * TILE_BYTES);
+        if (ea != hipSuccess) return eagle_fail_hip(ctx, ea, "hipFuncSetAttribute(k_vara_i8)");
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k_vara_i8, dim3((unsigned)(groups * 8 * smax)), dim3(512), 5 * TILE_BYTES, s, Mt8s, ld, ntm, Bs, n_pad, hdr, q, L_pad);
     hipLaunchKernelGGL(k_vara_i8_finish, dim3((unsigned)((L_pad + 255) / 256)), dim3(256), 0, s, q, L_pad, hdr, vdiag, cshift, mrho, vara_out);
     if (err_bound_dev) hipLaunchKernelGGL(k_vara_i8_bound, dim3(1), dim3(1), 0, s, hdr, err_bound_dev, (int*)nullptr);
     hipError_t e = hipGetLastError();
