@@ -911,7 +911,10 @@ __global__ __launch_bounds__(1024) void k_gemv_mfma(const int8_t* __restrict__ M
                 long long hx = s >= 4 ? vx << (8 * (s - 4)) : 0, lx = s < 4 ? vx << (8 * s) : 0;
 #pragma unroll
                 for (int o = 1; o < 8; o <<= 1) { hx += __shfl_xor(hx, o); lx += __shfl_xor(lx, o); }
-                if (r == 0) out_x[g * 16 + 4 * q + e] = sx * ((double)hx * 4294967296.0 + (double)lx);
+                if (r == 0) {
+                    const double xv = sx * ((double)hx * 4294967296.0 + (double)lx);
+                    out_x[g * 16 + 4 * q + e] = accumulate ? out_x[g * 16 + 4 * q + e] + xv : xv;
+                }
             }
         }
     }
@@ -919,8 +922,7 @@ __global__ __launch_bounds__(1024) void k_gemv_mfma(const int8_t* __restrict__ M
 
 // a = scale * Mt8 v, d_i = sum_j Mt8[i][j]^2 w[j] and (x != NULL) out_x = Mt8 x in one pass over the genotypes (w may be
 // NULL: no d; out_a may be NULL: no a).  Individuals beyond GV_MAXN columns are taken in further sweeps of GV_MAXN columns
-// that add into the outputs; the third vector rides along only while both LDS images fit (n_pad <= 5120), else it takes
-// a sweep of its own.
+// that add into the outputs (5120 columns per sweep when the third vector's second LDS image rides along).
 extern "C" int eagle_dev_gemv3_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* v,
                                   const double* w, const double* x, double scale, double* out_a, double* out_d, double* out_x, void* stream) {
     if (L_pad % 16 || n_pad % 256 || ld % 16 || n_pad > ld) return eagle_fail(ctx, EAGLE_ERR_ARG, "gemv_i8: layout contract violated (L_pad % 16, n_pad % 256, ld % 16)");
@@ -942,10 +944,13 @@ extern "C" int eagle_dev_gemv3_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad,
     long blocks = 256;
     const long groups = L_pad / 16;
     if (blocks > (groups + 15) / 16) blocks = (groups + 15) / 16;
-    if (x && w && n_pad <= 5120) {
-        hipLaunchKernelGGL(k_slice_vec, dim3(1), dim3(1024), 0, (hipStream_t)stream, v, w, x, (int)n_pad, B, exps);
-        hipLaunchKernelGGL((k_gemv_mfma<true, true>), dim3((unsigned)blocks), dim3(1024), (size_t)32 * n_pad, (hipStream_t)stream, Mt8, L_pad, (int)n_pad,
-                           ld, B, exps, scale, out_a, out_d, out_x, 0);
+    if (x && w) {  // three vectors: two 16-row LDS images, 5120 individuals per sweep; every genotype byte is still read once
+        for (long k0 = 0; k0 < n_pad; k0 += GV_MAXN / 2) {
+            const int nk = (int)(n_pad - k0 < GV_MAXN / 2 ? n_pad - k0 : GV_MAXN / 2);
+            hipLaunchKernelGGL(k_slice_vec, dim3(1), dim3(1024), 0, (hipStream_t)stream, v + k0, w + k0, x + k0, nk, B, exps);
+            hipLaunchKernelGGL((k_gemv_mfma<true, true>), dim3((unsigned)blocks), dim3(1024), (size_t)32 * nk, (hipStream_t)stream, Mt8 + k0, L_pad, nk,
+                               ld, B, exps, scale, out_a, out_d, out_x, k0 > 0);
+        }
         LAUNCH_CHECK(ctx);
         return EAGLE_OK;
     }
