@@ -358,6 +358,44 @@ def test_large_n_device_path(api, oracle):
     assert float(mx) == float(MMt.max())
 
 
+@pytest.mark.parametrize("n,L", [(1, 1), (2, 7), (15, 33), (17, 300), (255, 64), (256, 257), (257, 1000), (300, 1), (511, 513), (640, 129)])
+def test_ragged_small_shapes(n, L, api, oracle, tmp_path):
+    """Sizes around every padding / tile boundary (1, 16, 256) through the reference-shaped entry points, all modes:
+    MM^T and ReadBlock bit-exact, a / vara / reduced a against the oracle, same selected marker."""
+    rng = np.random.default_rng(1000 * n + L)
+    maf = rng.uniform(0.0, 0.5, size=L)
+    Mt8 = (rng.binomial(2, maf[:, None], size=(L, n)) - 1).astype(np.int8)
+    geno = synth.write_geno_pair(str(tmp_path), Mt8)
+    A = rng.standard_normal((n, max(1, n // 3))) / 4.0
+    S = np.eye(n) + A @ A.T
+    V = 0.7 * np.eye(n) - 0.05 * (A[:, :1] @ A[:, :1].T)
+    ahat = rng.standard_normal(n)
+    P = np.eye(n) * 0.3 + 0.01 * (A @ A.T)
+    y = rng.standard_normal((n, 1))
+    assert np.array_equal(api.calculateMMt_rcpp(geno["asciifileM"], 8.0, 2, NA, (n, L)),
+                          oracle.calculateMMt_rcpp(geno["asciifileM"], 8.0, 2, NA, (n, L)))
+    np.testing.assert_array_equal(api.ReadBlock(geno["asciifileMt"], 0, n, L), Mt8.astype(np.float64))
+    ref = oracle.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat)
+    tsq_ref, idx_ref, _ = oracle.tsq_argmax(ref["a"], ref["vara"])
+    vs = np.abs(ref["vara"]).max()
+    try:
+        for mode in (1, 0):
+            api.set_scan_mode(mode)
+            res = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat)
+            _close(res["a"], ref["a"])
+            rt = RTOL_DIGITS if mode == 1 else RTOL
+            # monomorphic markers have vara = c^2 1'W1 in both; everything is compared with the absolute floor of the budget
+            np.testing.assert_allclose(res["vara"].ravel(), ref["vara"].ravel(), rtol=rt, atol=rt * 1e-3 * vs)
+            idx, _, near = api.last_scan_argmax()
+            assert idx == idx_ref or near > 1
+    finally:
+        api.set_scan_mode(1)
+    ar = api.calculate_reduced_a_rcpp(geno["asciifileMt"], 0.8, P, y, 8.0, (n, L), NA)
+    ar_ref = oracle.calculate_reduced_a_rcpp(geno["asciifileMt"], 0.8, P, y, 8.0, (n, L), NA)
+    _close(ar, ar_ref)
+    api.drop_cache()
+
+
 def test_vara_rare_variants_and_monomorphic_markers(api, oracle):
     """Markers that are almost constant over the individuals, against a W that annihilates constants (a model with an
     intercept): their vara is orders of magnitude below the diagonal term of the raw g-1 coding.  The digit-slice kernel
