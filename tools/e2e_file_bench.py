@@ -65,6 +65,23 @@ def main():
             t = time.perf_counter(); r = scan2(); out["scan_streamed_sidecar%s_s" % env] = time.perf_counter() - t
         os.environ.pop("EAGLE_HIP_SIDECAR"); os.environ.pop("EAGLE_HIP_MAX_RESIDENT_GB")
         out["sidecar_bytes"] = os.path.getsize(mt2 + ".e2b")
+        # ReadMarker() on a whitespace-separated text table of the same genotypes (2 bytes per genotype)
+        G = (Mt8.T + 1).astype(np.uint8)                      # n x L codes 0/1/2
+        txt = np.empty((n, 2 * L), dtype=np.uint8)
+        txt[:, 0::2] = G + ord("0")
+        txt[:, 1::2] = ord(" ")
+        txt[:, -1] = ord("\n")
+        raw = os.path.join(d, "geno.txt")
+        txt.tofile(raw)
+        del txt, G
+        from eagleeverything_amd import r_api
+        rd = os.path.join(d, "rm")
+        os.mkdir(rd)
+        rcpp_api.drop_cache()
+        t = time.perf_counter(); g2 = r_api.ReadMarker(raw, type="text", AA=0, AB=1, BB=2, outdir=rd); out["ReadMarker_text_s"] = time.perf_counter() - t
+        out["ReadMarker_input_bytes"] = os.path.getsize(raw)
+        with open(g2["asciifileMt"], "rb") as fa, open(geno["asciifileMt"], "rb") as fb:
+            out["ReadMarker_Mt_identical"] = fa.read() == fb.read()
         out["scan_cold_markers_per_s"] = L / out["scan_cold_s"]
         out["scan_warm_markers_per_s"] = L / out["scan_warm_s"]
         out["file_bytes_each"] = os.path.getsize(geno["asciifileM"])
