@@ -405,6 +405,34 @@ __global__ __launch_bounds__(256) void k_colgemv(const double* __restrict__ At, 
     if (w == 0) out[i] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
+// The same product with the j range cut into gridDim.y parts (more workgroups than 64-column strips: an n x n matrix is
+// only n/64 strips wide): part[y][i] holds the partial sum of part y; k_colgemv_sum adds the parts in a fixed order.
+__global__ __launch_bounds__(256) void k_colgemv_part(const double* __restrict__ At, long n, long np, const double* __restrict__ x,
+                                                      double* __restrict__ part) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + lane;
+    const long per = ((n + gridDim.y - 1) / gridDim.y + 3) / 4 * 4;
+    const long j0 = (long)blockIdx.y * per, j1 = j0 + per < n ? j0 + per : n;
+    double s0 = 0, s1 = 0;
+    long j = j0 + w;
+    for (; j + 4 < j1; j += 8) {
+        s0 += At[j * np + i] * x[j];
+        s1 += At[(j + 4) * np + i] * x[j + 4];
+    }
+    for (; j < j1; j += 4) s0 += At[j * np + i] * x[j];
+    __shared__ double red[4][64];
+    red[w][lane] = s0 + s1;
+    __syncthreads();
+    if (w == 0) part[(long)blockIdx.y * np + i] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+__global__ __launch_bounds__(256) void k_colgemv_sum(const double* __restrict__ part, long np, int nparts, double* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= np) return;
+    double s = part[i];
+    for (int y = 1; y < nparts; y++) s += part[(long)y * np + i];
+    out[i] = s;
+}
+
 __global__ __launch_bounds__(256) void k_extract_col(const int8_t* __restrict__ M8, long n, long ld, long col, int* __restrict__ out) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = (int)M8[i * ld + col];
@@ -733,7 +761,9 @@ extern "C" int eagle_dev_scan_operands(eagle_ctx* ctx, const double* Sa, const d
     // v = S a_hat ; Sa is the row-major image of S^T, so v_i = sum_j Sa[j][i] a_hat[j]
     hipError_t e = hipMemsetAsync(v_out, 0, sizeof(double) * n_pad, s);
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "scan_operands memset");
-    hipLaunchKernelGGL(k_colgemv, dim3((unsigned)(n_pad / 64)), dim3(256), 0, s, Sa, n, n_pad, ahat, v_out);
+    // (tmp is free until the first product writes it: 8 partial vectors live there)
+    hipLaunchKernelGGL(k_colgemv_part, dim3((unsigned)(n_pad / 64), 8), dim3(256), 0, s, Sa, n, n_pad, ahat, tmp);
+    hipLaunchKernelGGL(k_colgemv_sum, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, s, tmp, n_pad, 8, v_out);
     LAUNCH_CHECK(ctx);
     // symmetric operands (every Eagle run): W = S V S is symmetric and only its upper 128-tiles are computed
     int* sym = (int*)eagle_ctx_scratch(ctx);
@@ -762,7 +792,9 @@ extern "C" int eagle_dev_scan_operands_rows(eagle_ctx* ctx, const double* Sa, co
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(v_out, 0, sizeof(double) * n_pad, s);
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "scan_operands memset");
-    hipLaunchKernelGGL(k_colgemv, dim3((unsigned)(n_pad / 64)), dim3(256), 0, s, Sa, n, n_pad, ahat, v_out);
+    // (tmp is free until the first product writes it: 8 partial vectors live there)
+    hipLaunchKernelGGL(k_colgemv_part, dim3((unsigned)(n_pad / 64), 8), dim3(256), 0, s, Sa, n, n_pad, ahat, tmp);
+    hipLaunchKernelGGL(k_colgemv_sum, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, s, tmp, n_pad, 8, v_out);
     LAUNCH_CHECK(ctx);
     const int rt0 = (int)(row0 / GF_T), rt1 = (int)(row1 / GF_T);
     int rc = gemm_f64_tiles(ctx, Sa, Va, tmp, n_pad, 0, nullptr, 0, stream, rt0, rt1);
