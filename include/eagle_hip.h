@@ -235,8 +235,8 @@ int eagle_dev_vara_f64(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad
                        double* vara_out, void* stream);
 /* Same result from int8 digit slices of the off-diagonal part of Wu on the int8 MFMA (exact integer partial sums)
  * plus the fp64 diagonal term.  nslices: 0 = automatic (see eagle_set_scan_slices), 1..8 = fixed.
- * ws: workspace, eagle_vara_i8_workspace_bytes(n_pad, L_pad, nslices) bytes; its first 32 bytes are written by the
- * device as { double max|offdiag|; int32 S_used; int32 pad; double bound; double sum|diag| }.
+ * ws: workspace, eagle_vara_i8_workspace_bytes(n_pad, L_pad, nslices) bytes; its first 48 bytes are written by the
+ * device as { double max|offdiag|; int32 S_used; int32 pad; double bound; double sum|diag|; double R = sum_{j<k} Wu_jk }.
  * err_bound_dev (device double, may be NULL): the absolute error bound n_pad^2 * 2^(e+1-8S) of every vara_i. */
 int64_t eagle_vara_i8_workspace_bytes(long n_pad, long L_pad, int nslices);
 /* The same in two phases, so that one pass over the genotype bytes serves both a = Mt8 v (if v != NULL; written to
