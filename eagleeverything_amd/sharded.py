@@ -46,10 +46,21 @@ class Collectives:
             fn(t)
         return t
 
-    def sum_partial_mmt(self, c32):
-        """In-place sum of the int32 partial MM^T tensors of all ranks (exact)."""
+    def sum_partial_mmt(self, c32, tile=256):
+        """In-place sum of the int32 partial MM^T tensors of all ranks (exact).  Only the 256 x 256 tiles on or above the
+        diagonal are live (the kernels never write the others), so only those travel: half the bytes of the matrix."""
         if self.world > 1:
-            self._staged(c32, lambda x: self.dist.all_reduce(x, op=self.dist.ReduceOp.SUM))
+            np_ = c32.shape[0]
+            if c32.dim() == 2 and c32.shape[1] == np_ and np_ % tile == 0 and np_ // tile > 1:
+                nt = np_ // tile
+                import torch
+                iu = torch.triu_indices(nt, nt, device=c32.device)
+                tiles = c32.view(nt, tile, nt, tile).permute(0, 2, 1, 3)       # [ti][tj][tile][tile] view
+                packed = tiles[iu[0], iu[1]].contiguous()                      # upper tiles only
+                self._staged(packed, lambda x: self.dist.all_reduce(x, op=self.dist.ReduceOp.SUM))
+                tiles[iu[0], iu[1]] = packed
+            else:
+                self._staged(c32, lambda x: self.dist.all_reduce(x, op=self.dist.ReduceOp.SUM))
         return c32
 
     def all_gather_rows(self, full, mine):

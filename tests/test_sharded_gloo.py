@@ -52,6 +52,17 @@ def _worker(rank, world, port, case, out_dir):
         sel, best = coll.best_marker(mx, gidx0)
         assert sel == int(g["argmax"]), (sel, int(g["argmax"]))
         np.testing.assert_allclose(best, float(g["tsqmax"]), rtol=1e-9)
+        # the same sum when only the upper 256-tiles of a padded partial are live (what the kernels produce): the lower
+        # tiles do not travel and stay untouched
+        big = torch.zeros((512, 512), dtype=torch.int32)
+        big[:n, :n] = torch.from_numpy(part.copy())
+        big[256:, :256] = -7 - rank                                    # dead tile: must neither travel nor change
+        coll.sum_partial_mmt(big)
+        exp = np.zeros((512, 512), dtype=np.int64)
+        exp[:n, :n] = g["MMt"]
+        got = big.numpy().astype(np.int64)
+        assert np.array_equal(got[:256, :], exp[:256, :]) and np.array_equal(got[256:, 256:], exp[256:, 256:])
+        assert np.all(got[256:, :256] == -7 - rank)
         # shared W: every rank computes its row block of S V S, one all-gather completes the image
         W = g["S"] @ (g["V"] @ g["S"])
         rows = 64
