@@ -101,3 +101,29 @@ def test_am_hip_selects_same_markers_as_oracle(oracle, golden, tmp_path):
     assert hip["all_picks"] == ref["all_picks"] and hip["selected_loci"] == ref["selected_loci"]
     np.testing.assert_allclose(hip["extBIC_trace"], ref["extBIC_trace"], rtol=1e-9)
     assert len(hip["all_picks"]) >= 2
+
+
+@pytest.mark.gpu
+def test_readmarker_to_am_end_to_end(oracle, golden, tmp_path):
+    """BASELINE configs[0] in this build's terms: the reference's demo genotypes as a whitespace-separated 0/1/2 table
+    (what MyPackage/genoDemo.dat is) -> ReadMarker() -> AM(), every hot call on the GPU; the oracle-backed loop on
+    oracle-converted files must pick the same markers with the same extBIC trace."""
+    from eagleeverything_amd import r_api
+    g = golden("genoDemo_150x4998")
+    raw = tmp_path / "genoDemo.dat"
+    with open(raw, "w") as f:
+        for row in (g["M8"] + 1):
+            f.write(" ".join(map(str, row)) + "\n")
+    d_hip, d_ref = tmp_path / "hip", tmp_path / "ref"
+    d_hip.mkdir(), d_ref.mkdir()
+    geno = r_api.ReadMarker(str(raw), type="text", AA=0, AB=1, BB=2, outdir=str(d_hip))
+    assert geno is not None and geno["dim_of_ascii_M"] == [150, 4998]
+    dims = oracle.getRowColumn(str(raw))
+    ok, _ = oracle.createM_ASCII_rcpp(str(raw), str(d_ref / "M.ascii"), "text", 0, 1, 2, 8, dims)
+    assert ok
+    oracle.createMt_ASCII_rcpp(str(d_ref / "M.ascii"), str(d_ref / "Mt.ascii"), "text", 8, dims)
+    geno_ref = {"asciifileM": str(d_ref / "M.ascii"), "asciifileMt": str(d_ref / "Mt.ascii"), "dim_of_ascii_M": dims}
+    ref = am.AM(g["y"], g["X"], geno_ref, maxit=5, backend=OracleBackend(oracle))
+    hip = am.AM(g["y"], g["X"], geno, maxit=5)
+    assert hip["all_picks"] == ref["all_picks"] and hip["selected_loci"] == ref["selected_loci"]
+    np.testing.assert_allclose(hip["extBIC_trace"], ref["extBIC_trace"], rtol=1e-9)
