@@ -94,6 +94,74 @@ __global__ __launch_bounds__(G::NW * 64) void k_tile(const int8_t* __restrict__ 
 }
 
 
+
+// G1p: 4 waves 2x2, wave tile 128x128 (256 accumulators, one wave per SIMD) with the fragments of k-step ks+1 loaded while
+// the 16 MFMAs of k-step ks issue (register double buffering: the single wave of a SIMD has no partner to hide LDS latency).
+template <class G>
+__global__ __launch_bounds__(256) void k_tile_g1p(const int8_t* __restrict__ A, const int8_t* __restrict__ B, long ld, int nstages,
+                                                   int* __restrict__ C, long ldc) {
+    extern __shared__ __attribute__((aligned(1024))) int8_t lds[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = w >> 1, wc = w & 1;
+    const int ldi = (int)ld;
+    const int voffE = (lane >> 3) * ldi + (((lane & 7) ^ (lane >> 4)) << 4);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (long)blockIdx.y * G::TM * ld), 0, G::TM * ldi, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(B + (long)blockIdx.x * G::TN * ld), 0, G::TN * ldi, 0x00020000);
+    i32x16 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < 4; n++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[m][n][q] = 0;
+    const int r = lane & 31, h = lane >> 5, swz = (r >> 1) & 7;
+    stage_tile<G>(rsA, voffE, ldi, 0, lds, G::TM, w);
+    stage_tile<G>(rsB, voffE, ldi, 0, lds + G::A_BYTES, G::TN, w);
+    __syncthreads();
+    int cur = 0;
+    i32x4 a[2][4], b[2][4];
+    auto load_frags = [&](int slot, const int8_t* base, int ks) {
+        const int ch = ((2 * ks + h) ^ swz) << 4;
+        const int8_t* pa = base + (wr * 128 + r) * BK;
+        const int8_t* pb = base + G::A_BYTES + (wc * 128 + r) * BK;
+#pragma unroll
+        for (int m = 0; m < 4; m++) a[slot][m] = *(const i32x4*)(pa + m * 32 * BK + ch);
+#pragma unroll
+        for (int n = 0; n < 4; n++) b[slot][n] = *(const i32x4*)(pb + n * 32 * BK + ch);
+    };
+    load_frags(0, lds, 0);
+    for (int st = 0; st < nstages; st++) {
+        int8_t* nb = lds + (cur ^ 1) * G::STAGE;
+        if (st + 1 < nstages) {
+            stage_tile<G>(rsA, voffE, ldi, (st + 1) * BK, nb, G::TM, w);
+            stage_tile<G>(rsB, voffE, ldi, (st + 1) * BK, nb + G::A_BYTES, G::TN, w);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            if (ks < 3) load_frags((ks + 1) & 1, lds + cur * G::STAGE, ks + 1);
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int n = 0; n < 4; n++) acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ks & 1][m], b[ks & 1][n], acc[m][n], 0, 0, 0);
+        }
+        __syncthreads();
+        cur ^= 1;
+        if (st + 1 < nstages) load_frags(0, lds + cur * G::STAGE, 0);
+    }
+    const int col = lane & 31, rq = 4 * (lane >> 5);
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < 4; n++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                long i = (long)blockIdx.y * G::TM + (wr * 4 + m) * 32 + (q & 3) + 8 * (q >> 2) + rq;
+                long j = (long)blockIdx.x * G::TN + (wc * 4 + n) * 32 + col;
+                C[i * ldc + j] = acc[m][n][q];
+            }
+}
+
 // Same engine on v_mfma_i32_16x16x64_i8: wave tile (WM*16) x (WN*16), two K=64 steps per 128-byte stage.
 template <class G, int WM, int WN>
 __global__ __launch_bounds__(G::NW * 64) void k_tile16(const int8_t* __restrict__ A, const int8_t* __restrict__ B, long ld, int nstages,
@@ -188,6 +256,39 @@ static void run(const char* name, const int8_t* dA, const int8_t* dB, long ld, i
            ops / best / 1e9, bad ? "WRONG" : "ok");
 }
 
+static void run_g1p(const int8_t* dA, const int8_t* dB, long ld, int K, int Mrows, int Nrows, int* dC, const std::vector<int8_t>& hA,
+                    const std::vector<int8_t>& hB) {
+    using G = Geo<2, 2, 4, 4>;
+    const int gx = Nrows / G::TN, gy = Mrows / G::TM;
+    const size_t ldsb = 2 * (size_t)G::STAGE;
+    auto kern = k_tile_g1p<G>;
+    CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    float best = 1e9;
+    const long ldc = (long)gx * G::TN;
+    for (int rep = 0; rep < 4; rep++) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), ldsb, 0, dA, dB, ld, K / BK, dC, ldc);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        CHECK(hipGetLastError());
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep && ms < best) best = ms;
+    }
+    std::vector<int> hC((size_t)8 * ldc);
+    CHECK(hipMemcpy(hC.data(), dC + (long)(gy * G::TM - 8) * ldc, hC.size() * sizeof(int), hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (int ii = 0; ii < 8; ii++)
+        for (long j = 0; j < ldc; j += 97) {
+            long i = (long)gy * G::TM - 8 + ii;
+            int s = 0;
+            for (int k = 0; k < K; k++) s += (int)hA[i * ld + k] * (int)hB[j * ld + k];
+            if (s != hC[(size_t)ii * ldc + j]) bad++;
+        }
+    double ops = 2.0 * gy * G::TM * (double)gx * G::TN * K;
+    printf("G1p (register double-buffered fragments): %.3f ms  %.0f TOP/s  (%s)\n", best, ops / best / 1e9, bad ? "WRONG" : "ok");
+}
+
 int main() {
     const int K = 5120;
     const long ld = K;
@@ -205,6 +306,7 @@ int main() {
         run<2, 4, 4, 2>("G0", dA, dB, ld, K, Mrows, Nrows, dC, hA, hB);
         run<2, 4, 4, 2, true>("G0/16x16x64", dA, dB, ld, K, Mrows, Nrows, dC, hA, hB);
         run<2, 2, 4, 4>("G1", dA, dB, ld, K, Mrows, Nrows, dC, hA, hB);
+        run_g1p(dA, dB, ld, K, Mrows, Nrows, dC, hA, hB);
         run<2, 2, 4, 5>("G2b", dA, dB, ld, K, Mrows, 320 * 48, dC, hA, hB);
         run<2, 2, 4, 6>("G2", dA, dB, ld, K, Mrows, Nrows, dC, hA, hB);
     }
