@@ -396,6 +396,37 @@ def test_ragged_small_shapes(n, L, api, oracle, tmp_path):
     api.drop_cache()
 
 
+def test_fuzz_random_shapes(api, oracle, tmp_path):
+    """Random (n, L) below (900, 3000), random allele frequencies incl. monomorphic markers, either coding of the common
+    allele, and every fourth case a W that annihilates constants: MM^T bit-exact, a to 1e-9, vara to the digit budget."""
+    rng0 = np.random.default_rng(2024)
+    for it in range(16):
+        n, L = int(rng0.integers(1, 900)), int(rng0.integers(1, 3000))
+        rng = np.random.default_rng(it)
+        maf = rng.uniform(0.0, 0.5, size=L)
+        Mt8 = (rng.binomial(2, maf[:, None], size=(L, n)) - 1).astype(np.int8)
+        if it % 3 == 0:
+            Mt8 = -Mt8
+        d = tmp_path / ("c%d" % it)
+        d.mkdir()
+        geno = synth.write_geno_pair(str(d), Mt8)
+        A = rng.standard_normal((n, max(1, n // 3))) / 4.0
+        S = np.eye(n) + A @ A.T
+        V = 0.7 * np.eye(n) - 0.05 * (A[:, :1] @ A[:, :1].T)
+        if it % 4 == 1:
+            P1 = np.eye(n) - np.ones((n, n)) / n
+            V, S = P1 @ V @ P1, 0.8 * np.eye(n)
+        ahat = rng.standard_normal(n)
+        assert np.array_equal(api.calculateMMt_rcpp(geno["asciifileM"], 8.0, 2, NA, (n, L)),
+                              oracle.calculateMMt_rcpp(geno["asciifileM"], 8.0, 2, NA, (n, L))), (n, L)
+        ref = oracle.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat)
+        res = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat)
+        _close(res["a"], ref["a"])
+        vs = np.abs(ref["vara"]).max()
+        np.testing.assert_allclose(res["vara"], ref["vara"], rtol=RTOL_DIGITS, atol=RTOL_DIGITS * 1e-4 * vs, err_msg=str((n, L)))
+        api.drop_cache()
+
+
 def test_vara_rare_variants_and_monomorphic_markers(api, oracle):
     """Markers that are almost constant over the individuals, against a W that annihilates constants (a model with an
     intercept): their vara is orders of magnitude below the diagonal term of the raw g-1 coding.  The digit-slice kernel
