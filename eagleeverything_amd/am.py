@@ -73,14 +73,15 @@ def _zeroin(f, a, b, tol=_EPS25, maxit=1000):
 
 
 def emma_eigen_L_wo_Z(K):
-    ev, U = np.linalg.eigh(K)
+    ev, U = host_model.algebra().eigh(K)
     return {"values": ev[::-1].copy(), "vectors": U[:, ::-1].copy()}  # R's eigen(): decreasing order
 
 
 def emma_eigen_R_wo_Z(K, X):
     n, q = X.shape
+    la = host_model.algebra()
     S = np.eye(n) - X @ np.linalg.solve(X.T @ X, X.T)
-    ev, U = np.linalg.eigh(S @ (K + np.eye(n)) @ S)
+    ev, U = la.eigh(la.mm(la.mm(S, K + np.eye(n)), S))
     ev, U = ev[::-1], U[:, ::-1]
     return {"values": ev[: n - q] - 1.0, "vectors": U[:, : n - q].copy()}
 
@@ -206,12 +207,14 @@ class HipBackend:
                                        device=self.device).astype(np.int64)
 
 
-def AM(trait, X, geno, availmemGb=8, ncpu=1, maxit=20, quiet=True, backend=None, message=None):
+def AM(trait, X, geno, availmemGb=8, ncpu=1, maxit=20, quiet=True, backend=None, message=None, algebra=None):
     """E/R/AM.R:400-475 for a complete-data trait vector and a ready design matrix X (n x q, intercept included).
 
     Returns dict(selected_loci = 1-based marker columns in order of selection, extBIC = list, ve, vg of the last fit).
     selected_loci starts as [NA] exactly like AM.R:260, so the selected_loci masking never fires."""
     backend = backend or HipBackend()
+    if algebra is not None:  # "host" (LAPACK, the reference's placement) or "device" (SURVEY 8 f-4, rocSOLVER through torch)
+        host_model.set_algebra(algebra)
     say = message or (lambda *_: None)
     trait = np.asarray(trait, dtype=np.float64).ravel()
     currentX = np.asarray(X, dtype=np.float64)

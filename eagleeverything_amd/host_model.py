@@ -1,9 +1,11 @@
-"""Host-side dense n x n model algebra that feeds the marker scan (stays on the host by design).
+"""Dense n x n model algebra that feeds the marker scan.
 
 north_star keeps calculateH / calculateP / the eigendecomposition of MM^T on host LAPACK; in the R
 package these are base-R calls.  This numpy restatement exists so that the scan can be driven with
 realistic operands (S = MMt^-1/2, V = Var(a_hat), a_hat) on a box without R.  It is *not* part of
-the GPU hot path and is not a fallback for it.
+the GPU hot path and is not a fallback for it.  Host LAPACK is the default; set_algebra("device") moves the
+O(n^3) primitives (eigh, chol2inv, inv, n x n products) to the GPU through torch.linalg -- SURVEY 8 f-4, the Amdahl
+term of a full AM() run once the scan takes 30 ms -- without changing a formula.
 
 Reference lines (E/ = MyPackage/Eagle/):
   calculateH ........................ E/R/calculateH.R:36
@@ -17,6 +19,70 @@ import numpy as np
 import scipy.linalg as sla
 
 
+class _HostLA:
+    """The O(n^3) primitives of this module on host LAPACK / BLAS (the default, as north_star asks)."""
+    name = "host"
+
+    @staticmethod
+    def eigh(A):
+        return np.linalg.eigh(A)
+
+    @staticmethod
+    def chol2inv(A):
+        c, low = sla.cho_factor(A, lower=False, check_finite=False)
+        return sla.cho_solve((c, low), np.eye(A.shape[0]), check_finite=False)
+
+    @staticmethod
+    def inv(A):
+        return np.linalg.inv(A)
+
+    @staticmethod
+    def mm(A, B):
+        return A @ B
+
+
+class _DeviceLA:
+    """the same primitives on the GPU through torch.linalg (rocSOLVER syevd / potrf / getrf, rocBLAS dgemm).
+    Library calls, not kernels of this repository; opt-in (set_algebra("device")).  numpy in, numpy out."""
+    name = "device"
+
+    def __init__(self, device=0):
+        import torch
+        self.torch = torch
+        self.dev = torch.device("cuda", device)
+
+    def _t(self, A):
+        return self.torch.as_tensor(np.ascontiguousarray(A), dtype=self.torch.float64, device=self.dev)
+
+    def eigh(self, A):
+        w, U = self.torch.linalg.eigh(self._t(A))
+        return w.cpu().numpy(), U.cpu().numpy()
+
+    def chol2inv(self, A):
+        c = self.torch.linalg.cholesky(self._t(A))
+        return self.torch.cholesky_inverse(c).cpu().numpy()
+
+    def inv(self, A):
+        return self.torch.linalg.inv(self._t(A)).cpu().numpy()
+
+    def mm(self, A, B):
+        return (self._t(A) @ self._t(B)).cpu().numpy()
+
+
+_la = _HostLA()
+
+
+def set_algebra(kind="host", device=0):
+    """"host" (default) or "device": where eigh / chol2inv / inv / n x n products of the model algebra run."""
+    global _la
+    _la = _DeviceLA(device) if kind == "device" else _HostLA()
+    return _la.name
+
+
+def algebra():
+    return _la
+
+
 def calculateH(MMt, varE, varG):
     if varE < 0 or varG < 0:
         raise ValueError("variance components cannot be negative")  # calculateH.R:19-30
@@ -25,8 +91,7 @@ def calculateH(MMt, varE, varG):
 
 
 def _chol2inv(A):
-    c, low = sla.cho_factor(A, lower=False, check_finite=False)
-    return sla.cho_solve((c, low), np.eye(A.shape[0]), check_finite=False)
+    return _la.chol2inv(A)
 
 
 def calculateP(H, X):
@@ -39,14 +104,14 @@ def calculateP(H, X):
 
 def calculateMMt_sqrt_and_sqrtinv(MMt, checkres=True):
     """eigen(MMt, symmetric=TRUE); sqrt = U diag(sqrt(l)) U^T ; invsqrt = chol2inv(chol(sqrt))."""
-    evals, U = np.linalg.eigh(MMt)
+    evals, U = _la.eigh(MMt)
     if evals.min() <= 0:
         raise ValueError("M %*% t(M) is not positive definite")  # :15-23
-    sq = (U * np.sqrt(evals)) @ U.T
+    sq = _la.mm(U * np.sqrt(evals), U.T)
     sq = 0.5 * (sq + sq.T)
     inv = _chol2inv(sq)
     if checkres:  # :35-46
-        tr = np.trace(sq @ inv)
+        tr = float(np.sum(sq * inv.T))  # trace(sq @ inv) without the n^3 product
         if int(np.trunc(tr)) != MMt.shape[0]:
             import warnings
             warnings.warn("sqrt(MMt) %*% invsqrt(MMt) trace = %r, expected %d" % (tr, MMt.shape[0]))
@@ -56,7 +121,7 @@ def calculateMMt_sqrt_and_sqrtinv(MMt, checkres=True):
 def calculate_reduced_a(varG, P, MMtsqrt, y):
     if P.shape[0] != np.size(y):
         raise ValueError("dimension mismatch between P and y")
-    return varG * (MMtsqrt @ (P @ np.ravel(y)))
+    return varG * (MMtsqrt @ (P @ np.ravel(y)))  # two matrix-vector products
 
 
 def calculate_reduced_vara(X, varE, varG, invMMt, MMtsqrt):
@@ -68,8 +133,8 @@ def calculate_reduced_vara(X, varE, varG, invMMt, MMtsqrt):
     A = r1 * (X.T @ X)
     B = r1 * (X.T @ Ze)
     Cm = r1 * (Ze.T @ X)
-    D = r1 * (Ze.T @ Ze) + g1 * np.eye(n)
-    D1 = np.linalg.inv(D)
+    D = r1 * _la.mm(Ze.T, Ze) + g1 * np.eye(n)
+    D1 = _la.inv(D)
     D1C = D1 @ Cm
     BD1 = B @ D1
     mid = np.linalg.solve(A - B @ D1C, BD1)

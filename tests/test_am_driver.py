@@ -127,3 +127,28 @@ def test_readmarker_to_am_end_to_end(oracle, golden, tmp_path):
     hip = am.AM(g["y"], g["X"], geno, maxit=5)
     assert hip["all_picks"] == ref["all_picks"] and hip["selected_loci"] == ref["selected_loci"]
     np.testing.assert_allclose(hip["extBIC_trace"], ref["extBIC_trace"], rtol=1e-9)
+
+
+@pytest.mark.gpu
+def test_am_device_algebra_matches_host_algebra(golden, tmp_path):
+    """SURVEY 8 f-4 (opt-in): eigh / chol2inv / inv / n x n products of the model algebra on the GPU through torch.linalg;
+    the AM loop picks the same markers and the extBIC trace agrees to 1e-8 with host LAPACK."""
+    g = golden("genoDemo_150x4998")
+    geno = synth.write_geno_pair(str(tmp_path), np.ascontiguousarray(g["M8"].T))
+    try:
+        host = am.AM(g["y"], g["X"], geno, maxit=5, algebra="host")
+        dev = am.AM(g["y"], g["X"], geno, maxit=5, algebra="device")
+    finally:
+        host_model.set_algebra("host")
+    assert dev["all_picks"] == host["all_picks"] and dev["selected_loci"] == host["selected_loci"]
+    np.testing.assert_allclose(dev["extBIC_trace"], host["extBIC_trace"], rtol=1e-8)
+    # the pieces themselves
+    MMtn = g["MMt"] / g["MMt"].max() + 0.95 * np.eye(150)
+    ops_h = host_model.scan_operands(MMtn, g["X"], g["y"], 1.0, 0.5)
+    host_model.set_algebra("device")
+    try:
+        ops_d = host_model.scan_operands(MMtn, g["X"], g["y"], 1.0, 0.5)
+    finally:
+        host_model.set_algebra("host")
+    for k in ("S", "V", "ahat", "P"):
+        np.testing.assert_allclose(ops_d[k], ops_h[k], rtol=1e-8, atol=1e-10 * np.abs(ops_h[k]).max())
