@@ -303,6 +303,10 @@ def main():
         rel = lambda x, r: float(np.max(np.abs(x - r)) / np.max(np.abs(r)))
         parity = {"a_max_rel": rel(a_g, a_ref), "vara_max_rel": float(np.max(np.abs(v_g - vara_ref) / np.abs(vara_ref))),
                   "sample_argmax_equal": bool(np.argmax(a_g ** 2 / v_g) == np.argmax(a_ref ** 2 / vara_ref))}
+        # SURVEY 8(d) parity gate run with every measurement: north_star's tolerance is 1e-6 relative on the score statistics
+        parity["gate"] = {"a_rel_tol": 1e-9, "vara_rel_tol": 1e-7 if sh.mode else 1e-9, "north_star_tol": 1e-6}
+        parity["gate"]["passed"] = bool(parity["a_max_rel"] <= parity["gate"]["a_rel_tol"] and
+                                        parity["vara_max_rel"] <= parity["gate"]["vara_rel_tol"] and parity["sample_argmax_equal"])
         # MM^T baseline on a marker subsample, scaled linearly in L
         nm = min(16384, Lloc)
         M_s = np.ascontiguousarray(sh.Mt8[:nm, :n].cpu().numpy().T)
