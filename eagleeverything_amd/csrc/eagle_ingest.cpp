@@ -400,7 +400,6 @@ static int create_M_plink(eagle_ctx* ctx, const char* fname, const char* asciifn
     (void)sc.open_for(ctx, asciifname, nlines, L, chunk_rows);
     RowError err;          // unequal number of columns (found on the host)
     unsigned long long h_flags[2] = {~0ull, ~0ull};
-    long written = 0;
     for (long r0 = 0; r0 < nlines; r0 += chunk_rows) {
         const long nr = std::min(chunk_rows, nlines - r0);
         char* cin = (char*)ctx->stage_pin[0];
@@ -441,11 +440,9 @@ static int create_M_plink(eagle_ctx* ctx, const char* fname, const char* asciifn
             if (h_flags[0] != ~0ull) ok_rows = (long)(h_flags[0] / (unsigned long long)L) - r0;  // the reference stops inside that row
             if (ok_rows > 0 && !pwrite_all(fdout, (const char*)ctx->stage_pin[1], (size_t)ok_rows * out_stride, (off_t)r0 * out_stride, threads))
                 return failf(ctx, EAGLE_ERR_OPEN, "ERROR: could not write %s", asciifname);
-            written = r0 + std::max(0L, ok_rows);
         }
         if (err.row >= 0 || h_flags[0] != ~0ull) break;
     }
-    (void)written;
     const bool allele_err = h_flags[0] != ~0ull;
     const unsigned long long stop = allele_err ? h_flags[0] : (err.row >= 0 ? (unsigned long long)err.row * (unsigned long long)L : ~0ull);
     if (h_flags[1] != ~0ull && h_flags[1] < stop) {                                              // :112-121, printed once
