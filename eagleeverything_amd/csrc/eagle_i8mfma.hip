@@ -104,6 +104,8 @@ __device__ __forceinline__ void t8_compute(i32x16 (&acc)[4][2], const int8_t* ld
 // 5.39 vs 5.41 ms, bit-identical result.  With the fill bytes quartered and the time unchanged the fill rate is not the
 // whole story either: every variant lands on the same ~2.5 POP/s, where MFMA-busy x clock is what the chip sustains on
 // random int8 operands (1.9 GHz at 55 % busy here; the guide's LDS-read + MFMA loops hold 1.5-1.7 GHz when denser).
+// Splitting a worker's column-tile pairs over 2 / 5 workgroups (fewer marker tiles resident per XCD, so that their genotype
+// panels stay in L2 across the column tiles): -1 % / -7 % (22.6 -> 22.9 / 24.2 ms), the W-digit tiles then have fewer sharers.
 // tools/ubench/fill_rate.hip measures what bounds it: filling 64 KiB of LDS takes 1.15-1.2 us per CU when every line
 // is an L2 hit and 3.1 us when every line comes from HBM, by LDS-DMA and by register staging alike; at the 72-82 %
 // hit rate of these kernels (rocprofv3 TCC_HIT/TCC_REQ) that is 1.5-1.7 us per stage against 0.9-1.1 us of MFMA work.
