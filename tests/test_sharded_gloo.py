@@ -102,3 +102,64 @@ def test_pick_best_rules():
     assert pick_best([1.0, 3.0, 3.0], [5, 9, 2]) == (3, 3.0)
     assert pick_best([np.nan, np.nan], [-1, -1])[0] == 0
     assert pick_best([np.inf, 2.0], [4, 1]) == (5, np.inf)
+
+
+def _gpu_worker(rank, world, port, out_dir):
+    """Two ranks sharing cuda:0 (collectives through the host over gloo): the device-resident sharded path end to end."""
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from eagleeverything_amd.sharded import DeviceShard
+        n, Lloc = 640, 3000                      # 5 x 128-row tiles of W: world 2 does not divide them -> replicated W
+        n2 = 512                                 # 4 tiles: shared W path
+        for nn in (n, n2):
+            rng = np.random.default_rng(7)
+            Mt8 = (rng.binomial(2, rng.uniform(0.02, 0.5, size=(world * Lloc, 1)), size=(world * Lloc, nn)) - 1).astype(np.int8)
+            A = rng.standard_normal((nn, 24)) / 6.0
+            S = np.eye(nn) + A @ A.T
+            V = 0.6 * np.eye(nn) - 0.04 * (A[:, :3] @ A[:, :3].T)
+            ahat = rng.standard_normal(nn)
+            coll = Collectives(dist)
+            sh = DeviceShard(nn, Lloc, first_marker=rank * Lloc, device=0)
+            sh.Mt8.zero_()
+            sh.Mt8[:Lloc, :nn] = torch.from_numpy(Mt8[rank * Lloc:(rank + 1) * Lloc]).cuda()
+            c32 = sh.mmt_partial()
+            coll.sum_partial_mmt(c32)
+            MMt, mx = sh.mmt_finish(c32)
+            assert np.array_equal(MMt.cpu().numpy(), (Mt8.astype(np.int64).T @ Mt8.astype(np.int64)).astype(np.float64))
+            Sd = torch.from_numpy(S).cuda() if rank == 0 else torch.empty((nn, nn), dtype=torch.float64, device="cuda")
+            Vd = torch.from_numpy(V).cuda() if rank == 0 else torch.empty((nn, nn), dtype=torch.float64, device="cuda")
+            ad = torch.from_numpy(ahat).cuda() if rank == 0 else torch.empty(nn, dtype=torch.float64, device="cuda")
+            for t in (Sd, Vd, ad):
+                coll.broadcast_(t)
+            sh.set_operands(Sd, Vd, ad)
+            sh.mode = 1
+            sh.scan(coll)
+            tsqmax, gidx, _ = sh.best()
+            sel, best = coll.best_marker(tsqmax, gidx, device=sh.dev)
+            # reference: fp64 numpy on the whole marker set
+            W = S @ V @ S
+            a = Mt8.astype(np.float64) @ (S @ ahat)
+            vara = np.einsum("ij,jk,ik->i", Mt8.astype(np.float64), W, Mt8.astype(np.float64))
+            tsq = a * a / vara
+            assert sel == int(np.nanargmax(tsq)) + 1, (nn, sel, int(np.nanargmax(tsq)) + 1)
+            np.testing.assert_allclose(best, np.nanmax(tsq), rtol=1e-7)
+            mine = slice(rank * Lloc, (rank + 1) * Lloc)
+            np.testing.assert_allclose(sh.vara[:Lloc].cpu().numpy(), vara[mine], rtol=1e-7, atol=1e-10 * np.abs(vara).max())
+            np.testing.assert_allclose(sh.a[:Lloc].cpu().numpy(), a[mine], rtol=1e-9, atol=1e-12 * np.abs(a).max())
+        open(os.path.join(out_dir, "gpu_ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_two_ranks_on_one_gpu(tmp_path):
+    """The rehearsal of bench.py --gpus 2 as a test: exact MM^T through the packed all-reduce, W shared by rows (n = 512) and
+    replicated (n = 640), per-shard scans and the global arg-max against fp64 numpy."""
+    world = 2
+    mp.spawn(_gpu_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / ("gpu_ok%d" % r)).exists() for r in range(world))
