@@ -1172,6 +1172,11 @@ __global__ __launch_bounds__(512, 2) void k_syrk_f4(const uint8_t* __restrict__ 
             }
 }
 
+static long ctx_cu_count(eagle_ctx* ctx) {
+    int cu = 0;
+    (void)eagle_device_info(ctx, nullptr, 0, &cu, nullptr);
+    return cu > 0 ? cu : 256;
+}
 // C32[np][np] += M M^T over the marker columns [0, L_pad) of the fp4 image M4[n_pad][ld4 bytes] (eagle_dev_pack_fp4 of M8).
 extern "C" int eagle_dev_mmt_accumulate_f4(eagle_ctx* ctx, const void* M4, long n_pad, long L_pad, long ld4, int32_t* C32, void* stream) {
     if (n_pad % T8 || L_pad % 256 || ld4 % 128 || L_pad > ld4 * 2 || n_pad <= 0 || (double)ld4 * T8 >= 2147483648.0)
@@ -1184,6 +1189,17 @@ extern "C" int eagle_dev_mmt_accumulate_f4(eagle_ctx* ctx, const void* M4, long 
     long maxsplit = nstages / 16 > 0 ? nstages / 16 : 1;
     long nsplit = want < maxsplit ? want : maxsplit;
     if (nsplit < 1) nsplit = 1;
+    {   // one workgroup per CU: among the split counts near `want`, take the one whose last wave of workgroups is fullest
+        const long slots = ctx_cu_count(ctx);
+        double best = 1e30;
+        long pick = nsplit;
+        for (long sp = nsplit > 4 ? nsplit - 4 : 1; sp <= nsplit + 4 && sp <= maxsplit; sp++) {
+            const long B = npairs * sp;
+            const double waste = (double)((B + slots - 1) / slots * slots) / (double)B;
+            if (waste < best - 1e-9) { best = waste; pick = sp; }
+        }
+        nsplit = pick;
+    }
     long per = (nstages + nsplit - 1) / nsplit;
     if (per * 256 >= (1L << 24)) per = (1L << 24) / 256 - 1;  // fp32 partial sums stay exact integers
     nsplit = (nstages + per - 1) / per;
