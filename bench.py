@@ -201,15 +201,25 @@ def main():
         return coll.best_marker(tsqmax, gidx, device=dev)
 
     if world > 1:
-        # pre-flight of the shared-W collective (every rank takes the same branch: the failure of a collective is symmetric);
-        # the replicated computation of W is the fallback and is reported in config.parallelism
-        try:
-            sel = step()
-            torch.cuda.synchronize(dev)
-        except Exception as exc:  # noqa: BLE001
-            if rank == 0:
-                print("bench.py: shared-W all-gather failed (%s); every rank computes W itself" % exc, file=sys.stderr)
-            sh.share_w = False
+        # W = S V S either shared (each rank 1/N of its rows + one all-gather) or replicated on every rank: which is faster
+        # depends on the links between the N GPUs, so both are timed before the warm-up (2 untimed steps each; every rank sees
+        # the same max-over-ranks times and takes the same branch).  A failing collective leaves the replicated form.
+        w_times = {}
+        for share in (True, False):
+            sh.share_w = share
+            try:
+                sel = step()
+                barrier()
+                tw = time.perf_counter()
+                sel = step()
+                sel = step()
+                barrier()
+                w_times[share] = max_over_ranks(time.perf_counter() - tw)
+            except Exception as exc:  # noqa: BLE001
+                if rank == 0:
+                    print("bench.py: shared-W all-gather failed (%s); every rank computes W itself" % exc, file=sys.stderr)
+                w_times[share] = float("inf")
+        sh.share_w = w_times[True] <= w_times[False]
     for _ in range(args.warmup):
         sel = step()
     barrier()
