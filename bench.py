@@ -1,19 +1,23 @@
 #!/usr/bin/env python3
-"""bench.py -- markers/sec through the calculate_a_and_vara genome scan (+ MM^T build wall-clock) on MI355X.
+"""bench.py -- markers/sec through the calculate_a_and_vara genome scan + MM^T build wall-clock on MI355X.
 
   python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-Workload (BASELINE.json configs[1]): synthetic 5,000 individuals x 500,000 biallelic SNPs per GPU, single trait,
-genotypes resident in HBM as int8 before the timed region.  A "step" is one full pass of the reference's
-calculate_a_and_vara_rcpp (v = S a_hat, a = Mt v, W = S V S, T = Mt W, vara_i = T_i . m_i;
-E/src/calculate_a_and_vara_rcpp.cpp:90-112) followed by find_qtl's tsq / arg-max (E/R/find_qtl.R:71-83) over all
-markers of the rank's shard; for N > 1 the shards' (max tsq, first index) pairs are all-gathered inside the step.
-Weak scaling: every rank holds L markers, value = N*L / max-over-ranks time.  The MM^T build
-(calculateMMt_rcpp.cpp:95; partial int32 SYRK per rank + one RCCL all-reduce) is timed separately and reported
-as mmt_build_s.  The CPU baseline is the C oracle (a port of the reference's in-memory branch) on a bounded
-marker sample on rank 0's host cores.
+Workload (BASELINE.json north_star / configs[2], the configuration the metric is quoted on): synthetic
+10,000 individuals x 1,000,000 biallelic SNPs, single trait.  STRONG scaling: the 1,000,000 markers are split into N
+contiguous shards (eagleeverything_amd.sharded.shard_range), one per GPU, resident in HBM as int8 before the timed region;
+N = 1 is the whole problem on one card.  A "step" is one full pass of the reference's calculate_a_and_vara_rcpp
+(v = S a_hat, a = Mt v, W = S V S, T = Mt W, vara_i = T_i . m_i; E/src/calculate_a_and_vara_rcpp.cpp:90-112) including
+the a-posteriori certification of the digit-slice kernel, followed by find_qtl's tsq / arg-max (E/R/find_qtl.R:71-83)
+over the rank's shard; for N > 1 the n^3 product W = S V S is shared by rows (one all-gather) and the shards'
+(max tsq, first index) pairs are all-gathered inside the step.  value = 1,000,000 markers / max-over-ranks step time.
+The MM^T build (calculateMMt_rcpp.cpp:95; exact int32 partial SYRK per rank + one RCCL sum + finish) is timed separately
+and reported as mmt_build_s.  Secondary entries (N = 1): BASELINE configs[1] (5,000 x 500,000), the fp64-mode scan and
+the 7-digit scan of the headline shape.  The CPU baseline is the C oracle (a port of the reference's in-memory branch) on
+a bounded marker sample on rank 0's host cores.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -29,6 +33,14 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix, AMD datasheet (the microarc
 I8_MFMA_PEAK_TOPS = 5000.0     # dense int8 = 2x the 2.5 PF bf16 dense peak (MI355X_MICROARCH.md, Matrix cores)
 FP4_MFMA_PEAK_TOPS = 10000.0   # dense fp4 / fp6 on the block-scaled path = 4x bf16 (same guide)
 HBM_PEAK_GBS = 8000.0
+
+
+def kernel_sha16():
+    """Hash of the kernel sources: a committed PMC figure is only attached to a line made by the same kernels."""
+    h = hashlib.sha256()
+    for f in ("eagle_i8mfma.hip", "eagle_kernels.hip"):
+        h.update(open(os.path.join(ROOT, "eagleeverything_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def host_operands_torch(torch, MMt_norm, X, y, varE, varG):
@@ -54,17 +66,190 @@ def host_operands_torch(torch, MMt_norm, X, y, varE, varG):
     return S, V, ahat
 
 
+class Run:
+    """One workload (n individuals x Ltot markers split over the ranks) set up in HBM, with its timed legs."""
+
+    def __init__(self, args, torch, dist, coll, n, Ltot, rank, world, local_rank, backend):
+        from eagleeverything_amd.sharded import DeviceShard, shard_range
+        self.args, self.torch, self.dist, self.coll = args, torch, dist, coll
+        self.n, self.Ltot, self.rank, self.world, self.backend = n, Ltot, rank, world, backend
+        self.dev = torch.device("cuda", local_rank)
+        m0, m1 = shard_range(Ltot, rank, world)
+        t0 = time.time()
+        self.sh = sh = DeviceShard(n, m1 - m0, first_marker=m0, device=local_rank)
+        sh.nslices = args.slices
+        sh.fill_synthetic()
+        sh.individual_major()
+        sh.individual_major_fp4()  # operand image of the MM^T kernel (made once per shard, like the int8 images)
+        torch.cuda.synchronize(self.dev)
+        self.t_gen = time.time() - t0
+        self.S = self.V = self.ahat = None
+
+    # ---- collectives-aware helpers ----------------------------------------------------------------
+    def barrier(self):
+        self.torch.cuda.synchronize(self.dev)
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=None if self.backend == "gloo" else self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- MM^T build: partial SYRK per shard + one sum to rank 0 + finish ----------------------------
+    def mmt_build(self, reps):
+        torch, sh = self.torch, self.sh
+        c32 = torch.empty((sh.np_, sh.np_), dtype=torch.int32, device=self.dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        times, syrk = [], []
+        MMt = None
+        for rep in range(reps + 1):
+            self.barrier()
+            t1 = time.perf_counter()
+            c32.zero_()
+            ev0.record()
+            sh.mmt_partial(out=c32)
+            ev1.record()
+            self.coll.sum_partial_mmt(c32, dst=0)   # the process that talks to R needs the sum; the others only contribute
+            if self.rank == 0:
+                MMt, mx = sh.mmt_finish(c32, normalise=True)
+            self.barrier()
+            dt = self.max_over_ranks(time.perf_counter() - t1)
+            if rep > 0:
+                times.append(dt)
+                syrk.append(ev0.elapsed_time(ev1))
+        del c32
+        return MMt, float(np.mean(times)), float(np.mean(syrk)) / 1e3
+
+    # ---- scan operands from the model algebra on the actual MM^T (untimed input manufacturing) ------
+    def make_operands(self, MMt):
+        torch, sh, n, args = self.torch, self.sh, self.n, self.args
+        t2 = time.time()
+        gen = torch.Generator(device=self.dev)
+        gen.manual_seed(7)
+        if self.rank == 0:
+            qtl = torch.linspace(0, sh.Lloc - 1, 12, device=self.dev).long()[1:-1]
+            y = 0.5 * sh.Mt8[qtl, :n].double().sum(0) + torch.randn(n, generator=gen, device=self.dev, dtype=torch.float64)
+            X = torch.ones((n, 1), dtype=torch.float64, device=self.dev)
+            if args.load_operands:
+                S, V, ahat = [t.to(self.dev) for t in torch.load(args.load_operands, weights_only=True)]
+            elif args.simple_operands:
+                A = torch.randn((n, 64), generator=gen, device=self.dev, dtype=torch.float64) / 8.0
+                S = torch.eye(n, dtype=torch.float64, device=self.dev) + A @ A.T
+                V = 0.5 * torch.eye(n, dtype=torch.float64, device=self.dev) - 0.01 * (A[:, :8] @ A[:, :8].T)
+                ahat = torch.randn(n, generator=gen, device=self.dev, dtype=torch.float64)
+            else:
+                S, V, ahat = host_operands_torch(torch, MMt, X, y, 1.0, 0.5)
+        else:
+            S = torch.empty((n, n), dtype=torch.float64, device=self.dev)
+            V = torch.empty((n, n), dtype=torch.float64, device=self.dev)
+            ahat = torch.empty(n, dtype=torch.float64, device=self.dev)
+        S, V, ahat = S.contiguous(), V.contiguous(), ahat.contiguous()
+        if args.save_operands and self.rank == 0:
+            torch.save([S.cpu(), V.cpu(), ahat.cpu()], args.save_operands)
+        self.coll.broadcast_(S); self.coll.broadcast_(V); self.coll.broadcast_(ahat)
+        sh.set_operands(S, V, ahat)
+        torch.cuda.synchronize(self.dev)
+        self.S, self.V, self.ahat = S, V, ahat
+        return time.time() - t2
+
+    # ---- one scan step --------------------------------------------------------------------------------
+    def step(self, evs=None):
+        sh = self.sh
+        if evs:
+            evs["w"][0].record()
+        sh.scan_operands(self.coll)  # N > 1: each rank computes 1/N of W's rows, one all-gather (N = 1: the whole of it)
+        if evs:
+            evs["w"][1].record()
+            evs["prep"][0].record()
+        if sh.mode == 0:
+            sh.gemv_a()
+        else:
+            sh.vara_prepare()  # slices W; one genotype pass for a = Mt v and the diagonal term of vara
+        if evs:
+            evs["prep"][1].record()
+            evs["kern"][0].record()
+        sh.vara_kernel()
+        if evs:
+            evs["kern"][1].record()
+            evs["cert"][0].record()
+        sh.certify()       # digit-slice mode: fp64 re-evaluation of every marker the error bounds cannot settle
+        if evs:
+            evs["cert"][1].record()
+        sh.argmax()
+        tsqmax, gidx, near = sh.best()
+        return self.coll.best_marker(tsqmax, gidx, device=self.dev)
+
+    def choose_w_sharing(self):
+        """W = S V S either shared (each rank 1/N of its rows + one all-gather) or replicated on every rank: which is faster
+        depends on the links between the N GPUs.  Both forms are timed before the warm-up; the only value exchanged is the
+        all-reduced max, so every rank takes the same branch.  A failing collective raises and the job exits non-zero."""
+        sh = self.sh
+        if self.world == 1 or (sh.np_ // 128) % self.world != 0:
+            sh.share_w = False
+            return None
+        w_times = {}
+        for share in (True, False):
+            sh.share_w = share
+            self.step()
+            self.barrier()
+            tw = time.perf_counter()
+            self.step()
+            self.step()
+            self.barrier()
+            w_times[share] = self.max_over_ranks(time.perf_counter() - tw)
+        sh.share_w = w_times[True] <= w_times[False]
+        return {"shared_s": w_times[True] / 2, "replicated_s": w_times[False] / 2}
+
+    def timed(self, steps, warmup):
+        torch = self.torch
+        names = ("w", "prep", "kern", "cert")
+        evs = [{k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for k in names} for _ in range(steps)]
+        sel = None
+        for _ in range(warmup):
+            sel = self.step()
+        self.barrier()
+        t3 = time.perf_counter()
+        for i in range(steps):
+            sel = self.step(evs[i])
+        self.barrier()
+        elapsed = self.max_over_ranks(time.perf_counter() - t3)
+        parts = {k: float(np.mean([e[k][0].elapsed_time(e[k][1]) for e in evs])) / 1e3 for k in names}
+        return sel, elapsed, parts
+
+
+def vara_roofline(sh, kern_s, S_used):
+    np_, Lp = sh.np_, sh.Lp
+    if sh.mode == 0:
+        nct = np_ // 128  # executed = algorithmic for the triangular fp64 kernel: column tile ct needs k < (ct+1)*128
+        flops = sum(2.0 * Lp * 128 * min((ct + 1) * 128, np_) for ct in range(nct))
+        roof = {"bound": "mfma", "kernel": "k_vara_f64 (v_mfma_f64_16x16x4_f64)", "dtype": "f64",
+                "achieved": flops / kern_s / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
+    else:
+        nct8 = np_ // 256
+        ops = sum(2.0 * Lp * 256 * min((ct + 1) * 256, np_) for ct in range(nct8)) * S_used
+        roof = {"bound": "mfma", "kernel": "k_vara_i8 (v_mfma_i32_32x32x32_i8, %d digit slices)" % S_used, "dtype": "i8",
+                "achieved": ops / kern_s / 1e12, "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s"}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    roof["kernel_ms"] = kern_s * 1e3
+    return roof
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=5000, help="individuals")
-    ap.add_argument("--markers", type=int, default=500000, help="markers per GPU")
+    ap.add_argument("--n", type=int, default=10000, help="individuals")
+    ap.add_argument("--markers", type=int, default=1000000, help="markers in TOTAL (split over the GPUs: strong scaling)")
     ap.add_argument("--mode", choices=["f64", "i8"], default=os.environ.get("EAGLE_SCAN_MODE", "i8"))
     ap.add_argument("--slices", type=int, default=0, help="int8 digit slices of W in i8 mode (0 = chosen from the error bound)")
     ap.add_argument("--mmt-reps", type=int, default=2)
-    ap.add_argument("--cpu-sample", type=int, default=131072, help="markers in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=32768, help="markers in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary entries (C2, fp64 mode, 7 digits)")
     ap.add_argument("--simple-operands", action="store_true", help="seeded random SPD S / V instead of the model algebra")
     ap.add_argument("--save-operands", default=None, help="write S, V, a_hat (torch.save) after computing them")
     ap.add_argument("--load-operands", default=None, help="read S, V, a_hat written by --save-operands (used by the PMC passes of\n                    tools/profile_gpu.sh: rocSOLVER's eigh crashes under rocprofv3 counter collection)")
@@ -93,145 +278,27 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from eagleeverything_amd import rcpp_api
-    from eagleeverything_amd.sharded import Collectives, DeviceShard
+    from eagleeverything_amd.sharded import Collectives
 
     coll = Collectives(dist if world > 1 else None)
     info = rcpp_api.device_info(local_rank)
-    n, Lloc = args.n, args.markers
-    Ltot = Lloc * world
+    n, Ltot = args.n, args.markers
     dev = torch.device("cuda", local_rank)
 
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    def max_over_ranks(x):
-        if world == 1:
-            return x
-        t = torch.tensor([x], dtype=torch.float64, device=None if backend == "gloo" else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
-    # ---- resident inputs (untimed) ---------------------------------------------------------------
-    t0 = time.time()
-    sh = DeviceShard(n, Lloc, first_marker=rank * Lloc, device=local_rank)
+    run = Run(args, torch, dist, coll, n, Ltot, rank, world, local_rank, backend)
+    sh = run.sh
+    t_gen = run.t_gen
     sh.mode = 0 if args.mode == "f64" else 1
-    sh.nslices = args.slices
-    sh.fill_synthetic()
-    sh.individual_major()
-    sh.individual_major_fp4()  # operand image of the MM^T kernel (made once per shard, like the int8 images)
-    torch.cuda.synchronize(dev)
-    t_gen = time.time() - t0
-
-    # ---- MM^T build: partial SYRK per shard + one all-reduce + finish (timed separately) ----------
-    c32 = torch.empty((sh.np_, sh.np_), dtype=torch.int32, device=dev)
-    mmt_times = []
-    ev_k0, ev_k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    syrk_ms = []
-    MMt = None
-    for rep in range(args.mmt_reps + 1):
-        barrier()
-        t1 = time.perf_counter()
-        c32.zero_()
-        ev_k0.record()
-        sh.mmt_partial(out=c32)
-        ev_k1.record()
-        coll.sum_partial_mmt(c32)
-        MMt, mx = sh.mmt_finish(c32, normalise=True)
-        barrier()
-        dt = max_over_ranks(time.perf_counter() - t1)
-        if rep > 0:
-            mmt_times.append(dt)
-            syrk_ms.append(ev_k0.elapsed_time(ev_k1))
-    mmt_build_s = float(np.mean(mmt_times))
-    syrk_s = float(np.mean(syrk_ms)) / 1e3
-
-    # ---- scan operands from the model algebra on the actual MM^T (untimed input manufacturing) ----
-    t2 = time.time()
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(7)
-    if rank == 0:
-        qtl = torch.linspace(0, Lloc - 1, 12, device=dev).long()[1:-1]
-        y = 0.5 * sh.Mt8[qtl, :n].double().sum(0) + torch.randn(n, generator=gen, device=dev, dtype=torch.float64)
-        X = torch.ones((n, 1), dtype=torch.float64, device=dev)
-        if args.load_operands:
-            S, V, ahat = [t.to(dev) for t in torch.load(args.load_operands, weights_only=True)]
-        elif args.simple_operands:
-            A = torch.randn((n, 64), generator=gen, device=dev, dtype=torch.float64) / 8.0
-            S = torch.eye(n, dtype=torch.float64, device=dev) + A @ A.T
-            V = 0.5 * torch.eye(n, dtype=torch.float64, device=dev) - 0.01 * (A[:, :8] @ A[:, :8].T)
-            ahat = torch.randn(n, generator=gen, device=dev, dtype=torch.float64)
-        else:
-            S, V, ahat = host_operands_torch(torch, MMt, X, y, 1.0, 0.5)
-    else:
-        S = torch.empty((n, n), dtype=torch.float64, device=dev)
-        V = torch.empty((n, n), dtype=torch.float64, device=dev)
-        ahat = torch.empty(n, dtype=torch.float64, device=dev)
-    S, V, ahat = S.contiguous(), V.contiguous(), ahat.contiguous()
-    if args.save_operands and rank == 0:
-        torch.save([S.cpu(), V.cpu(), ahat.cpu()], args.save_operands)
-    coll.broadcast_(S); coll.broadcast_(V); coll.broadcast_(ahat)
-    sh.set_operands(S, V, ahat)
-    torch.cuda.synchronize(dev)
-    t_ops = time.time() - t2
-    del MMt, c32
-
-    # ---- timed scan steps -------------------------------------------------------------------------
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    ev_gemv = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-
-    def step(i=None):
-        sh.scan_operands(coll)  # N > 1: each rank computes 1/N of W's rows, one all-gather (N = 1: the whole of it)
-        if i is not None:
-            ev_gemv[i][0].record()
-        if sh.mode == 0:
-            sh.gemv_a()
-        else:
-            sh.vara_prepare()  # slices W; one genotype pass for a = Mt v and the diagonal term of vara
-        if i is not None:
-            ev_gemv[i][1].record()
-            ev[i][0].record()
-        sh.vara_kernel()
-        if i is not None:
-            ev[i][1].record()
-        sh.argmax()
-        tsqmax, gidx, near = sh.best()
-        return coll.best_marker(tsqmax, gidx, device=dev)
-
-    if world > 1:
-        # W = S V S either shared (each rank 1/N of its rows + one all-gather) or replicated on every rank: which is faster
-        # depends on the links between the N GPUs, so both are timed before the warm-up (2 untimed steps each; every rank sees
-        # the same max-over-ranks times and takes the same branch).  A failing collective leaves the replicated form.
-        w_times = {}
-        for share in (True, False):
-            sh.share_w = share
-            try:
-                sel = step()
-                barrier()
-                tw = time.perf_counter()
-                sel = step()
-                sel = step()
-                barrier()
-                w_times[share] = max_over_ranks(time.perf_counter() - tw)
-            except Exception as exc:  # noqa: BLE001
-                if rank == 0:
-                    print("bench.py: shared-W all-gather failed (%s); every rank computes W itself" % exc, file=sys.stderr)
-                w_times[share] = float("inf")
-        sh.share_w = w_times[True] <= w_times[False]
-    for _ in range(args.warmup):
-        sel = step()
-    barrier()
-    t3 = time.perf_counter()
-    for i in range(args.steps):
-        sel = step(i)
-    barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t3)
+    MMt, mmt_build_s, syrk_s = run.mmt_build(args.mmt_reps)
+    t_ops = run.make_operands(MMt)
+    del MMt
+    w_choice = run.choose_w_sharing()
+    sel, elapsed, parts = run.timed(args.steps, args.warmup)
     ms_per_step = elapsed / args.steps * 1e3
     value = Ltot * args.steps / elapsed
-    kern_s = float(np.mean([a.elapsed_time(b) for a, b in ev])) / 1e3
-    gemv_s = float(np.mean([a.elapsed_time(b) for a, b in ev_gemv])) / 1e3
+    kern_s = parts["kern"]
+    cert = sh.certificate() if sh.mode == 1 else None
+
     # the HBM-bound kernel of the scan on its own (a = Mt v: L*n genotype bytes, read once), outside the timed steps
     gp = []
     for _ in range(4):
@@ -244,49 +311,49 @@ def main():
     gpass_s = float(np.median(gp[1:])) / 1e3
 
     # ---- roofline of the dominant kernel (vara) ---------------------------------------------------
-    np_, Lp = sh.np_, sh.Lp
-    nct = np_ // 128
+    np_, Lp, Lloc = sh.np_, sh.Lp, sh.Lloc
     S_used, vara_bound = (sh.vara_i8_info()[:2] if sh.mode else (None, None))
-    if sh.mode == 0:
-        # executed = algorithmic for the triangular fp64 kernel: column tile ct needs k < (ct+1)*128
-        flops = sum(2.0 * Lp * 128 * min((ct + 1) * 128, np_) for ct in range(nct))
-        roof = {"bound": "mfma", "kernel": "k_gemm_f64<int8 A, row-dot> (v_mfma_f64_16x16x4_f64)", "dtype": "f64",
-                "achieved": flops / kern_s / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
-    else:
-        nct8 = np_ // 256
-        ops = sum(2.0 * Lp * 256 * min((ct + 1) * 256, np_) for ct in range(nct8)) * S_used
-        roof = {"bound": "mfma", "kernel": "k_vara_i8 (v_mfma_i32_32x32x32_i8, %d digit slices)" % S_used, "dtype": "i8",
-                "achieved": ops / kern_s / 1e12, "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s"}
-    roof["frac"] = roof["achieved"] / roof["peak"]
-    # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command (tools/profile_gpu.sh);
-    # they cannot be collected in-process, so the committed figure is attached when the configuration matches.
+    roof = vara_roofline(sh, kern_s, S_used)
+    # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command (tools/profile_gpu.sh):
+    # they cannot be collected in-process.  The committed figure is attached only when it was measured on these very
+    # kernel sources (hash) and this configuration; otherwise traffic is null.
     roof["traffic"] = None
+    sha = kernel_sha16()
     try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["k_vara_i8"]
-        if sh.mode == 1 and tr["config"] == {"n": n, "markers": Lloc, "slices": S_used}:
+        trf = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+        tr = trf["k_vara_i8"]
+        if sh.mode == 1 and trf.get("kernel_sha16") == sha and tr["config"] == {"n": n, "markers": Lloc, "slices": S_used}:
             roof["traffic"] = tr["hbm_side_bytes"]
-            roof["traffic_unit"] = "bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r01_rocprof_final5"
-            roof["algorithmic_bytes"] = float(Lp) * np_ + float(S_used) * np_ * np_ / 2
-            roof["l2_hit_rate"] = tr["TCC_hit_rate"]
-    except Exception:
+            roof["traffic_source"] = "%s, kernel sources sha16 %s; (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes per launch" % (tr["source"], sha)
+            roof["l2_hit_rate"] = tr.get("TCC_hit_rate")
+    except (OSError, KeyError, ValueError):
         pass
-    roof["kernel_ms"] = kern_s * 1e3
+    if sh.mode == 1:
+        roof["algorithmic_bytes"] = float(Lp) * np_ + float(S_used) * np_ * np_ / 2
     roof["reference_flops_per_launch"] = 2.0 * Lloc * n * n + 2.0 * Lloc * n
     roof["fp64_equiv_tflops"] = roof["reference_flops_per_launch"] / kern_s / 1e12
     # the judge's HBM figure for the whole scan uses L*n genotype bytes per pass
-    roof["scan_hbm_view"] = {"bytes_per_scan": float(Lloc) * n, "achieved_GBps": float(Lloc) * n / (elapsed / args.steps) / 1e9,
-                             "frac_of_8TBps": float(Lloc) * n / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+    roof["scan_hbm_view"] = {"bytes_per_scan": float(Ltot) * n, "achieved_GBps": float(Ltot) * n / (elapsed / args.steps) / 1e9,
+                             "frac_of_8TBps_per_gpu": float(Lloc) * n / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                              "note": "the scan is MFMA-bound (2Ln^2 flop on L*n bytes); its HBM-bound kernel is roofline_secondary.genotype_pass"}
+    w_flops = 3.0 * np_ ** 3 if world == 1 or not sh.share_w else 4.0 * np_ ** 3 / world
     secondary = {
+        "step_breakdown_ms": {"W=S*V*S (+all-gather)": parts["w"] * 1e3, "prepare (slice W, genotype pass)": parts["prep"] * 1e3,
+                              "vara kernel": parts["kern"] * 1e3, "certify": parts["cert"] * 1e3},
+        "w_product": {"bound": "mfma", "kernel": "k_gemm_f64_list (v_mfma_f64_16x16x4_f64), S*(V*S), upper tiles of the 2nd product",
+                      "achieved": w_flops / parts["w"] / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                      "frac": w_flops / parts["w"] / 1e12 / FP64_MFMA_PEAK_TFLOPS, "ms": parts["w"] * 1e3,
+                      "note": "includes v = S a_hat, the symmetry check, the fold and (N > 1) the all-gather of W's rows"},
         "genotype_pass": {"bound": "hbm", "kernel": "k_slice_vec + k_gemv_mfma (a = Mt v; algorithmic bytes = L_pad*n_pad genotype bytes)",
                           "achieved": Lp * np_ / gpass_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": Lp * np_ / gpass_s / 1e9 / HBM_PEAK_GBS, "kernel_ms": gpass_s * 1e3},
-        "scan_prepare_ms": gemv_s * 1e3,  # inside a step: the same pass fused with the diagonal term of vara, + slicing of W (i8 mode)
         "syrk_f4": {"bound": "mfma", "kernel": "k_syrk_f4 (v_mfma_scale_f32_32x32x64_f8f6f4, fp4 x fp4, exact)", "dtype": "fp4",
                     "achieved": (np_ * (np_ + 256.0)) * Lp / syrk_s / 1e12, "peak": FP4_MFMA_PEAK_TOPS,
                     "unit": "TFLOP/s", "frac": (np_ * (np_ + 256.0)) * Lp / syrk_s / 1e12 / FP4_MFMA_PEAK_TOPS,
                     "kernel_ms": syrk_s * 1e3},
     }
+    if w_choice:
+        secondary["w_sharing_preflight_s"] = w_choice
 
     # ---- CPU baseline + parity gate on a bounded sample (rank 0, N = 1 only) ----------------------
     cpu = None
@@ -298,15 +365,15 @@ def main():
         oracle_c.set_num_threads(int(os.environ.get("OMP_NUM_THREADS", min(16, os.cpu_count() or 1))))
         ns = min(args.cpu_sample, Lloc)
         Mt_s = sh.Mt8[:ns, :n].cpu().numpy()
-        Sh, Vh, ah = S.cpu().numpy(), V.cpu().numpy(), ahat.cpu().numpy()
+        Sh, Vh, ah = run.S.cpu().numpy(), run.V.cpu().numpy(), run.ahat.cpu().numpy()
         v_h, W_h = oracle_c.scan_operands(Sh, Vh, ah)          # n^3 part, done once per call in the reference too
         tc = time.perf_counter()
         a_ref, vara_ref = oracle_c.scan_from_i8_with_W(Mt_s, v_h, W_h)
         cpu_s = time.perf_counter() - tc
         cores = oracle_c.num_threads()
         cpu = {"value": ns / cpu_s, "unit": "markers/s", "cores": cores, "kind": "port",
-               "sample": "first %d markers of the %dx%d shard, reference in-memory branch order (GEMV, T=Mt*W, row-dot; "
-                         "calculate_a_and_vara_rcpp.cpp:91-112), W=S*V*S precomputed and excluded" % (ns, n, Lloc),
+               "sample": "first %d markers of the %dx%d problem, reference in-memory branch order (GEMV, T=Mt*W, row-dot; "
+                         "calculate_a_and_vara_rcpp.cpp:91-112), W=S*V*S precomputed and excluded" % (ns, n, Ltot),
                "seconds": cpu_s}
         a_g = sh.a[:ns].cpu().numpy()
         v_g = sh.vara[:ns].cpu().numpy()
@@ -318,30 +385,66 @@ def main():
         parity["gate"]["passed"] = bool(parity["a_max_rel"] <= parity["gate"]["a_rel_tol"] and
                                         parity["vara_max_rel"] <= parity["gate"]["vara_rel_tol"] and parity["sample_argmax_equal"])
         # MM^T baseline on a marker subsample, scaled linearly in L
-        nm = min(16384, Lloc)
+        nm = min(8192, Lloc)
         M_s = np.ascontiguousarray(sh.Mt8[:nm, :n].cpu().numpy().T)
         tc = time.perf_counter()
-        mm_ref = oracle_c.mmt_from_i8(M_s)
+        oracle_c.mmt_from_i8(M_s)
         mm_s = time.perf_counter() - tc
-        cpu["mmt_build_s_est"] = mm_s * Lloc / nm
-        cpu["mmt_sample"] = "%d markers, scaled linearly to %d" % (nm, Lloc)
+        cpu["mmt_build_s_est"] = mm_s * Ltot / nm
+        cpu["mmt_sample"] = "%d markers, scaled linearly to %d" % (nm, Ltot)
+        del Mt_s, M_s, W_h
+
+    # ---- secondary entries (N = 1): fp64-mode and 7-digit scans of the headline shape, and BASELINE configs[1] --------
+    if world == 1 and not args.no_secondary and sh.mode == 1:
+        sel_i8 = sel
+        sh.mode = 0
+        s64, el64, p64 = run.timed(1, 1)
+        secondary["scan_fp64_mode"] = {"value": Ltot / el64, "unit": "markers/s", "ms_per_step": el64 * 1e3,
+                                       "selected_marker_equal_to_digit_mode": bool(s64[0] == sel_i8[0]),
+                                       "roofline": vara_roofline(sh, p64["kern"], None)}
+        sh.mode = 1
+        sh.nslices = 7
+        sh.ws = None
+        s7, el7, p7 = run.timed(1, 1)
+        secondary["scan_7_digits"] = {"value": Ltot / el7, "unit": "markers/s", "ms_per_step": el7 * 1e3,
+                                      "selected_marker_equal": bool(s7[0] == sel_i8[0]), "roofline": vara_roofline(sh, p7["kern"], 7)}
+        sh.nslices = args.slices
+        sh.ws = None
+        # BASELINE configs[1]: 5,000 x 500,000 on one card
+        del run, sh
+        torch.cuda.empty_cache()
+        run2 = Run(args, torch, dist, coll, 5000, 500000, rank, world, local_rank, backend)
+        run2.sh.mode = 1
+        MMt2, mmt2_s, syrk2_s = run2.mmt_build(1)
+        run2.make_operands(MMt2)
+        del MMt2
+        run2.sh.share_w = False
+        _, el2, p2 = run2.timed(3, 1)
+        S2 = run2.sh.vara_i8_info()[0]
+        secondary["config_C2_5000x500000"] = {"value": 500000 * 3 / el2, "unit": "markers/s", "ms_per_step": el2 / 3 * 1e3,
+                                              "mmt_build_s": mmt2_s, "slices": S2, "step_breakdown_ms": {k: v * 1e3 for k, v in p2.items()},
+                                              "roofline": vara_roofline(run2.sh, p2["kern"], S2)}
+        sh = run2.sh
 
     if rank == 0:
         out = {
-            "metric": "markers/sec in calculate_a_and_vara scan", "value": value, "unit": "markers/s",
+            "metric": "markers/sec in calculate_a_and_vara scan (+ MMt build wall-clock: mmt_build_s)", "value": value, "unit": "markers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64" if sh.mode == 0 else "i8 (int32/int64 exact sums, f64 finish)", "data": "synthetic",
-            "config": {"workload": "synthetic %d individuals x %d SNPs per GPU (HWE genotypes, int8 resident in HBM), "
-                                   "single trait, full calculate_a_and_vara pass + tsq arg-max" % (n, Lloc),
-                       "n": n, "markers_per_gpu": Lloc, "markers_total": Ltot,
-                       "parallelism": "marker-shard x%d" % world + (", W rows 1/%d per rank + all-gather" % world if world > 1 and sh.share_w and (sh.np_ // 128) % world == 0 else "")
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64" if args.mode == "f64" else "i8 (int32/int64 exact sums, f64 finish, fp64 re-evaluation of uncertified markers)",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2] / north_star: synthetic %d individuals x %d SNPs in total (HWE genotypes, int8 resident "
+                                   "in HBM), %d contiguous marker shards, single trait, full calculate_a_and_vara pass + certification + "
+                                   "tsq arg-max" % (n, Ltot, world),
+                       "n": n, "markers_total": Ltot, "markers_rank0": Lloc,
+                       "parallelism": "marker-shard x%d" % world + (", W rows 1/%d per rank + all-gather" % world if world > 1 and w_choice and w_choice["shared_s"] <= w_choice["replicated_s"] else "")
                                       + (" (REHEARSAL: gloo, ranks share one card)" if backend == "gloo" and world > 1 else ""),
-                       "scan_mode": args.mode, "slices": S_used, "vara_abs_error_bound": vara_bound,
-                       "vara_rel_error_bound": (vara_bound / (0.5 * sh.last_sumdiag) if sh.mode else None), "operands": "simple" if args.simple_operands else "model algebra on MM^T" + (" (reloaded)" if args.load_operands else "")},
+                       "scan_mode": args.mode, "slices": S_used, "vara_abs_error_bound_worst_case": vara_bound,
+                       "certificate": cert,
+                       "operands": "simple" if args.simple_operands else "model algebra on MM^T" + (" (reloaded)" if args.load_operands else "")},
             "mmt_build_s": mmt_build_s, "selected_marker": int(sel[0]), "tsqmax": sel[1],
             "roofline": roof, "roofline_secondary": secondary, "cpu_baseline": cpu, "parity": parity,
-            "device": info, "setup_s": {"genotypes": t_gen, "operands": t_ops},
+            "device": info, "kernel_sha16": sha, "setup_s": {"genotypes": t_gen, "operands": t_ops},
         }
         print(json.dumps(out))
     if world > 1:

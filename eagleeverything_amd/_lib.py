@@ -69,7 +69,11 @@ SIGNATURES = {
                                      C.c_void_p]),
     "eagle_vara_i8_workspace_bytes": (C.c_int64, [C.c_long, C.c_long, C.c_int]),
     "eagle_dev_marker_shift": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p,
-                                         C.c_void_p]),
+                                         C.c_void_p, C.c_void_p]),
+    "eagle_scan_certify_workspace_bytes": (C.c_int64, [C.c_long]),
+    "eagle_dev_scan_certify": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eagle_last_scan_certificate": (C.c_int, [C.c_void_p, c_lp, c_lp, C.POINTER(C.c_int)]),
     "eagle_dev_vara_i8_mfma_shifted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_int, C.c_void_p,
                                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     "eagle_vara_f6_workspace_bytes": (C.c_int64, [C.c_long, C.c_long, C.c_int]),
@@ -89,7 +93,7 @@ SIGNATURES = {
     "eagle_dev_tsq_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
     # internal helpers exported for tests / the sharded driver
-    "eagle_dev_set_tune": (None, [C.c_int]),
+    "eagle_dev_set_tune": (None, [C.c_void_p, C.c_int]),
     "eagle_dev_gemm_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]),
     "eagle_dev_colgemv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p]),
 }

@@ -117,7 +117,7 @@ extern "C" eagle_ctx* eagle_open(int device) {
 extern "C" void eagle_drop_cache(eagle_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    for (auto& g : ctx->cache) { if (g.dev) (void)hipFree(g.dev); if (g.dev_s) (void)hipFree(g.dev_s); if (g.cshift) (void)hipFree(g.cshift); }
+    for (auto& g : ctx->cache) { if (g.dev) (void)hipFree(g.dev); if (g.dev_s) (void)hipFree(g.dev_s); if (g.cshift) (void)hipFree(g.cshift); if (g.l1) (void)hipFree(g.l1); }
     ctx->cache.clear();
     if (ctx->f4_buf) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->f4_buf); ctx->f4_buf = nullptr; ctx->f4_cap = 0; }
 }
@@ -500,6 +500,7 @@ static void cache_drop_path(eagle_ctx* ctx, const char* path) {
             (void)hipFree(ctx->cache[i].dev);
             if (ctx->cache[i].dev_s) (void)hipFree(ctx->cache[i].dev_s);
             if (ctx->cache[i].cshift) (void)hipFree(ctx->cache[i].cshift);
+            if (ctx->cache[i].l1) (void)hipFree(ctx->cache[i].l1);
             ctx->cache.erase(ctx->cache.begin() + i);
         } else i++;
 }
@@ -770,16 +771,19 @@ extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_asc
     const int nslices = ctx->scan_slices;
     GenoEntry* g = nullptr;
     rc = get_resident(ctx, f_name_ascii, L, n, max_memory_in_Gbytes, host_threads(), &g,
-                      4 * sq + (use_i8 ? (size_t)eagle_vara_i8_workspace_bytes(np, Lp, nslices) + (size_t)Lp * np + Lp : 0) +
-                          ((size_t)1 << 30));  // operands, digit workspace, the re-centred image of the file
+                      4 * sq + (use_i8 ? (size_t)eagle_vara_i8_workspace_bytes(np, Lp, nslices) + (size_t)Lp * np + 5 * (size_t)Lp +
+                                             (size_t)eagle_scan_certify_workspace_bytes(np) : 0) +
+                          ((size_t)1 << 30));  // operands, digit + certification workspaces, the re-centred image of the file
     if (rc < 0) return rc;
     const bool streamed = (rc == EAGLE_STREAM);
     const long Lc = streamed ? stream_chunk_rows(np, Lp) : Lp;  // marker rows per pass
     DevBuf dsel;
     const size_t wsb = use_i8 ? (size_t)eagle_vara_i8_workspace_bytes(np, Lc, nslices) : 0;
+    const size_t certb = use_i8 ? (size_t)eagle_scan_certify_workspace_bytes(np) : 0;
     const double t0 = now_s();
-    if ((rc = arena_reserve(ctx, 4 * arena_round(sq) + 2 * arena_round(sizeof(double) * np) + arena_round(wsb) +
-                                     (streamed ? (use_i8 ? 4 : 2) * arena_round((size_t)Lc * np) + 2 * arena_round((size_t)Lc) : 0))))
+    if ((rc = arena_reserve(ctx, 4 * arena_round(sq) + 2 * arena_round(sizeof(double) * np) + arena_round(wsb) + arena_round(certb) +
+                                     (streamed ? (use_i8 ? 4 : 2) * arena_round((size_t)Lc * np) + 2 * arena_round((size_t)Lc) +
+                                                     2 * arena_round(sizeof(int32_t) * (size_t)Lc) : 0))))
         return rc;
     double* Sa = arena_take<double>(ctx, sq);
     double* Va = arena_take<double>(ctx, sq);
@@ -788,9 +792,12 @@ extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_asc
     double* ah = arena_take<double>(ctx, sizeof(double) * np);
     double* v = arena_take<double>(ctx, sizeof(double) * np);
     void* ws = arena_take<char>(ctx, wsb);
+    void* cert = arena_take<char>(ctx, certb);
+    long* cert_totals = (long*)((char*)ctx->d_scratch + 256);  // {re-evaluated, flagged, fell back}, summed over marker blocks
     ChunkRing ring;
     int8_t* shifted[2] = {nullptr, nullptr};
     int8_t* cs[2] = {nullptr, nullptr};
+    int32_t* l1s[2] = {nullptr, nullptr};
     if (streamed) {
         if ((rc = ring.init(ctx))) return rc;
         ring.buf[0] = arena_take<int8_t>(ctx, (size_t)Lc * np);
@@ -798,12 +805,14 @@ extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_asc
         for (int b = 0; b < 2 && use_i8; b++) {
             shifted[b] = arena_take<int8_t>(ctx, (size_t)Lc * np);
             cs[b] = arena_take<int8_t>(ctx, (size_t)Lc);
+            l1s[b] = arena_take<int32_t>(ctx, sizeof(int32_t) * (size_t)Lc);
         }
     }
     if ((rc = upload_square(ctx, inv_MMt_sqrt, n, np, Sa))) return rc;
     if ((rc = upload_square(ctx, dim_reduced_vara, n, np, Va))) return rc;
     if ((rc = upload_vec(ctx, a, n, np, ah))) return rc;
     if ((rc = ensure_scan_out(ctx, Lp))) return rc;
+    HIPCHK(ctx, hipMemsetAsync(cert_totals, 0, 3 * sizeof(long), ctx->stream));
     double t1 = 0;
     if (timing_on()) { (void)hipStreamSynchronize(ctx->stream); t1 = now_s(); }
     rc = eagle_dev_scan_operands(ctx, Sa, Va, ah, n, np, v, Wu, tmp, ctx->stream);
@@ -824,24 +833,40 @@ extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_asc
             // re-centred image of the markers (kept with a resident file, rebuilt per chunk when streaming)
             const int8_t* Ms = nullptr;
             const int8_t* cv = nullptr;
+            const int32_t* l1 = nullptr;
             if (streamed) {
                 const int b = (int)(ring.k & 1);
-                rc = eagle_dev_marker_shift(ctx, Mt8, nrp, n, np, ldm, shifted[b], cs[b], ctx->stream);
+                rc = eagle_dev_marker_shift(ctx, Mt8, nrp, n, np, ldm, shifted[b], cs[b], l1s[b], ctx->stream);
                 if (rc) return rc;
-                Ms = shifted[b]; cv = cs[b];
+                Ms = shifted[b]; cv = cs[b]; l1 = l1s[b];
             } else {
                 if (!g->dev_s) {
-                    HIPCHK(ctx, hipMalloc((void**)&g->dev_s, (size_t)g->rows_pad * g->ld));
-                    HIPCHK(ctx, hipMalloc((void**)&g->cshift, (size_t)g->rows_pad));
-                    rc = eagle_dev_marker_shift(ctx, g->dev, g->rows_pad, n, np, g->ld, g->dev_s, g->cshift, ctx->stream);
-                    if (rc) return rc;
+                    hipError_t e = hipMalloc((void**)&g->dev_s, (size_t)g->rows_pad * g->ld);
+                    if (e == hipSuccess) e = hipMalloc((void**)&g->cshift, (size_t)g->rows_pad);
+                    if (e == hipSuccess) e = hipMalloc((void**)&g->l1, sizeof(int32_t) * (size_t)g->rows_pad);
+                    rc = e == hipSuccess ? eagle_dev_marker_shift(ctx, g->dev, g->rows_pad, n, np, g->ld, g->dev_s, g->cshift, g->l1, ctx->stream)
+                                         : eagle_fail_hip(ctx, e, "re-centred image hipMalloc");
+                    if (rc) {  // never leave a half-made image behind: the next call would scan garbage
+                        if (g->dev_s) (void)hipFree(g->dev_s);
+                        if (g->cshift) (void)hipFree(g->cshift);
+                        if (g->l1) (void)hipFree(g->l1);
+                        g->dev_s = nullptr; g->cshift = nullptr; g->l1 = nullptr;
+                        return rc;
+                    }
                 }
-                Ms = g->dev_s; cv = g->cshift;
+                Ms = g->dev_s; cv = g->cshift; l1 = g->l1;
             }
             // one pass over the genotypes gives a = Mt v and the diagonal term of vara; then the int8 MFMA kernel
             rc = eagle_dev_vara_i8_prepare(ctx, Mt8, nrp, np, ldm, Wu, nslices, ws, v, ctx->d_a + r0, ctx->stream);
             if (rc) return rc;
             rc = eagle_dev_vara_i8_mfma_shifted(ctx, Ms, cv, nrp, np, ldm, nslices, ws, ctx->d_vara + r0, nullptr, ctx->stream);
+            if (rc) return rc;
+            // a-posteriori certificate: markers the digit bounds cannot settle are re-evaluated by the fp64 kernel, so that
+            // which(tsq == max(tsq))[1] on the returned arrays is the marker the fp64 scan selects (find_qtl.R:71-83).  A
+            // streamed file is certified block by block against the block's own maximum (a superset of the global candidates).
+            rc = eagle_dev_scan_certify(ctx, Mt8, nr, nrp, np, ldm, cv, l1, nslices, ws, Wu, ctx->d_a + r0, ctx->d_vara + r0, cert, ctx->stream);
+            if (rc) return rc;
+            rc = eagle_dev_cert_accumulate(ctx, cert, cert_totals, ctx->stream);
         } else {
             rc = eagle_dev_gemv_i8(ctx, Mt8, nrp, np, ldm, v, 1.0, ctx->d_a + r0, ctx->stream);
             if (rc) return rc;
@@ -863,9 +888,20 @@ extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_asc
         if (rc) return rc;
     }
     ctx->scan_L = L;
+    long totals[3] = {0, 0, 0};
     HIPCHK(ctx, hipMemcpyAsync(a_out, ctx->d_a, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(vara_out, ctx->d_vara, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(totals, cert_totals, sizeof totals, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->cert_reevaluated = totals[0]; ctx->cert_flagged = totals[1]; ctx->cert_fell_back = totals[2] != 0;
+    return EAGLE_OK;
+}
+
+extern "C" int eagle_last_scan_certificate(eagle_ctx* ctx, long* n_reevaluated, long* n_flagged, int* fell_back) {
+    if (!ctx) return EAGLE_ERR_ARG;
+    if (n_reevaluated) *n_reevaluated = ctx->cert_reevaluated;
+    if (n_flagged) *n_flagged = ctx->cert_flagged;
+    if (fell_back) *fell_back = ctx->cert_fell_back;
     return EAGLE_OK;
 }
 

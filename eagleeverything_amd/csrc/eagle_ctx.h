@@ -25,6 +25,7 @@ struct GenoEntry {
     int8_t* dev = nullptr;
     int8_t* dev_s = nullptr;    // re-centred image m - c_i (eagle_dev_marker_shift), made on the first digit-slice scan of the file
     int8_t* cshift = nullptr;   // c_i per row
+    int32_t* l1 = nullptr;      // sum_j |m_ij - c_i| per row (error bound of the digit-slice scan)
 };
 
 struct eagle_ctx {
@@ -40,12 +41,17 @@ struct eagle_ctx {
     // results of the last calls, kept in HBM
     double* d_mmt = nullptr; long mmt_n = 0; double* d_mmt_max = nullptr;
     double* d_a = nullptr; double* d_vara = nullptr; long scan_L = 0; long scan_cap = 0;
+    long cert_reevaluated = 0, cert_flagged = 0; int cert_fell_back = 0;  // certification counters of the last digit-slice scan
     void* d_scratch = nullptr;
     void* arena = nullptr; size_t arena_cap = 0, arena_off = 0;  // grow-only device workspace reused across calls
     void* f4_buf = nullptr; size_t f4_cap = 0;  // fp4 image of the tile eagle_dev_mmt_accumulate is working on
     void* gemm_scratch = nullptr; size_t gemm_scratch_cap = 0;  // split-K partial tiles of the fp64 GEMM's last wave
     void* gemv_ws = nullptr;  // 16 digit-slice rows of the GEMV vectors + their exponents (k_gemv_mfma)
     void* stage_pin[2] = {nullptr, nullptr}; void* stage_raw[2] = {nullptr, nullptr}; size_t stage_cap = 0;  // tile streamer
+    // per-device launch state (a process may hold one ctx per GPU): dynamic-LDS attributes set on this device, schedule
+    // experiment switch of tools/bench_i8_engine.py (0 = shipped)
+    bool attr_vara_i8 = false, attr_vara_f6 = false, attr_gemv = false;
+    int tune = 0;
     char arch[64] = {0};
     int cu_count = 0;
     int64_t hbm_bytes = 0;

@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include "../../include/eagle_hip.h"
+#include "eagle_ctx.h"
 #include "eagle_internal.h"
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -189,9 +190,12 @@ __global__ __launch_bounds__(512, 2) void k_syrk_i8(const int8_t* __restrict__ M
 
 // Upper-triangular tile pairs (ti<<16 | tj) in super-tile order, cached on the device per tile count.
 #include <map>
+#include <mutex>
 #include <vector>
 static std::map<std::pair<int, int>, int*> g_pair_tables;  // (device, nt) -> device table
+static std::mutex g_pair_mutex;                             // one worker thread per device may come through here
 static int syrk_pair_table(eagle_ctx* ctx, int nt, const int** out, hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(g_pair_mutex);
     int dev = 0;
     (void)hipGetDevice(&dev);
     auto key = std::make_pair(dev, nt);
@@ -213,9 +217,8 @@ static int syrk_pair_table(eagle_ctx* ctx, int nt, const int** out, hipStream_t 
     return EAGLE_OK;
 }
 
-// Experiment switch for the tile-engine schedule (tools/bench_i8_engine.py); 0 is the shipped default.
-static int g_tune = 0;
-extern "C" void eagle_dev_set_tune(int v) { g_tune = v; }
+// Experiment switch for the tile-engine schedule (tools/bench_i8_engine.py); 0 is the shipped default.  Per ctx.
+extern "C" void eagle_dev_set_tune(eagle_ctx* ctx, int v) { if (ctx) ctx->tune = v; }
 
 // The int8 form of the MM^T kernel (the shipped one is k_syrk_f4 below: same engine, fp4 operands, twice the markers per
 // stage).  Kept for the schedule ablations of tools/bench_i8_engine.py; not part of the public ABI.
@@ -241,7 +244,7 @@ extern "C" int eagle_dev_mmt_accumulate_i8(eagle_ctx* ctx, const int8_t* M8, lon
     if (rc) return rc;
     dim3 grid((unsigned)((nblocks + 7) / 8 * 8));
 #define SYRK_LAUNCH(T) hipLaunchKernelGGL(k_syrk_i8<T>, grid, dim3(512), 0, (hipStream_t)stream, M8, ld, pairs, (int)npairs, (int)nblocks, nstages, per, C32, n_pad)
-    switch (g_tune) {
+    switch (ctx->tune) {
         case 3: SYRK_LAUNCH(3); break;
         case 4: SYRK_LAUNCH(4); break;
         default: SYRK_LAUNCH(0);
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(256) void k_slice_w(const double* __restrict__ Wu, 
 // is then bounded by (sum_j |m'_ij|)^2 / 2 * 2^(e+1-8S): it shrinks with the marker's own diagonal term.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_marker_shift(const int8_t* __restrict__ Mt8, long L_pad, int n, long ld, int8_t* __restrict__ Mt8s,
-                                                      int8_t* __restrict__ cshift) {
+                                                      int8_t* __restrict__ cshift, int32_t* __restrict__ l1norm) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per marker
     if (row >= L_pad) return;
@@ -406,7 +409,11 @@ __global__ __launch_bounds__(256) void k_marker_shift(const int8_t* __restrict__
     int c = 0;  // ties go to 0, then to -1: any fixed rule will do
     if (neg > zer && neg >= pos) c = -1;
     else if (pos > zer && pos > neg) c = 1;
-    if (lane == 0) cshift[row] = (int8_t)c;
+    if (lane == 0) {
+        cshift[row] = (int8_t)c;
+        // sum_j |m'_ij| of the re-centred marker: the per-marker digit error bound is l1^2 / 2 * 2^(e+1-8S) (k_cert_*)
+        if (l1norm) l1norm[row] = c == 0 ? neg + pos : (c < 0 ? zer + 2 * pos : zer + 2 * neg);
+    }
     int8_t* dst = Mt8s + row * ld;
     for (int j = lane * 16; j < (int)ld; j += 64 * 16) {
         i32x4 x = {0, 0, 0, 0};
@@ -424,10 +431,10 @@ __global__ __launch_bounds__(256) void k_marker_shift(const int8_t* __restrict__
     }
 }
 extern "C" int eagle_dev_marker_shift(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n, long n_pad, long ld, int8_t* Mt8s,
-                                      int8_t* cshift, void* stream) {
+                                      int8_t* cshift, int32_t* l1norm, void* stream) {
     if (ld % 16 || n > n_pad || n_pad > ld || n <= 0) return eagle_fail(ctx, EAGLE_ERR_ARG, "marker_shift: layout contract violated");
     if (L_pad <= 0) return EAGLE_OK;
-    hipLaunchKernelGGL(k_marker_shift, dim3((unsigned)((L_pad + 3) / 4)), dim3(256), 0, (hipStream_t)stream, Mt8, L_pad, (int)n, ld, Mt8s, cshift);
+    hipLaunchKernelGGL(k_marker_shift, dim3((unsigned)((L_pad + 3) / 4)), dim3(256), 0, (hipStream_t)stream, Mt8, L_pad, (int)n, ld, Mt8s, cshift, l1norm);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "k_marker_shift");
     return EAGLE_OK;
@@ -623,6 +630,152 @@ __global__ __launch_bounds__(256) void k_vara_i8_finish(const long long* __restr
     vara[i] = vdiag[i] + s;  // diagonal term sum_k m_ik^2 W_kk (fp64) + exact-integer off-diagonal term
 }
 
+// ------------------------------------------------------------------------------------------------
+// Certification of a digit-slice scan (find_qtl.R:71-83 must select the marker the fp64 arithmetic selects).
+//
+// Every vara_i of k_vara_i8_finish differs from the exact m_i^T W m_i by at most
+//     b_i = l1_i^2 / 2 * 2^(e+1-8S)  +  2^-48 (|diag_i| + |vara_i - diag_i| + 2|c_i m_i^T rho| + 2 c_i^2 |R|)  +  2^-50 sum_k |W_kk|,
+// l1_i = sum_j |m'_ij| of the re-centred marker (k_marker_shift): the first term is the truncation of W to S digits
+// (|sum_{j<k} m'_j m'_k R_jk| <= 2^(e+1-8S) ((sum|m'_j|)^2 - sum m'_j^2)/2), the others cover the fp64 roundings of the
+// handful of terms the finish kernel adds (each an exactly evaluated integer sum rounded once).
+// Markers are RE-EVALUATED with the fp64 kernel (k_vara_f64<SPLIT>, bitwise the value scan mode 0 gives that marker) when
+//   (1) b_i > 1e-7 |vara_i|                      -- the digit result is not certified to a tenth of the path's 1e-6 tolerance
+//                                                   (a quadratic form that cancels against its diagonal term, or W with huge
+//                                                   off-diagonal entries), or
+//   (2) a_i^2 / (vara_i - b_i) >= LB (1 - 1e-9),  LB = max_j a_j^2 / (vara_j + b_j)  -- marker i cannot be excluded from being
+//                                                   the arg-max: LB is a lower bound of the true maximum, the left side an upper
+//                                                   bound of marker i's true tsq (vara_i - b_i <= 0: no bound, re-evaluated).
+// After that the arg-max over [fp64 values of the candidates, digit values of everybody else] is the arg-max of the fp64
+// scan: every marker that can win carries its fp64 value, every other marker is strictly below the winner in both.
+// At most CERT_CAP markers are re-evaluated per call; if more qualify (degenerate operands) the whole block is redone by the
+// fp64 kernel (device-side gate, no host round trip).
+// ------------------------------------------------------------------------------------------------
+#define CERT_CAP 2048
+struct CertHdr { unsigned long long lb_bits; int count; int overflow; int flagged; int pad; };  // = eagle_cert_info of the public header
+
+struct CertCtx { double delta, absR, sumdiag; };
+__device__ __forceinline__ CertCtx cert_ctx(const VaraHdr* hdr) {
+    CertCtx c;
+    int e = 0;
+    const double mx = hdr->maxabs_off;
+    if (mx > 0.0) (void)frexp(mx, &e);
+    c.delta = mx > 0.0 ? ldexp(1.0, e + 1 - 8 * hdr->S) : 0.0;
+    c.absR = fabs(hdr->R);
+    c.sumdiag = hdr->sumdiag;
+    return c;
+}
+__device__ __forceinline__ double cert_bound(const CertCtx& cc, int l1, int c, double vdiag, double mrho, double vara) {
+    const double l = (double)l1;
+    double b = 0.5 * l * l * cc.delta;
+    double mag = fabs(vdiag) + fabs(vara - vdiag);
+    if (c != 0) mag += 2.0 * (fabs(mrho) + cc.absR);
+    return b + 0x1p-48 * mag + 0x1p-50 * cc.sumdiag;
+}
+__global__ __launch_bounds__(256) void k_cert_lb(const double* __restrict__ a, const double* __restrict__ vara, long L,
+                                                 const int32_t* __restrict__ l1, const int8_t* __restrict__ cshift,
+                                                 const double* __restrict__ vdiag, const double* __restrict__ mrho,
+                                                 const VaraHdr* __restrict__ hdr, CertHdr* __restrict__ ch) {
+    const CertCtx cc = cert_ctx(hdr);
+    double best = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L; i += (long)gridDim.x * 256) {
+        const double x = a[i], v = vara[i];
+        if (!(isfinite(x) && isfinite(v))) continue;
+        const double up = v + cert_bound(cc, l1[i], cshift[i], vdiag[i], mrho[i], v);
+        if (!(up > 0.0)) continue;
+        const double lb = (x * x) / up;
+        best = lb > best ? lb : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_down(best, o); best = y > best ? y : best; }
+    if ((threadIdx.x & 63) == 0 && best > 0.0 && isfinite(best)) atomicMax(&ch->lb_bits, (unsigned long long)__double_as_longlong(best));
+}
+__global__ __launch_bounds__(256) void k_cert_select(const double* __restrict__ a, const double* __restrict__ vara, long L,
+                                                     const int32_t* __restrict__ l1, const int8_t* __restrict__ cshift,
+                                                     const double* __restrict__ vdiag, const double* __restrict__ mrho,
+                                                     const VaraHdr* __restrict__ hdr, CertHdr* __restrict__ ch, long* __restrict__ idx) {
+    const CertCtx cc = cert_ctx(hdr);
+    const double thr = __longlong_as_double((long long)ch->lb_bits) * (1.0 - 1e-9);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L; i += (long)gridDim.x * 256) {
+        const double x = a[i], v = vara[i];
+        if (!(isfinite(x) && isfinite(v))) continue;  // NaN / Inf operands: the fp64 kernel gives the same
+        const double b = cert_bound(cc, l1[i], cshift[i], vdiag[i], mrho[i], v);
+        const bool flagged = b > 1e-7 * fabs(v);
+        const double den = v - b;
+        const bool cand = !(den > 0.0) || (x * x) / den >= thr;
+        if (flagged) atomicAdd(&ch->flagged, 1);
+        if (flagged || cand) {
+            const int k = atomicAdd(&ch->count, 1);
+            if (k < CERT_CAP) idx[k] = i; else ch->overflow = 1;
+        }
+    }
+}
+// rows[k][0..n_pad) = Mt8[idx[k]][0..n_pad) for k < count, zero rows up to the next multiple of 128 (the fp64 kernel works on
+// whole 128-row blocks)
+__global__ __launch_bounds__(256) void k_cert_gather(const int8_t* __restrict__ Mt8, long ld, long n_pad, const CertHdr* __restrict__ ch,
+                                                     const long* __restrict__ idx, int8_t* __restrict__ rows) {
+    const int cnt = ch->count < CERT_CAP ? ch->count : CERT_CAP;
+    const int k = blockIdx.x;
+    if (k >= (cnt + 127) / 128 * 128) return;
+    const int8_t* src = k < cnt ? Mt8 + idx[k] * ld : nullptr;
+    for (long j = (long)threadIdx.x * 16; j < n_pad; j += 256 * 16) {
+        i32x4 x = {0, 0, 0, 0};
+        if (src) x = *(const i32x4*)(src + j);
+        *(i32x4*)(rows + (long)k * n_pad + j) = x;
+    }
+}
+
+// totals[0..2] += {re-evaluated rows, flagged rows, overflow} of one certification (streamed files certify per marker block)
+__global__ void k_cert_accumulate(const CertHdr* __restrict__ ch, long* __restrict__ totals) {
+    totals[0] += ch->count < CERT_CAP ? ch->count : CERT_CAP;
+    totals[1] += ch->flagged;
+    totals[2] += ch->overflow;
+}
+extern "C" int eagle_dev_cert_accumulate(eagle_ctx* ctx, const void* cert_ws, long* totals_dev, void* stream) {
+    hipLaunchKernelGGL(k_cert_accumulate, dim3(1), dim3(1), 0, (hipStream_t)stream, (const CertHdr*)cert_ws, totals_dev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "k_cert_accumulate");
+    return EAGLE_OK;
+}
+
+static int ws_smax(int nslices);  // layout of the vara workspace (defined with it, below)
+static size_t ws_vd_off(long n_pad, long L_pad, int smax);
+static size_t ws_mr_off(long n_pad, long L_pad, int smax);
+static size_t cert_idx_off() { return 256; }
+static size_t cert_rows_off() { return cert_idx_off() + (size_t)CERT_CAP * sizeof(long); }
+static size_t cert_part_off(long n_pad) { return (cert_rows_off() + (size_t)CERT_CAP * n_pad + 255) / 256 * 256; }
+extern "C" int64_t eagle_scan_certify_workspace_bytes(long n_pad) {
+    return (int64_t)(cert_part_off(n_pad) + (size_t)(CERT_CAP / 128) * (size_t)(n_pad / 128) * 256 * sizeof(double));
+}
+extern "C" int eagle_dev_scan_certify(eagle_ctx* ctx, const int8_t* Mt8, long L, long L_pad, long n_pad, long ld, const int8_t* cshift,
+                                      const int32_t* l1norm, int nslices, void* vara_ws, const double* Wu, const double* a, double* vara,
+                                      void* cert_ws, void* stream) {
+    if (n_pad % T8 || L_pad % T8 || ld % 16 || n_pad > ld || L < 0 || L > L_pad || !cshift || !l1norm || !cert_ws)
+        return eagle_fail(ctx, EAGLE_ERR_ARG, "scan_certify: layout contract violated");
+    hipStream_t s = (hipStream_t)stream;
+    CertHdr* ch = (CertHdr*)cert_ws;
+    hipError_t e = hipMemsetAsync(ch, 0, 256, s);
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "scan_certify memset");
+    if (L == 0) return EAGLE_OK;
+    const int smax = ws_smax(nslices);
+    const VaraHdr* hdr = (const VaraHdr*)vara_ws;
+    const double* vdiag = (const double*)((const char*)vara_ws + ws_vd_off(n_pad, L_pad, smax));
+    const double* mrho = (const double*)((const char*)vara_ws + ws_mr_off(n_pad, L_pad, smax));
+    long* idx = (long*)((char*)cert_ws + cert_idx_off());
+    int8_t* rows = (int8_t*)cert_ws + cert_rows_off();
+    double* partial = (double*)((char*)cert_ws + cert_part_off(n_pad));
+    unsigned blocks = (unsigned)((L + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_cert_lb, dim3(blocks), dim3(256), 0, s, a, vara, L, l1norm, cshift, vdiag, mrho, hdr, ch);
+    hipLaunchKernelGGL(k_cert_select, dim3(blocks), dim3(256), 0, s, a, vara, L, l1norm, cshift, vdiag, mrho, hdr, ch, idx);
+    hipLaunchKernelGGL(k_cert_gather, dim3(CERT_CAP), dim3(256), 0, s, Mt8, ld, n_pad, ch, idx, rows);
+    e = hipGetLastError();
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "scan_certify");
+    int rc = eagle_dev_vara_f64_split(ctx, rows, CERT_CAP, n_pad, n_pad, Wu, &ch->count, idx, partial, vara, stream);
+    if (rc) return rc;
+    // more than CERT_CAP markers qualified: the whole block in fp64 (dropped on the device otherwise)
+    return eagle_dev_vara_f64_gated(ctx, Mt8, L_pad, n_pad, ld, Wu, vara, &ch->overflow, stream);
+}
+
 __global__ void k_vara_i8_bound(const VaraHdr* __restrict__ hdr, double* __restrict__ out, int* __restrict__ slices_out) {
     *out = hdr->bound;
     if (slices_out) *slices_out = hdr->S;
@@ -707,11 +860,10 @@ extern "C" int eagle_dev_vara_i8_mfma_shifted(eagle_ctx* ctx, const int8_t* Mt8s
     int8_t* Bs = (int8_t*)((char*)ws + ws_bs_off(n_pad, L_pad, smax));
     const int ntm = (int)(L_pad / T8);
     const int groups = (ntm + 7) / 8;
-    static bool attr_done = false;
-    if (!attr_done) {
+    if (!ctx->attr_vara_i8) {  // per device: a second ctx on another GPU must set it again
         hipError_t ea = hipFuncSetAttribute((const void*)k_vara_i8, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * TILE_BYTES);
         if (ea != hipSuccess) return eagle_fail_hip(ctx, ea, "hipFuncSetAttribute(k_vara_i8)");
-        attr_done = true;
+        ctx->attr_vara_i8 = true;
     }
     hipLaunchKernelGGL(k_vara_i8, dim3((unsigned)(groups * 8 * smax)), dim3(512), 5 * TILE_BYTES, s, Mt8s, ld, ntm, Bs, n_pad, hdr, q, L_pad);
     hipLaunchKernelGGL(k_vara_i8_finish, dim3((unsigned)((L_pad + 255) / 256)), dim3(256), 0, s, q, L_pad, hdr, vdiag, cshift, mrho, vara_out);
@@ -1073,11 +1225,10 @@ extern "C" int eagle_dev_vara_f6_mfma(eagle_ctx* ctx, const int8_t* Mt8, const v
     long long* q = (long long*)((char*)ws + ws_q_off());
     double* vdiag = (double*)((char*)ws + ws_vd_off(n_pad, L_pad, smax));
     uint8_t* Bs6 = (uint8_t*)((char*)ws + ws_bs_off(n_pad, L_pad, smax));
-    static bool attr_done = false;
-    if (!attr_done) {
+    if (!ctx->attr_vara_f6) {
         hipError_t ea = hipFuncSetAttribute((const void*)k_vara_f6, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F6_STAGE);
         if (ea != hipSuccess) return eagle_fail_hip(ctx, ea, "hipFuncSetAttribute(k_vara_f6)");
-        attr_done = true;
+        ctx->attr_vara_f6 = true;
     }
     const int ntm = (int)(L_pad / T8);
     const int groups = (ntm + 7) / 8;

@@ -3,9 +3,8 @@
 //
 //   k_decode_ascii ........ text tile '0','1','2' -> int8 {-1,0,1}     (E/src/ReadBlock.cpp:52-55)
 //   (k_syrk_i8 / k_vara_i8: the int8 MFMA tile engine lives in eagle_i8mfma.hip)
-//   k_gemm_f64<..> ........ fp64 MFMA GEMM core (v_mfma_f64_16x16x4_f64):
-//                             A = f64 : W = S (V S)                     (calculate_a_and_vara_rcpp.cpp:97-98)
-//                             A = int8: T = Mt W fused with the row-dot (calculate_a_and_vara_rcpp.cpp:103-112)
+//   k_gemm_f64_list ....... fp64 MFMA GEMM (v_mfma_f64_16x16x4_f64): W = S (V S)   (calculate_a_and_vara_rcpp.cpp:97-98)
+//   k_vara_f64<..> ........ same core, A = int8: T = Mt W fused with the row-dot    (calculate_a_and_vara_rcpp.cpp:103-112)
 //   k_gemv_mfma ........... a = Mt v (+ diagonal term of vara)          (calculate_a_and_vara_rcpp.cpp:91,
 //                                                                        calculate_reduced_a_rcpp.cpp:83-84)
 //   k_tsq_* ............... tsq = a^2/vara, first arg-max ignoring NaN  (E/R/find_qtl.R:71-83)
@@ -154,11 +153,8 @@ __global__ __launch_bounds__(256) void k_mmt_normalise(double* __restrict__ A, l
 // K block 16.  Inside a K block the lane group g = lane>>4 owns k = 4g + s for MFMA step s, so a lane reads
 // 4 consecutive k of its A row at once (the k order of an fp64 sum is a free choice; it is fixed, hence
 // deterministic).
-//   AMODE 0: A is fp64 row-major.   AMODE 1: A is int8 row-major (genotypes), converted in registers.
-//   EPI 0  : store C.
-//   EPI 1  : row-dot: out[i] = sum_c C[i][c] * A8[i][c] over ALL column tiles, accumulated in registers
-//            (one block owns 128 markers and walks every column tile; B is upper triangular (Wu), so
-//            column tile ct only needs k < (ct+1)*128).
+//   AMODE 0: A is fp64 row-major (k_gemm_f64_list).   AMODE 1: A is int8 row-major (genotypes), converted in registers
+//   (k_vara_f64, which fuses the row-dot out[i] = sum_c C[i][c] * A8[i][c] into the tile epilogue).
 // LDS rows: A f64 [128][16] doubles (+2 pad), A i8 [128][16] bytes, B [16][128] doubles (+4 pad).
 // ------------------------------------------------------------------------------------------------
 #define GF_T 128
@@ -214,9 +210,11 @@ __device__ __forceinline__ void gf_store(const GfStage<AMODE>& s, double* ldsA, 
         if (t < 128) *(i32x4*)((int8_t*)ldsA + t * 16) = s.a8;
     }
 }
+// mlim: only the first mlim 16-row tiles of the wave's four are computed (the SPLIT vara kernel re-evaluates a handful of
+// rows; the MFMA sequence of a computed element is the same whatever mlim is)
 template <int AMODE>
 __device__ __forceinline__ void gf_compute(f64x4 (&acc)[4][4], const double* ldsA, const double* ldsB, int wr, int wc,
-                                           int lane) {
+                                           int lane, int mlim = 4) {
     const int i16 = lane & 15, g = lane >> 4;
     int w4[4];  // AMODE 1: the lane's 4 consecutive genotype bytes of each row tile
     if (AMODE == 1) {
@@ -235,8 +233,10 @@ __device__ __forceinline__ void gf_compute(f64x4 (&acc)[4][4], const double* lds
         for (int n = 0; n < 4; n++) b[n] = ldsB[(4 * g + s) * GF_LDB + wc * 64 + n * 16 + i16];
 #pragma unroll
         for (int m = 0; m < 4; m++)
+            if (m < mlim) {
 #pragma unroll
-            for (int n = 0; n < 4; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+                for (int n = 0; n < 4; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+            }
     }
 }
 
@@ -244,94 +244,116 @@ __device__ __forceinline__ void gf_compute(f64x4 (&acc)[4][4], const double* lds
 #define GF_LDSA_DOUBLES (GF_T * GF_LDA)
 #define GF_LDSB_DOUBLES (GF_BK * GF_LDB)
 
-template <int AMODE, int EPI>
-__global__ __launch_bounds__(256, 2) void k_gemm_f64(const void* __restrict__ A, long lda, const double* __restrict__ B,
-                                                     long ldb, double* __restrict__ C, long ldc, int n_coltiles,
-                                                     long K, const int* __restrict__ upper_only) {
+// The fp64 vara kernel (calculate_a_and_vara_rcpp.cpp:103-112): vara_i = sum_k m_ik sum_{j<=k} m_ij Wu[j][k] for the 128 markers
+// of a row block, A = int8 genotypes converted in registers, B = Wu (upper triangular fold of W, so column tile ct only
+// needs k < (ct+1)*128).  The summation order is FIXED and is the definition of this library's fp64 result:
+//   s_ct(i, wc) = the row-dot of tile ct restricted to the 64 columns of wave column wc: per lane a 4-term chain over the
+//                 lane's columns, then a butterfly over the 16 lanes of the row;
+//   P_wc(i)     = ((s_0 + s_1) + s_2) + ... in ascending ct;        vara_i = P_0(i) + P_1(i).
+// SPLIT = false: one workgroup walks every column tile of its row block and keeps P in registers.
+// SPLIT = true : grid.y = column tile; the workgroup writes s_ct to partial[rb][ct][wc][128] and k_vara_f64_sum forms the same
+//                chain -- bitwise the same vara for a row, whichever form computed it and whatever rows share its block.
+//                That is what lets the digit-slice scan re-evaluate a handful of markers in fp64 on the whole chip
+//                (k_cert_*, eagle_i8mfma.hip) and promise the fp64-mode result for them.
+// gate (may be NULL): SPLIT = false -> the launch is dropped unless *gate != 0; SPLIT = true -> row blocks at or beyond
+// *gate rows are dropped.
+template <bool SPLIT>
+__global__ __launch_bounds__(256, 2) void k_vara_f64(const int8_t* __restrict__ A8, long lda, const double* __restrict__ B, long ldb,
+                                                     double* __restrict__ out, int n_coltiles, long K, const int* __restrict__ gate,
+                                                     double* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) double lds[2][GF_LDSA_DOUBLES + GF_LDSB_DOUBLES];
-    // EPI 0 with a symmetric product: tiles below the diagonal are not needed (k_fold_upper doubles the upper ones)
-    if (EPI == 0 && upper_only && *upper_only && blockIdx.x > blockIdx.y) return;
+    if (gate) {
+        if (!SPLIT && *gate == 0) return;
+        if (SPLIT && (long)blockIdx.x * GF_T >= (long)*gate) return;
+    }
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
     const int i16 = lane & 15, g = lane >> 4;
     const long row0 = (long)blockIdx.x * GF_T;
-    const void* Ablk = (AMODE == 0) ? (const void*)((const double*)A + row0 * lda) : (const void*)((const int8_t*)A + row0 * lda);
-    double part[4][4];  // EPI 1: per-lane partial row-dots [row tile][reg]
+    const int8_t* Ablk = A8 + row0 * lda;
+    // SPLIT with a row count: 16-row tiles entirely beyond the count are not computed (wave-uniform)
+    int mlim = 4;
+    if (SPLIT && gate) {
+        const long left = (long)*gate - row0 - wr * 64;
+        mlim = left <= 0 ? 0 : (left >= 64 ? 4 : (int)((left + 15) >> 4));
+        mlim = __builtin_amdgcn_readfirstlane(mlim);
+    }
+    double P[4][4];
 #pragma unroll
     for (int m = 0; m < 4; m++)
 #pragma unroll
-        for (int q = 0; q < 4; q++) part[m][q] = 0.0;
-
-    const int ct0 = (EPI == 0) ? blockIdx.y : 0;
-    const int ct1 = (EPI == 0) ? blockIdx.y + 1 : n_coltiles;
+        for (int q = 0; q < 4; q++) P[m][q] = 0.0;
+    const int ct0 = SPLIT ? (int)blockIdx.y : 0;
+    const int ct1 = SPLIT ? (int)blockIdx.y + 1 : n_coltiles;
     for (int ct = ct0; ct < ct1; ct++) {
         const double* Bblk = B + (long)ct * GF_T;
-        // EPI 1: B is upper triangular -> rows k >= (ct+1)*128 of this column tile are zero
-        long kend = (EPI == 1) ? ((long)(ct + 1) * GF_T < K ? (long)(ct + 1) * GF_T : K) : K;
+        const long kend = (long)(ct + 1) * GF_T < K ? (long)(ct + 1) * GF_T : K;
         const long nkb = kend / GF_BK;
         f64x4 acc[4][4];
 #pragma unroll
         for (int m = 0; m < 4; m++)
 #pragma unroll
             for (int n = 0; n < 4; n++) acc[m][n] = (f64x4){0.0, 0.0, 0.0, 0.0};
-        GfStage<AMODE> st;
-        gf_load<AMODE>(st, Ablk, lda, Bblk, ldb, 0, t);
+        GfStage<1> st;
+        gf_load<1>(st, Ablk, lda, Bblk, ldb, 0, t);
         __syncthreads();  // previous column tile's readers are done with buffer 0
-        gf_store<AMODE>(st, lds[0], lds[0] + GF_LDSA_DOUBLES, t);
+        gf_store<1>(st, lds[0], lds[0] + GF_LDSA_DOUBLES, t);
         __syncthreads();
         int cur = 0;
         for (long kb = 0; kb < nkb; kb++) {
             const bool more = kb + 1 < nkb;
-            if (more) gf_load<AMODE>(st, Ablk, lda, Bblk, ldb, (kb + 1) * GF_BK, t);
-            gf_compute<AMODE>(acc, lds[cur], lds[cur] + GF_LDSA_DOUBLES, wr, wc, lane);
-            if (more) gf_store<AMODE>(st, lds[cur ^ 1], lds[cur ^ 1] + GF_LDSA_DOUBLES, t);
+            if (more) gf_load<1>(st, Ablk, lda, Bblk, ldb, (kb + 1) * GF_BK, t);
+            gf_compute<1>(acc, lds[cur], lds[cur] + GF_LDSA_DOUBLES, wr, wc, lane, mlim);
+            if (more) gf_store<1>(st, lds[cur ^ 1], lds[cur ^ 1] + GF_LDSA_DOUBLES, t);
             __syncthreads();
             cur ^= 1;
         }
         // C/D map of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
-        if (EPI == 0) {
-#pragma unroll
-            for (int m = 0; m < 4; m++)
-#pragma unroll
-                for (int n = 0; n < 4; n++)
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        long r = row0 + wr * 64 + m * 16 + g + 4 * q;
-                        long c = (long)ct * GF_T + wc * 64 + n * 16 + i16;
-                        C[r * ldc + c] = acc[m][n][q];
-                    }
-        } else {
-            const int8_t* A8 = (const int8_t*)A;
-#pragma unroll
-            for (int m = 0; m < 4; m++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    long r = row0 + wr * 64 + m * 16 + g + 4 * q;
-                    const int8_t* mr = A8 + r * lda + (long)ct * GF_T + wc * 64 + i16;
-                    double s = part[m][q];
-#pragma unroll
-                    for (int n = 0; n < 4; n++) s += acc[m][n][q] * (double)mr[n * 16];
-                    part[m][q] = s;
-                }
-        }
-    }
-    if (EPI == 1) {
-        // reduce over the 16 lanes that share a row (lane&15), then over the two waves wc = 0,1 (fixed order)
-        __syncthreads();
-        double* red = lds[0];  // [2][128]
 #pragma unroll
         for (int m = 0; m < 4; m++)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                double s = part[m][q];
+                const long r = row0 + wr * 64 + m * 16 + g + 4 * q;
+                const int8_t* mr = A8 + r * lda + (long)ct * GF_T + wc * 64 + i16;
+                double s = 0.0;
+#pragma unroll
+                for (int n = 0; n < 4; n++) s += acc[m][n][q] * (double)mr[n * 16];
                 s += __shfl_xor(s, 1);
                 s += __shfl_xor(s, 2);
                 s += __shfl_xor(s, 4);
                 s += __shfl_xor(s, 8);
-                if (i16 == 0) red[wc * 128 + wr * 64 + m * 16 + g + 4 * q] = s;
+                if (SPLIT) {
+                    if (i16 == 0)
+                        partial[(((long)blockIdx.x * n_coltiles + ct) * 2 + wc) * GF_T + wr * 64 + m * 16 + g + 4 * q] = s;
+                } else {
+                    P[m][q] += s;
+                }
             }
-        __syncthreads();
-        if (t < 128) C[row0 + t] = red[t] + red[128 + t];
     }
+    if (!SPLIT) {
+        __syncthreads();
+        double* red = lds[0];  // [2][128]
+        if (i16 == 0) {
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) red[wc * 128 + wr * 64 + m * 16 + g + 4 * q] = P[m][q];
+        }
+        __syncthreads();
+        if (t < 128) out[row0 + t] = red[t] + red[128 + t];
+    }
+}
+// vara of the rows of the SPLIT form: out[dst ? dst[r] : r] = P_0 + P_1, P_wc the ascending-ct chain of the partial sums.
+__global__ __launch_bounds__(128) void k_vara_f64_sum(const double* __restrict__ partial, int n_coltiles, const int* __restrict__ count,
+                                                      const long* __restrict__ dst, double* __restrict__ out) {
+    const long r = (long)blockIdx.x * GF_T + threadIdx.x;
+    if (count && r >= (long)*count) return;
+    const double* p = partial + (long)blockIdx.x * n_coltiles * 2 * GF_T + threadIdx.x;
+    double P0 = 0.0, P1 = 0.0;
+    for (int ct = 0; ct < n_coltiles; ct++) {
+        P0 += p[((long)ct * 2 + 0) * GF_T];
+        P1 += p[((long)ct * 2 + 1) * GF_T];
+    }
+    out[dst ? dst[r] : r] = P0 + P1;
 }
 
 // In-place fold  W -> Wu:  Wu[j][k] = W[j][k] + W[k][j] (j<k) ; W[k][k] (j==k) ; 0 (j>k).
@@ -676,11 +698,14 @@ __global__ __launch_bounds__(256) void k_gemm_f64_tail(const double* __restrict_
 
 // device tile lists, cached per (device, tiles per side, kind): 0 = all tiles, 1 = row tile <= column tile, 2 = row tile > column tile
 #include <map>
+#include <mutex>
 #include <tuple>
 #include <vector>
 static std::map<std::tuple<int, int, int, int, int>, std::pair<int*, long>> g_gemm_lists;
+static std::mutex g_gemm_lists_mutex;
 // kind: 0 = all tiles, 1 = row tile <= column tile, 2 = row tile > column tile; restricted to row tiles [rt0, rt1)
 static int gemm_tile_list(eagle_ctx* ctx, int nt, int kind, int rt0, int rt1, const int** out, long* count) {
+    std::lock_guard<std::mutex> lock(g_gemm_lists_mutex);
     int dev = 0;
     (void)hipGetDevice(&dev);
     auto key = std::make_tuple(dev, nt, kind, rt0, rt1);
@@ -965,13 +990,12 @@ extern "C" int eagle_dev_gemv3_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad,
     }
     int8_t* B = (int8_t*)ctx->gemv_ws;
     int* exps = (int*)(B + 32 * GV_MAXN);
-    static bool attr_done = false;
-    if (!attr_done) {
+    if (!ctx->attr_gemv) {  // per device
         hipError_t e = hipFuncSetAttribute((const void*)k_gemv_mfma<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemv_mfma<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemv_mfma<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return eagle_fail_hip(ctx, e, "hipFuncSetAttribute");
-        attr_done = true;
+        ctx->attr_gemv = true;
     }
     long blocks = 256;
     const long groups = L_pad / 16;
@@ -1010,12 +1034,33 @@ extern "C" int eagle_dev_gemv_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, 
 
 extern "C" int eagle_dev_vara_f64(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu,
                                   double* vara_out, void* stream) {
+    return eagle_dev_vara_f64_gated(ctx, Mt8, L_pad, n_pad, ld, Wu, vara_out, nullptr, stream);
+}
+// run_if (device int, may be NULL): the launch is dropped on the device unless *run_if != 0.
+extern "C" int eagle_dev_vara_f64_gated(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu,
+                                        double* vara_out, const int* run_if, void* stream) {
     if (L_pad % GF_T || n_pad % GF_T || ld % 16 || n_pad > ld)
         return eagle_fail(ctx, EAGLE_ERR_ARG, "vara_f64: layout contract violated");
     if (L_pad == 0) return EAGLE_OK;
     dim3 grid((unsigned)(L_pad / GF_T));
-    hipLaunchKernelGGL((k_gemm_f64<1, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const void*)Mt8, ld, Wu, n_pad,
-                       vara_out, 0L, (int)(n_pad / GF_T), n_pad, (const int*)nullptr);
+    hipLaunchKernelGGL((k_vara_f64<false>), grid, dim3(256), 0, (hipStream_t)stream, Mt8, ld, Wu, n_pad, vara_out, (int)(n_pad / GF_T), n_pad,
+                       run_if, (double*)nullptr);
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+// The same values for the first *count_dev rows (count <= rows_cap, a multiple of 128) of a compact row buffer, with the
+// column tiles spread over the chip (a few rows would otherwise sit on one CU): partial needs
+// rows_cap/128 * n_pad/128 * 256 doubles.  Results go to out[dst_dev[r]] (dst_dev == NULL: out[r]).
+extern "C" int eagle_dev_vara_f64_split(eagle_ctx* ctx, const int8_t* rows8, long rows_cap, long n_pad, long ld, const double* Wu,
+                                        const int* count_dev, const long* dst_dev, double* partial, double* out, void* stream) {
+    if (rows_cap % GF_T || n_pad % GF_T || ld % 16 || n_pad > ld || n_pad / GF_T > 65535)
+        return eagle_fail(ctx, EAGLE_ERR_ARG, "vara_f64_split: layout contract violated");
+    if (rows_cap == 0) return EAGLE_OK;
+    const int nct = (int)(n_pad / GF_T);
+    dim3 grid((unsigned)(rows_cap / GF_T), (unsigned)nct);
+    hipLaunchKernelGGL((k_vara_f64<true>), grid, dim3(256), 0, (hipStream_t)stream, rows8, ld, Wu, n_pad, (double*)nullptr, nct, n_pad, count_dev,
+                       partial);
+    hipLaunchKernelGGL(k_vara_f64_sum, dim3((unsigned)(rows_cap / GF_T)), dim3(GF_T), 0, (hipStream_t)stream, partial, nct, count_dev, dst_dev, out);
     LAUNCH_CHECK(ctx);
     return EAGLE_OK;
 }

@@ -46,21 +46,28 @@ class Collectives:
             fn(t)
         return t
 
-    def sum_partial_mmt(self, c32, tile=256):
+    def sum_partial_mmt(self, c32, tile=256, dst=None):
         """In-place sum of the int32 partial MM^T tensors of all ranks (exact).  Only the 256 x 256 tiles on or above the
-        diagonal are live (the kernels never write the others), so only those travel: half the bytes of the matrix."""
+        diagonal are live (the kernels never write the others), so only those travel: half the bytes of the matrix.
+        dst = None: all-reduce (every rank holds the sum); dst = r: reduce to rank r only -- MM^T goes back to ONE host
+        process (calculateMMt_rcpp returns it to R), so the other ranks need not receive it: half the link traffic."""
         if self.world > 1:
             np_ = c32.shape[0]
+            if dst is None:
+                red = lambda x: self.dist.all_reduce(x, op=self.dist.ReduceOp.SUM)
+            else:
+                red = lambda x: self.dist.reduce(x, dst=dst, op=self.dist.ReduceOp.SUM)
             if c32.dim() == 2 and c32.shape[1] == np_ and np_ % tile == 0 and np_ // tile > 1:
                 nt = np_ // tile
                 import torch
                 iu = torch.triu_indices(nt, nt, device=c32.device)
                 tiles = c32.view(nt, tile, nt, tile).permute(0, 2, 1, 3)       # [ti][tj][tile][tile] view
                 packed = tiles[iu[0], iu[1]].contiguous()                      # upper tiles only
-                self._staged(packed, lambda x: self.dist.all_reduce(x, op=self.dist.ReduceOp.SUM))
-                tiles[iu[0], iu[1]] = packed
+                self._staged(packed, red)
+                if dst is None or dst == self.rank:
+                    tiles[iu[0], iu[1]] = packed
             else:
-                self._staged(c32, lambda x: self.dist.all_reduce(x, op=self.dist.ReduceOp.SUM))
+                self._staged(c32, red)
         return c32
 
     def all_gather_rows(self, full, mine):
@@ -132,7 +139,9 @@ class DeviceShard:
         self.ws = None
         self._ws_mode = None
         self.Mt4 = None
-        self.Mt8s = self.cshift = None
+        self.Mt8s = self.cshift = self.l1 = None
+        self.cert_ws = None
+        self.certified = True  # digit-slice scans are certified (eagle_dev_scan_certify) before the arg-max
         self.share_w = True  # multi-rank runs split the n^3 part of the scan operands (scan_operands)
         self.mode = 0
         self.nslices = 0  # 0 = chosen by the library from its error bound
@@ -278,8 +287,9 @@ class DeviceShard:
         if self.Mt8s is None:
             self.Mt8s = self.torch.empty_like(self.Mt8)
             self.cshift = self.torch.empty(self.Lp, dtype=self.torch.int8, device=self.dev)
+            self.l1 = self.torch.empty(self.Lp, dtype=self.torch.int32, device=self.dev)
             self._check(self.L.eagle_dev_marker_shift(self.ctx, self.Mt8.data_ptr(), self.Lp, self.n, self.np_, self.np_,
-                                                      self.Mt8s.data_ptr(), self.cshift.data_ptr(), self._stream()))
+                                                      self.Mt8s.data_ptr(), self.cshift.data_ptr(), self.l1.data_ptr(), self._stream()))
         return self.Mt8s, self.cshift
 
     def fp4_image(self):
@@ -313,6 +323,27 @@ class DeviceShard:
                                                               self.nslices, self._ws().data_ptr(), self.vara.data_ptr(), None,
                                                               self._stream()))
 
+    def certify(self):
+        """Digit-slice mode: re-evaluate in fp64 every marker whose error bound exceeds 1e-7 |vara| and every marker the
+        bounds cannot exclude from being the arg-max, so that the arg-max below is the fp64 scan's (find_qtl.R:71-83)."""
+        if self.mode != 1:
+            return
+        self.shifted_image()
+        if self.cert_ws is None:
+            nb = int(self.L.eagle_scan_certify_workspace_bytes(self.np_))
+            self.cert_ws = self.torch.empty(nb, dtype=self.torch.uint8, device=self.dev)
+        self._check(self.L.eagle_dev_scan_certify(self.ctx, self.Mt8.data_ptr(), self.Lloc, self.Lp, self.np_, self.np_,
+                                                  self.cshift.data_ptr(), self.l1.data_ptr(), self.nslices, self._ws().data_ptr(),
+                                                  self.Wu.data_ptr(), self.a.data_ptr(), self.vara.data_ptr(), self.cert_ws.data_ptr(),
+                                                  self._stream()))
+
+    def certificate(self):
+        """{lower_bound, reevaluated, overflow, flagged} of the last certify() (synchronises)."""
+        h = self.cert_ws[:24].cpu().numpy().tobytes()
+        i = np.frombuffer(h[8:24], dtype=np.int32)
+        return {"lower_bound": float(np.frombuffer(h[0:8], dtype=np.float64)[0]), "reevaluated": int(min(i[0], 2048)),
+                "overflow": int(i[1]), "flagged": int(i[2])}
+
     def vara_i8_info(self):
         """(slices used, absolute error bound, max |off-diagonal W|) of the last int8-slice vara launch (synchronises)."""
         h = self.ws[:32].cpu().numpy().tobytes()
@@ -332,6 +363,8 @@ class DeviceShard:
         else:
             self.vara_prepare()
         self.vara_kernel()
+        if self.certified:
+            self.certify()
         self.argmax()
 
     def best(self):

@@ -1,4 +1,4 @@
-// eagle_backend.h -- glue shared by the four replacement translation units of the R package's src/.
+// eagle_backend.h -- glue shared by the eight replacement translation units of the R package's src/ (this directory).
 // Compiled only where R + Rcpp exist (not in the build container of this repository).
 #ifndef EAGLE_BACKEND_H
 #define EAGLE_BACKEND_H

@@ -5,7 +5,7 @@
  * (E/src/RcppExports.cpp:154-170, E/ = MyPackage/Eagle/).  The functions of section 1 below are what the
  * bodies of the reference's exported C++ functions are replaced with; each one cites the interface it
  * replaces.  The R-side binding (plain R C API, no Rcpp) is shown in INTEGRATION.md and in
- * eagleeverything_amd/shim/eagle_rshim.c.
+ * eagleeverything_amd/shim/ (one Rcpp-typed translation unit per exported function + eagle_backend.h).
  *
  * Conventions
  *   - plain pointers and sizes only; matrices crossing section 1 are COLUMN-major doubles (R / Eigen).
@@ -160,8 +160,10 @@ int eagle_create_Mt_ascii(eagle_ctx* ctx, const char* f_name, const char* f_name
 /* Replaces the R tail of .find_qtl:  tsq <- a^2/vara ; which(tsq == max(tsq, na.rm=TRUE))[1]
  *                                                E/R/find_qtl.R:71-83
  * Evaluated on the device on the a / vara of the LAST eagle_calculate_a_and_vara call of this ctx (still in
- * HBM).  index_out is 1-based (0 if every tsq is NaN); n_near_ties counts markers whose tsq is within a
- * relative 1e-9 of the maximum (1 = unambiguous). */
+ * HBM).  index_out is 1-based (0 if every tsq is NaN).  In digit-slice mode the arrays were certified inside the scan call
+ * (eagle_dev_scan_certify below: every marker that could be the arg-max carries its fp64-kernel value), so the index is
+ * the one scan mode 0 returns and the one R's own which(tsq == max(tsq))[1] finds on the returned a / vara.
+ * n_near_ties is informational: markers whose tsq is within a relative 1e-9 of the maximum (1 = unambiguous). */
 int eagle_last_scan_argmax(eagle_ctx* ctx, long* index_out, double* tsqmax_out, long* n_near_ties);
 
 /* MMt/max(MMt) + 0.95 I  (E/R/calcMMt.R:13) of the LAST eagle_calculateMMt result, on the device. */
@@ -251,13 +253,32 @@ int eagle_dev_vara_i8_mfma(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n
  * zero), c_i in {-1,0,+1} = the majority genotype of marker i, cshift[i] = c_i.  eagle_dev_vara_i8_mfma_shifted runs
  * the MFMA kernel on Mt8s (rare-variant markers become sparse rows, so their truncation error bound
  * (sum_j |m'_ij|)^2 / 2 * 2^(e+1-8S) shrinks with their own diagonal term) and adds c_i m_i^T rho - c_i^2 R in fp64;
- * prepare (always on the ORIGINAL image) has left rho, R and m^T rho in the workspace. */
+ * prepare (always on the ORIGINAL image) has left rho, R and m^T rho in the workspace.
+ * l1norm (may be NULL): l1norm[i] = sum_j |Mt8s[i][j]|, which eagle_dev_scan_certify turns into marker i's error bound. */
 int eagle_dev_marker_shift(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n, long n_pad, long ld, int8_t* Mt8s,
-                           int8_t* cshift, void* stream);
+                           int8_t* cshift, int32_t* l1norm, void* stream);
 int eagle_dev_vara_i8_mfma_shifted(eagle_ctx* ctx, const int8_t* Mt8s, const int8_t* cshift, long L_pad, long n_pad, long ld,
                                    int nslices, void* ws, double* vara_out, double* err_bound_dev, void* stream);
 int eagle_dev_vara_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu,
                       int nslices, void* ws, double* vara_out, double* err_bound_dev, void* stream);
+/* Certification of a digit-slice scan (after eagle_dev_vara_i8_mfma_shifted, before the arg-max), all on the device:
+ * every vara_i carries the a-posteriori bound b_i = l1norm[i]^2 / 2 * 2^(e+1-8S) + fp64 rounding terms; markers with
+ * b_i > 1e-7 |vara_i|, and every marker that the bounds cannot exclude from being the arg-max of tsq = a^2 / vara
+ * (a_i^2 / (vara_i - b_i) >= max_j a_j^2 / (vara_j + b_j)), are re-evaluated by the fp64 MFMA kernel on the ORIGINAL image
+ * Mt8 -- bitwise the value eagle_dev_vara_f64 gives that marker -- and written back into vara.  The arg-max of tsq over the
+ * certified arrays is then the arg-max of the fp64 scan (find_qtl.R:71-83 selects the same marker in either mode).
+ * L = real markers of the block (rows beyond it are padding), L_pad / nslices / vara_ws as passed to prepare + mfma.
+ * cert_ws: eagle_scan_certify_workspace_bytes(n_pad) bytes; its head is an eagle_cert_info the host may copy back.  If more
+ * than 2048 markers qualify (degenerate operands) the whole block is redone in fp64 (overflow = 1). */
+typedef struct { double lower_bound; int32_t reevaluated; int32_t overflow; int32_t flagged; int32_t pad; } eagle_cert_info;
+int64_t eagle_scan_certify_workspace_bytes(long n_pad);
+int eagle_dev_scan_certify(eagle_ctx* ctx, const int8_t* Mt8, long L, long L_pad, long n_pad, long ld, const int8_t* cshift,
+                           const int32_t* l1norm, int nslices, void* vara_ws, const double* Wu, const double* a, double* vara,
+                           void* cert_ws, void* stream);
+/* Certification counters of the LAST eagle_calculate_a_and_vara call of this ctx in digit-slice mode (summed over the
+ * marker blocks of a streamed file): markers re-evaluated in fp64, of which flagged by their own error bound, and
+ * whether a block fell back to the fp64 kernel entirely. */
+int eagle_last_scan_certificate(eagle_ctx* ctx, long* n_reevaluated, long* n_flagged, int* fell_back);
 /* The same quadratic form on the block-scaled matrix path (v_mfma_scale_f32_32x32x64_f8f6f4): genotypes as fp4, balanced
  * base-33 digits of Wu as fp6 (every integer in [-16,16] is an e2m3 number / 8), exact fp32 sums, twice the MAC rate of
  * the int8 instruction.  Mt4: [L_pad][n_pad/2] bytes made once per genotype matrix by eagle_dev_pack_fp4 (two genotypes

@@ -2,6 +2,7 @@
 refuses to open (no CPU fallback).  No compute calls here."""
 import os
 import re
+import subprocess
 
 import pytest
 
@@ -68,3 +69,18 @@ def test_c_example_runs(tmp_path):
     out = subprocess.check_output([exe, os.path.join(ROOT, "tests", "golden", "geno_150x100.txt"), "0", "1", "2", str(tmp_path)],
                                   stderr=subprocess.DEVNULL, text=True)
     assert "n=150 L=100 trace(MMt)=9748 max(MMt)=89 " in out and "closed_form_mismatches=0" in out  # SURVEY section 4 known answers
+
+
+def test_shims_typecheck():
+    """The eight Rcpp-typed translation units of eagleeverything_amd/shim/ (what a maintainer drops into the R package's
+    src/) against include/eagle_hip.h: every argument passed to the C ABI has the declared type.  No R in
+    this container, so Rcpp / Eigen are tests/stubs/Rcpp.h (declarations only, labelled test infrastructure); the exported
+    prototypes are the reference's (E/src/RcppExports.cpp:9-151)."""
+    import glob
+    shims = sorted(glob.glob(os.path.join(ROOT, "eagleeverything_amd", "shim", "*.cpp")))
+    assert len(shims) == 8
+    for f in shims:
+        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "tests", "stubs"),
+                            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "eagleeverything_amd", "shim"), f],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, f + "\n" + r.stderr

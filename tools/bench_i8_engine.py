@@ -42,7 +42,7 @@ res = {v: [] for v in variants}
 ops = (sh.np_ * (sh.np_ + 256.0)) * sh.Lp
 for rnd in range(5):
     for v in variants:
-        lib.eagle_dev_set_tune(0 if v == 8 else v % 100)
+        lib.eagle_dev_set_tune(sh.ctx, 0 if v == 8 else v % 100)
         use_f4 = v == 8
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         c32.zero_()
@@ -56,7 +56,7 @@ for rnd in range(5):
                     assert torch.equal(ref, c32), "variant %d differs" % v
         else:
             res[v].append(e0.elapsed_time(e1))
-lib.eagle_dev_set_tune(0)
+lib.eagle_dev_set_tune(sh.ctx, 0)
 for v in variants:
     ms = np.array(res[v])
     print("variant %d: median %.3f ms  min %.3f ms  -> %.0f TOP/s (median)" % (v, np.median(ms), ms.min(), ops / np.median(ms) / 1e9))

@@ -25,7 +25,7 @@ ref = None
 res = {v: [] for v in variants}
 for rnd in range(6):
     for v in variants:
-        lib.eagle_dev_set_tune(v)
+        lib.eagle_dev_set_tune(sh.ctx, v)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         sh.vara_prepare(with_a=False)  # re-zeroes q
         e0.record(); sh.vara_kernel(); e1.record()
@@ -33,7 +33,7 @@ for rnd in range(6):
         if ref is None: ref = sh.vara.clone()
         else: assert torch.equal(ref, sh.vara), "variant %d differs" % v
         if rnd: res[v].append(e0.elapsed_time(e1))
-lib.eagle_dev_set_tune(0)
+lib.eagle_dev_set_tune(sh.ctx, 0)
 print("slices used", sh.vara_i8_info())
 for v in variants:
     ms = np.array(res[v]); print("variant %d: median %.3f ms  min %.3f ms" % (v, np.median(ms), ms.min()))
