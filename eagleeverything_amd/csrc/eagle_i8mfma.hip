@@ -614,6 +614,136 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8(const int8_t* __restrict__ M
         if ((lane & 16) == 0 && keep[m]) atomicAdd((unsigned long long*)&qs[m * 32], (unsigned long long)keep[m]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_vara_i8w: the same computation on a 384 (markers) x 256 (columns) workgroup tile.
+// The 256 x 256 form reads 6 fragments from LDS per 8 MFMAs and fills 64 KiB of LDS per 32 MFMAs per wave; at 55 % MFMA busy
+// the LDS port (ds_read_b128 + LDS-DMA writes: 256 KiB per stage against 128 B/clk) is as loaded as the matrix pipe.  Here the
+// 8 waves sit 4 (M) x 2 (N) with a 96 x 128 wave tile = 3 x 4 MFMA tiles (192 accumulator registers): 7 fragment reads per
+// 12 MFMAs (-22 % LDS reads per MAC) and 80 KiB of fill per 48 MFMAs per wave (-17 % L2 -> LDS bytes per MAC).  Stages are
+// double buffered (2 x (48 + 32) KiB = all 160 KiB), so the tile epilogue takes its genotype bytes from global memory (L2).
+// Same integer sums as k_vara_i8: bit-identical q.  int32 butterfly over 128 columns per wave: n_pad < 32768.
+// ------------------------------------------------------------------------------------------------
+#define TW_M 384
+#define TW_ABYTES (TW_M * BK8)
+__device__ __forceinline__ void tw_kstep(i32x16 (&acc)[3][4], const int8_t* pa, const int8_t* pb, int ch) {
+    i32x4 a[3], b[4];
+#pragma unroll
+    for (int m = 0; m < 3; m++) a[m] = *(const i32x4*)(pa + m * (32 * BK8) + ch);
+#pragma unroll
+    for (int n = 0; n < 4; n++) b[n] = *(const i32x4*)(pb + n * (32 * BK8) + ch);
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+#pragma unroll
+        for (int n = 0; n < 4; n++) acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b[n], acc[m][n], 0, 0, 0);
+}
+// `groups` row groups (8 rows each) of an operand tile per wave: wave w issues groups w*groups .. (groups is even)
+template <int GROUPS>
+__device__ __forceinline__ void tw_stage(__amdgpu_buffer_rsrc_t rs, const T8Lane& ln, int ld, int k0, int8_t* ldsTile, int w) {
+#pragma unroll
+    for (int i = 0; i < GROUPS; i++) {
+        const int grp = w * GROUPS + i;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(ldsTile + grp * 1024), 16,
+                                                 (i & 1) ? ln.voffO : ln.voffE, grp * 8 * ld + k0, 0, 0);
+    }
+}
+__global__ __launch_bounds__(512, 2) void k_vara_i8w(const int8_t* __restrict__ Mt8, long ld, int ntm, const int8_t* __restrict__ Bs,
+                                                     long np, const VaraHdr* __restrict__ hdr, long long* __restrict__ q, long Lp) {
+    extern __shared__ __attribute__((aligned(1024))) int8_t ldsv[];  // [2][A 48 KiB | B 32 KiB]
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int nslices = hdr->S;
+    const int mt = (slot / nslices) * 8 + xcd, sl = slot % nslices;
+    if (mt >= ntm) return;
+    const int nct = (int)(np / T8), npair = (nct + 1) / 2;
+    const int8_t* Bsl = Bs + (long)sl * np * np;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = w >> 1, wc = w & 1;   // 4 x 2 waves
+    const int ldi = (int)ld, npi = (int)np;
+    const T8Lane lnA = t8_lane(lane, ldi), lnB = t8_lane(lane, npi);
+    const long row0 = (long)mt * TW_M;
+    const long rows_here = Lp - row0 < TW_M ? Lp - row0 : TW_M;  // the last marker tile may be short: rows beyond read as zero
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(Mt8 + row0 * ld), 0, (int)(rows_here * ld), 0x00020000);
+
+    VaraIt cur, nxt;
+    cur.p = 0; cur.half = 0; vit_set_tile(cur, nct, npair);
+    if (!cur.valid) return;
+    nxt = cur;
+    i32x16 acc[3][4];
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+#pragma unroll
+        for (int n = 0; n < 4; n++)
+#pragma unroll
+            for (int x = 0; x < 16; x++) acc[m][n][x] = 0;
+    long long keep[3] = {0, 0, 0};
+    const int r = lane & 31, h = lane >> 5, swz = (r >> 1) & 7;
+    const int offA = wr * (96 * BK8) + r * BK8, offB = TW_ABYTES + wc * (128 * BK8) + r * BK8;
+    int ch[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) ch[ks] = ((2 * ks + h) ^ swz) << 4;
+    const int xsel = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
+    // epilogue: genotype byte (row = wr*96 + m*32 + rx + 4h, column = ct*256 + wc*128 + n*32 + r) through the tile's buffer
+    const int evoff = (wr * 96 + 4 * h) * ldi + wc * 128 + r;
+
+    tw_stage<6>(rsA, lnA, ldi, nxt.kt * BK8, ldsv, w);
+    tw_stage<4>(t8_rsrc(Bsl + (long)nxt.ct * T8 * np, npi), lnB, npi, nxt.kt * BK8, ldsv + TW_ABYTES, w);
+    vit_advance(nxt, nct, npair);
+    __syncthreads();
+    int buf = 0;
+    while (cur.valid) {
+        const int8_t* st = ldsv + buf * (TW_ABYTES + TILE_BYTES);
+        if (nxt.valid) {
+            int8_t* nx = ldsv + (buf ^ 1) * (TW_ABYTES + TILE_BYTES);
+            tw_stage<6>(rsA, lnA, ldi, nxt.kt * BK8, nx, w);
+            tw_stage<4>(t8_rsrc(Bsl + (long)nxt.ct * T8 * np, npi), lnB, npi, nxt.kt * BK8, nx + TW_ABYTES, w);
+            vit_advance(nxt, nct, npair);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) tw_kstep(acc, st + offA, st + offB, ch[ks]);
+        if (cur.kt == cur.nk - 1) {
+            const int ecol = cur.ct * T8;
+            const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+#pragma unroll
+            for (int m = 0; m < 3; m++) {
+                int v16[16], v8[8], v4[4], v2[2];
+#pragma unroll
+                for (int x = 0; x < 16; x++) {
+                    const int so = (m * 32 + (x & 3) + 8 * (x >> 2)) * ldi + ecol;
+                    int sacc = 0;
+#pragma unroll
+                    for (int n = 0; n < 4; n++) {
+                        const int g = (int)(int8_t)__builtin_amdgcn_raw_buffer_load_b8(rsA, evoff, so + n * 32, 0);
+                        sacc += acc[m][n][x] * g;
+                        acc[m][n][x] = 0;
+                    }
+                    v16[x] = sacc;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++) { int snd = b0 ? v16[i] : v16[i + 8]; int kp = b0 ? v16[i + 8] : v16[i]; v8[i] = kp + __shfl_xor(snd, 1); }
+#pragma unroll
+                for (int i = 0; i < 4; i++) { int snd = b1 ? v8[i] : v8[i + 4]; int kp = b1 ? v8[i + 4] : v8[i]; v4[i] = kp + __shfl_xor(snd, 2); }
+#pragma unroll
+                for (int i = 0; i < 2; i++) { int snd = b2 ? v4[i] : v4[i + 2]; int kp = b2 ? v4[i + 2] : v4[i]; v2[i] = kp + __shfl_xor(snd, 4); }
+                int v1 = (b3 ? v2[1] : v2[0]) + __shfl_xor(b3 ? v2[0] : v2[1], 8);
+                v1 += __shfl_xor(v1, 16);
+                keep[m] += v1;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            vit_advance(cur, nct, npair);
+        } else {
+            cur.kt++;
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    const long qrow = row0 + wr * 96 + 4 * h + (xsel & 3) + 8 * (xsel >> 2);
+    long long* qs = q + (long)sl * Lp + qrow;
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+        if ((lane & 16) == 0 && keep[m] && qrow + m * 32 < Lp) atomicAdd((unsigned long long*)&qs[m * 32], (unsigned long long)keep[m]);
+}
+
 __global__ __launch_bounds__(256) void k_vara_i8_finish(const long long* __restrict__ q, long Lp, const VaraHdr* __restrict__ hdr,
                                                         const double* __restrict__ vdiag, const int8_t* __restrict__ cshift,
                                                         const double* __restrict__ mrho, double* __restrict__ vara) {
@@ -865,6 +995,15 @@ extern "C" int eagle_dev_vara_i8_mfma_shifted(eagle_ctx* ctx, const int8_t* Mt8s
         if (ea != hipSuccess) return eagle_fail_hip(ctx, ea, "hipFuncSetAttribute(k_vara_i8)");
         ctx->attr_vara_i8 = true;
     }
+    if (ctx->tune == 9 && n_pad < 32768) {  // the 384 x 256 tile form (A/B switch while it is being measured)
+        if (!ctx->attr_vara_i8w) {
+            hipError_t ea = hipFuncSetAttribute((const void*)k_vara_i8w, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TW_ABYTES + TILE_BYTES));
+            if (ea != hipSuccess) return eagle_fail_hip(ctx, ea, "hipFuncSetAttribute(k_vara_i8w)");
+            ctx->attr_vara_i8w = true;
+        }
+        const int ntw = (int)((L_pad + TW_M - 1) / TW_M), gw = (ntw + 7) / 8;
+        hipLaunchKernelGGL(k_vara_i8w, dim3((unsigned)(gw * 8 * smax)), dim3(512), 2 * (TW_ABYTES + TILE_BYTES), s, Mt8s, ld, ntw, Bs, n_pad, hdr, q, L_pad);
+    } else
     hipLaunchKernelGGL(k_vara_i8, dim3((unsigned)(groups * 8 * smax)), dim3(512), 5 * TILE_BYTES, s, Mt8s, ld, ntm, Bs, n_pad, hdr, q, L_pad);
     hipLaunchKernelGGL(k_vara_i8_finish, dim3((unsigned)((L_pad + 255) / 256)), dim3(256), 0, s, q, L_pad, hdr, vdiag, cshift, mrho, vara_out);
     if (err_bound_dev) hipLaunchKernelGGL(k_vara_i8_bound, dim3(1), dim3(1), 0, s, hdr, err_bound_dev, (int*)nullptr);
