@@ -21,6 +21,9 @@ class EagleBest(C.Structure):
 # name -> (restype, argtypes); must list every symbol include/eagle_hip.h declares
 SIGNATURES = {
     "eagle_open": (C.c_void_p, [C.c_int]),
+    "eagle_open_devices": (C.c_void_p, [C.POINTER(C.c_int), C.c_int]),
+    "eagle_open_env": (C.c_void_p, []),
+    "eagle_device_count": (C.c_int, [C.c_void_p]),
     "eagle_open_error": (C.c_char_p, []),
     "eagle_close": (None, [C.c_void_p]),
     "eagle_last_error": (C.c_char_p, [C.c_void_p]),
@@ -40,6 +43,11 @@ SIGNATURES = {
     "eagle_calculate_reduced_a": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double, c_dp, c_dp, C.c_double, c_lp, c_dp,
                                             C.c_long, C.c_int, c_dp]),
     "eagle_extract_geno": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double, C.c_long, c_lp, C.POINTER(C.c_int)]),
+    "eagle_sym_eig": (C.c_int, [C.c_void_p, c_dp, C.c_long, c_dp, c_dp]),
+    "eagle_chol2inv": (C.c_int, [C.c_void_p, c_dp, C.c_long, c_dp]),
+    "eagle_inverse": (C.c_int, [C.c_void_p, c_dp, C.c_long, c_dp]),
+    "eagle_matmul": (C.c_int, [C.c_void_p, c_dp, c_dp, C.c_long, C.c_long, C.c_long, c_dp]),
+    "eagle_mmt_sqrt_and_sqrtinv": (C.c_int, [C.c_void_p, c_dp, C.c_long, c_dp, c_dp, c_dp]),
     "eagle_last_scan_argmax": (C.c_int, [C.c_void_p, c_lp, c_dp, c_lp]),
     "eagle_last_mmt_normalised": (C.c_int, [C.c_void_p, c_dp, c_dp]),
     "eagle_pad": (C.c_long, [C.c_long]),
@@ -73,6 +81,10 @@ SIGNATURES = {
     "eagle_scan_certify_workspace_bytes": (C.c_int64, [C.c_long]),
     "eagle_dev_scan_certify": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p, C.c_int,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eagle_dev_scan_certify_lb": (C.c_int, [C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eagle_dev_scan_certify_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p,
+                                               C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
     "eagle_last_scan_certificate": (C.c_int, [C.c_void_p, c_lp, c_lp, C.POINTER(C.c_int)]),
     "eagle_dev_vara_i8_mfma_shifted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_int, C.c_void_p,
                                                  C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -213,7 +213,7 @@ def AM(trait, X, geno, availmemGb=8, ncpu=1, maxit=20, quiet=True, backend=None,
     Returns dict(selected_loci = 1-based marker columns in order of selection, extBIC = list, ve, vg of the last fit).
     selected_loci starts as [NA] exactly like AM.R:260, so the selected_loci masking never fires."""
     backend = backend or HipBackend()
-    if algebra is not None:  # "host" (LAPACK, the reference's placement) or "device" (SURVEY 8 f-4, rocSOLVER through torch)
+    if algebra is not None:  # "host" (LAPACK, the reference's placement) or "device" (SURVEY 8 f-4: rocSOLVER / the fp64 MFMA GEMM through the C ABI)
         host_model.set_algebra(algebra)
     say = message or (lambda *_: None)
     trait = np.asarray(trait, dtype=np.float64).ravel()

@@ -114,17 +114,143 @@ extern "C" eagle_ctx* eagle_open(int device) {
     return ctx;
 }
 
-extern "C" void eagle_drop_cache(eagle_ctx* ctx) {
-    if (!ctx) return;
+// ------------------------------------------------------------------------------------------------
+// Several GPUs behind ONE context (the hook the reference left unused: AM(..., ngpu), E/R/AM.R:185-196, hard-wired to 0 at :214
+// and handed to .find_qtl at :450-455).  The lead context owns one sub-context per further device; eagle_calculateMMt,
+// eagle_calculate_a_and_vara and eagle_calculate_reduced_a split the file's markers into contiguous ranges (boundaries at
+// multiples of 256), one per device, worked by one host thread + stream per device that are joined before the call returns.
+// Exchange steps: ONE sum of the partial int32 MM^T (upper tiles) to the lead, the rows of W = S V S shared and all-gathered,
+// the lower bounds of the shards' tsq maxima (8 bytes per device, on the host).  Between distinct devices the two device
+// collectives are RCCL (ncclReduce / ncclAllGather over xGMI, communicators from ncclCommInitAll, the library dlopen()ed on
+// first use); when the list names one card twice (how the path is tested on a one-GPU box) or EAGLE_HIP_COLLECTIVES=host,
+// the sum is staged by device-to-device copies and W is computed on every device.
+// ------------------------------------------------------------------------------------------------
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+struct RcclState {
+    void* lib = nullptr;
+    std::vector<ncclComm_t> comms;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclState* rccl_open(const int* devices, int ndev, char* err, size_t errlen) {
+    RcclState* r = new RcclState();
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+        if ((r->lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!r->lib) { snprintf(err, errlen, "cannot load librccl: %s", dlerror()); delete r; return nullptr; }
+    r->CommInitAll = (decltype(r->CommInitAll))dlsym(r->lib, "ncclCommInitAll");
+    r->CommDestroy = (decltype(r->CommDestroy))dlsym(r->lib, "ncclCommDestroy");
+    r->Reduce = (decltype(r->Reduce))dlsym(r->lib, "ncclReduce");
+    r->AllGather = (decltype(r->AllGather))dlsym(r->lib, "ncclAllGather");
+    r->GetErrorString = (decltype(r->GetErrorString))dlsym(r->lib, "ncclGetErrorString");
+    if (!r->CommInitAll || !r->CommDestroy || !r->Reduce || !r->AllGather || !r->GetErrorString) {
+        snprintf(err, errlen, "librccl lacks an entry point");
+        dlclose(r->lib); delete r; return nullptr;
+    }
+    r->comms.resize(ndev);
+    ncclResult_t rc = r->CommInitAll(r->comms.data(), ndev, devices);
+    if (rc != ncclSuccess) {
+        snprintf(err, errlen, "ncclCommInitAll: %s", r->GetErrorString(rc));
+        dlclose(r->lib); delete r; return nullptr;
+    }
+    return r;
+}
+
+extern "C" eagle_ctx* eagle_open_devices(const int* devices, int ndev) {
+    if (!devices || ndev <= 0 || ndev > 64) { snprintf(g_open_err, sizeof g_open_err, "eagle_open_devices: bad device list"); return nullptr; }
+    eagle_ctx* lead = eagle_open(devices[0]);
+    if (!lead) return nullptr;
+    for (int k = 1; k < ndev; k++) {
+        eagle_ctx* sub = eagle_open(devices[k]);
+        if (!sub) { eagle_close(lead); return nullptr; }
+        sub->lead = lead;
+        lead->peers.push_back(sub);
+    }
+    bool distinct = true;
+    for (int a = 0; a < ndev; a++) for (int b = a + 1; b < ndev; b++) if (devices[a] == devices[b]) distinct = false;
+    const char* env = getenv("EAGLE_HIP_COLLECTIVES");
+    if (ndev > 1 && distinct && !(env && strcmp(env, "host") == 0)) {
+        lead->rccl = rccl_open(devices, ndev, g_open_err, sizeof g_open_err);
+        if (!lead->rccl) { eagle_close(lead); return nullptr; }
+    }
+    (void)hipSetDevice(devices[0]);
+    return lead;
+}
+// EAGLE_HIP_DEVICES="0,1,2,3" (several GPUs), else EAGLE_HIP_DEVICE=<d>, else device 0: what the R-side shim opens.
+extern "C" eagle_ctx* eagle_open_env(void) {
+    std::vector<int> devs;
+    if (const char* e = getenv("EAGLE_HIP_DEVICES")) {
+        for (const char* p = e; *p;) {
+            char* end = nullptr;
+            long v = strtol(p, &end, 10);
+            if (end == p) { snprintf(g_open_err, sizeof g_open_err, "EAGLE_HIP_DEVICES: cannot parse '%s'", e); return nullptr; }
+            devs.push_back((int)v);
+            p = end;
+            while (*p == ',' || *p == ' ') p++;
+        }
+    }
+    if (devs.empty()) { const char* d = getenv("EAGLE_HIP_DEVICE"); devs.push_back(d ? atoi(d) : 0); }
+    return devs.size() == 1 ? eagle_open(devs[0]) : eagle_open_devices(devs.data(), (int)devs.size());
+}
+extern "C" int eagle_device_count(eagle_ctx* ctx) { return ctx ? 1 + (int)ctx->peers.size() : 0; }
+
+static inline int ndev_of(eagle_ctx* ctx) { return 1 + (int)ctx->peers.size(); }
+static inline eagle_ctx* dev_ctx(eagle_ctx* ctx, int k) { return k == 0 ? ctx : ctx->peers[k - 1]; }
+// Contiguous marker ranges, one per device; boundaries at multiples of 256 (kernel tiles, and so that the lead's range is a
+// prefix view of a whole-file image the converters may have left resident).
+static void split_markers(long L, int ndev, std::vector<long>& edge) {
+    edge.assign(ndev + 1, 0);
+    const long tiles = (L + 255) / 256;
+    for (int k = 1; k < ndev; k++) edge[k] = std::min(L, (tiles * k / ndev) * 256);
+    edge[ndev] = L;
+}
+// fn(k, ctx_k) on every device: the lead's share on the calling thread (the only one that may send messages to R), one
+// worker thread per further device; all joined before return.  First hard error wins, then the soft sentinel.
+template <class F> static int run_on_devices(eagle_ctx* ctx, F fn) {
+    const int nd = ndev_of(ctx);
+    std::vector<int> rc(nd, 0);
+    std::vector<std::thread> th;
+    for (int k = 1; k < nd; k++) th.emplace_back([&rc, &fn, ctx, k] { rc[k] = fn(k, dev_ctx(ctx, k)); });
+    rc[0] = fn(0, ctx);
+    for (auto& t : th) t.join();
+    (void)hipSetDevice(ctx->device);
+    for (int k = 0; k < nd; k++)
+        if (rc[k] < 0) {
+            if (k) { char buf[1024]; snprintf(buf, sizeof buf, "device %d: %s", dev_ctx(ctx, k)->device, dev_ctx(ctx, k)->err); snprintf(ctx->err, sizeof ctx->err, "%s", buf); }
+            return rc[k];
+        }
+    for (int k = 0; k < nd; k++) if (rc[k] > 0) return rc[k];
+    return EAGLE_OK;
+}
+
+// this device's resident genotype copies only (safe from a per-device worker thread)
+static void drop_cache_local(eagle_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     for (auto& g : ctx->cache) { if (g.dev) (void)hipFree(g.dev); if (g.dev_s) (void)hipFree(g.dev_s); if (g.cshift) (void)hipFree(g.cshift); if (g.l1) (void)hipFree(g.l1); }
     ctx->cache.clear();
     if (ctx->f4_buf) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->f4_buf); ctx->f4_buf = nullptr; ctx->f4_cap = 0; }
 }
+extern "C" void eagle_drop_cache(eagle_ctx* ctx) {
+    if (!ctx) return;
+    for (eagle_ctx* p : ctx->peers) drop_cache_local(p);
+    drop_cache_local(ctx);
+}
 
 extern "C" void eagle_close(eagle_ctx* ctx) {
     if (!ctx) return;
+    if (ctx->rccl) {
+        RcclState* r = (RcclState*)ctx->rccl;
+        for (ncclComm_t c : r->comms) if (c) (void)r->CommDestroy(c);
+        delete r;  // the library stays loaded
+        ctx->rccl = nullptr;
+    }
+    for (eagle_ctx* p : ctx->peers) eagle_close(p);
+    ctx->peers.clear();
     (void)hipSetDevice(ctx->device);
+    eagle_linalg_release(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     eagle_drop_cache(ctx);
     if (ctx->d_mmt) (void)hipFree(ctx->d_mmt);
@@ -136,6 +262,9 @@ extern "C" void eagle_close(eagle_ctx* ctx) {
     if (ctx->gemv_ws) (void)hipFree(ctx->gemv_ws);
     if (ctx->f4_buf) (void)hipFree(ctx->f4_buf);
     if (ctx->gemm_scratch) (void)hipFree(ctx->gemm_scratch);
+    if (ctx->d_c32) (void)hipFree(ctx->d_c32);
+    if (ctx->d_pack) (void)hipFree(ctx->d_pack);
+    if (ctx->d_pack2) (void)hipFree(ctx->d_pack2);
     for (int b = 0; b < 2; b++) { if (ctx->stage_pin[b]) (void)hipHostFree(ctx->stage_pin[b]); if (ctx->stage_raw[b]) (void)hipFree(ctx->stage_raw[b]); }
     (void)hipStreamDestroy(ctx->stream);
     if (ctx->load_stream) (void)hipStreamDestroy(ctx->load_stream);
@@ -165,11 +294,13 @@ extern "C" int eagle_device_info(eagle_ctx* ctx, char* arch_out, int arch_len, i
 extern "C" int eagle_set_scan_mode(eagle_ctx* ctx, int mode) {
     if (!ctx || mode < 0 || mode > 1) return EAGLE_ERR_ARG;
     ctx->scan_mode = mode;
+    for (eagle_ctx* p : ctx->peers) p->scan_mode = mode;
     return EAGLE_OK;
 }
 extern "C" int eagle_set_scan_slices(eagle_ctx* ctx, int nslices) {
     if (!ctx || nslices < 0 || nslices > 8) return EAGLE_ERR_ARG;
     ctx->scan_slices = nslices;
+    for (eagle_ctx* p : ctx->peers) p->scan_slices = nslices;
     return EAGLE_OK;
 }
 
@@ -487,20 +618,38 @@ static bool file_key(const char* path, off_t* size, long* mtime_ns) {
     *mtime_ns = (long)st.st_mtim.tv_sec * 1000000000L + st.st_mtim.tv_nsec;
     return true;
 }
+static void free_entry(GenoEntry& g) {
+    if (g.dev) (void)hipFree(g.dev);
+    if (g.dev_s) (void)hipFree(g.dev_s);
+    if (g.cshift) (void)hipFree(g.cshift);
+    if (g.l1) (void)hipFree(g.l1);
+    g.dev = g.dev_s = g.cshift = nullptr; g.l1 = nullptr;
+}
+// Whole-file resident copy (rows lines x cols characters from the origin), current size and mtime.
 const GenoEntry* eagle_cache_find(eagle_ctx* ctx, const char* path, long rows, long cols) {
     off_t size; long mt;
     if (!file_key(path, &size, &mt)) return nullptr;
     for (auto& g : ctx->cache)
-        if (g.path == path && g.size == size && g.mtime_ns == mt && g.rows == rows && g.cols == cols) return &g;
+        if (g.path == path && g.size == size && g.mtime_ns == mt && g.row0 == 0 && g.col0 == 0 && g.rows == rows && g.cols == cols) return &g;
+    return nullptr;
+}
+// An entry that can serve the window [row0, row0+rows) x [col0, col0+cols): the same window, or an image from the origin that
+// holds it as a prefix (all columns and the first `rows` lines, or all lines and the first `cols` characters): what the lead of
+// a multi-device context finds when the converters left the whole file resident.
+static GenoEntry* cache_find_window(eagle_ctx* ctx, const char* path, off_t size, long mt, long row0, long rows, long col0, long cols) {
+    for (auto& g : ctx->cache) {
+        if (!(g.path == path && g.size == size && g.mtime_ns == mt)) continue;
+        if (g.row0 == row0 && g.col0 == col0 && g.rows == rows && g.cols == cols) return &g;
+        if (row0 == 0 && col0 == 0 && g.row0 == 0 && g.col0 == 0 &&
+            ((g.cols == cols && g.rows >= rows && rows % 256 == 0) || (g.rows == rows && g.cols >= cols && cols % 256 == 0)))
+            return &g;
+    }
     return nullptr;
 }
 static void cache_drop_path(eagle_ctx* ctx, const char* path) {
     for (size_t i = 0; i < ctx->cache.size();)
         if (ctx->cache[i].path == path) {
-            (void)hipFree(ctx->cache[i].dev);
-            if (ctx->cache[i].dev_s) (void)hipFree(ctx->cache[i].dev_s);
-            if (ctx->cache[i].cshift) (void)hipFree(ctx->cache[i].cshift);
-            if (ctx->cache[i].l1) (void)hipFree(ctx->cache[i].l1);
+            free_entry(ctx->cache[i]);
             ctx->cache.erase(ctx->cache.begin() + i);
         } else i++;
 }
@@ -513,28 +662,33 @@ int eagle_cache_adopt(eagle_ctx* ctx, const char* path, long rows, long cols, lo
     return EAGLE_OK;
 }
 
-static int get_resident(eagle_ctx* ctx, const char* path, long rows, long cols, double max_mem_gb, int threads,
+// Resident int8 image of the window [row0, row0+rows) x [col0, col0+cols) of a genotype text file, zero padded to
+// [pad256(rows)][pad256(cols)] (the whole file: row0 = col0 = 0).
+// Returns EAGLE_OK (*out set), EAGLE_STREAM (too large: the caller streams marker chunks) or an error.
+// reserve_bytes: HBM the caller still needs for operands and workspaces.
+static int get_resident(eagle_ctx* ctx, const char* path, long row0, long rows, long col0, long cols, double max_mem_gb, int threads,
                         GenoEntry** out, size_t reserve_bytes = (size_t)1 << 30) {
     off_t fsize; long mt;
     if (!file_key(path, &fsize, &mt)) return failf(ctx, EAGLE_ERR_OPEN, "ERROR: Could not open  %s", path);
-    if (const GenoEntry* hit = eagle_cache_find(ctx, path, rows, cols)) { *out = const_cast<GenoEntry*>(hit); return EAGLE_OK; }
-    cache_drop_path(ctx, path);  // stale entries of the same path
+    if (GenoEntry* hit = cache_find_window(ctx, path, fsize, mt, row0, rows, col0, cols)) { *out = hit; return EAGLE_OK; }
+    for (size_t i = 0; i < ctx->cache.size();)  // stale entries of the same path (the file changed) and other windows of it
+        if (ctx->cache[i].path == path) { free_entry(ctx->cache[i]); ctx->cache.erase(ctx->cache.begin() + i); } else i++;
     GenoEntry g;
-    g.path = path; g.size = fsize; g.mtime_ns = mt; g.rows = rows; g.cols = cols;
+    g.path = path; g.size = fsize; g.mtime_ns = mt; g.rows = rows; g.cols = cols; g.row0 = row0; g.col0 = col0;
     g.rows_pad = eagle_pad(rows); g.ld = eagle_pad(cols);
     size_t bytes = (size_t)g.rows_pad * (size_t)g.ld;
     if (bytes > resident_budget()) return EAGLE_STREAM;
     size_t freeb = 0, totalb = 0;
     HIPCHK(ctx, hipMemGetInfo(&freeb, &totalb));
     if (bytes + reserve_bytes > freeb) {
-        eagle_drop_cache(ctx);
+        drop_cache_local(ctx);
         HIPCHK(ctx, hipMemGetInfo(&freeb, &totalb));
         if (bytes + reserve_bytes > freeb) return EAGLE_STREAM;  // does not fit beside the operands: stream it
     }
     HIPCHK(ctx, hipMalloc((void**)&g.dev, bytes));
     hipError_t e = hipMemsetAsync(g.dev, 0, bytes, ctx->stream);
     if (e != hipSuccess) { (void)hipFree(g.dev); return eagle_fail_hip(ctx, e, "memset"); }
-    int rc = eagle_dev_load_ascii(ctx, path, 0, rows, 0, cols, g.dev, g.ld, max_mem_gb, threads);
+    int rc = eagle_dev_load_ascii(ctx, path, row0, rows, col0, cols, g.dev, g.ld, max_mem_gb, threads);
     if (rc) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(g.dev); return rc; }
     ctx->cache.push_back(g);
     *out = &ctx->cache.back();
@@ -543,7 +697,7 @@ static int get_resident(eagle_ctx* ctx, const char* path, long rows, long cols, 
 
 int eagle_get_resident(eagle_ctx* ctx, const char* path, long rows, long cols, double max_mem_gb, int threads, const GenoEntry** out) {
     GenoEntry* g = nullptr;
-    int rc = get_resident(ctx, path, rows, cols, max_mem_gb, threads, &g);
+    int rc = get_resident(ctx, path, 0, rows, 0, cols, max_mem_gb, threads, &g);
     *out = g;
     return rc;
 }
@@ -629,6 +783,78 @@ extern "C" int eagle_read_block(eagle_ctx* ctx, const char* asciifname, long sta
     return EAGLE_OK;
 }
 
+// grow-only ctx-owned device buffer
+template <class T> static int ensure_buf(eagle_ctx* ctx, T** buf, size_t* cap, size_t bytes, const char* what) {
+    if (bytes <= *cap) return EAGLE_OK;
+    if (*buf) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(*buf); *buf = nullptr; *cap = 0; }
+    hipError_t e = hipMalloc((void**)buf, bytes);
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, what);
+    *cap = bytes;
+    return EAGLE_OK;
+}
+
+// Exact int32 partial  sum_{c in [c0, c1)} m_c m_c^T  into ctx->d_c32 (zeroed here; upper 256-tiles live), with the columns of
+// `sel` that fall into the range masked (calculateMMt_rcpp.cpp:88-92 as an exact rank-k downdate).  The window of M.ascii is
+// kept resident if it fits, else streamed through HBM in marker windows.
+static int mmt_range(eagle_ctx* ctx, const char* path, long n, long L, long c0, long c1, const std::vector<long>& sel, double mem_gb,
+                     int threads, int quiet) {
+    const long np = eagle_pad(n);
+    int rc = ensure_buf(ctx, &ctx->d_c32, &ctx->c32_cap, sizeof(int32_t) * (size_t)np * np, "MM^T accumulator hipMalloc");
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_c32, 0, sizeof(int32_t) * (size_t)np * np, ctx->stream));
+    const long Lw_all = c1 - c0;
+    if (Lw_all <= 0) return EAGLE_OK;
+    GenoEntry* g = nullptr;
+    rc = get_resident(ctx, path, 0, n, c0, Lw_all, mem_gb, threads, &g, sizeof(int32_t) * (size_t)np * np);
+    if (rc < 0) return rc;
+    std::vector<long> in_range;
+    for (long c : sel) if (c >= c0 && c < c1) in_range.push_back(c - c0);
+    DevBuf dsel, win;
+    if (rc == EAGLE_OK) {
+        rc = eagle_dev_mmt_accumulate(ctx, g->dev, np, eagle_pad(Lw_all), g->ld, ctx->d_c32, ctx->stream);
+        if (rc) return rc;
+        if (!in_range.empty()) {
+            HIPCHK(ctx, dsel.alloc(sizeof(long) * in_range.size()));
+            HIPCHK(ctx, hipMemcpyAsync(dsel.p, in_range.data(), sizeof(long) * in_range.size(), hipMemcpyHostToDevice, ctx->stream));
+            rc = eagle_dev_mmt_downdate(ctx, g->dev, np, g->ld, dsel.as<long>(), (long)in_range.size(), ctx->d_c32, ctx->stream);
+            if (rc) return rc;
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        return EAGLE_OK;
+    }
+    // the window does not fit (or may not stay) in HBM: stream column windows of every line (= marker chunks) and accumulate
+    // the exact integer partial products, MMt = sum_w M_w M_w^T.
+    const long Lw = stream_chunk_rows(np, eagle_pad(Lw_all));  // window width in markers; rows of the window = np
+    HIPCHK(ctx, win.alloc((size_t)2 * np * Lw));
+    ChunkRing ring;
+    if ((rc = ring.init(ctx))) return rc;
+    ring.buf[0] = win.as<int8_t>();
+    ring.buf[1] = win.as<int8_t>() + (size_t)np * Lw;
+    if (!quiet) say(ctx, " M.ascii streamed through HBM in windows of %ld markers", Lw);
+    for (long w0 = 0; w0 < Lw_all; w0 += Lw) {
+        const long nc = std::min(Lw, Lw_all - w0);
+        int8_t* wtile = nullptr;
+        rc = ring.load(ctx, path, 0, n, c0 + w0, nc, Lw, (size_t)np * Lw, mem_gb, threads, &wtile);
+        if (rc) return rc;
+        rc = eagle_dev_mmt_accumulate(ctx, wtile, np, Lw, Lw, ctx->d_c32, ctx->stream);
+        if (rc) return rc;
+        std::vector<long> in_win;
+        for (long c : in_range) if (c >= w0 && c < w0 + nc) in_win.push_back(c - w0);
+        if (!in_win.empty()) {
+            DevBuf dw;
+            HIPCHK(ctx, dw.alloc(sizeof(long) * in_win.size()));
+            HIPCHK(ctx, hipMemcpyAsync(dw.p, in_win.data(), sizeof(long) * in_win.size(), hipMemcpyHostToDevice, ctx->stream));
+            // duplicates of one column must be dropped across the whole list, which k_mmt_downdate does per call:
+            // selected_loci entries are distinct columns in any sane call; duplicates inside one window are handled
+            rc = eagle_dev_mmt_downdate(ctx, wtile, np, Lw, dw.as<long>(), (long)in_win.size(), ctx->d_c32, ctx->stream);
+            if (rc) return rc;
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        if ((rc = ring.computed(ctx))) return rc;
+    }
+    return EAGLE_OK;
+}
+
 extern "C" int eagle_calculateMMt(eagle_ctx* ctx, const char* f_name_ascii, double max_memory_in_Gbytes, int num_cores,
                                   const double* selected_loci, long n_selected, const long dims[2], int quiet,
                                   double* MMt_out) {
@@ -651,53 +877,43 @@ extern "C" int eagle_calculateMMt(eagle_ctx* ctx, const char* f_name_ascii, doub
     }
     const int threads = num_cores > 0 ? num_cores : 1;
     const long np = eagle_pad(n);
-    GenoEntry* g = nullptr;
-    rc = get_resident(ctx, f_name_ascii, n, L, max_memory_in_Gbytes, threads, &g, sizeof(int32_t) * (size_t)np * np * 2);
-    if (rc < 0) return rc;
-    DevBuf c32, dsel, win;
-    HIPCHK(ctx, c32.alloc(sizeof(int32_t) * (size_t)np * np));
-    HIPCHK(ctx, hipMemsetAsync(c32.p, 0, sizeof(int32_t) * (size_t)np * np, ctx->stream));
-    if (rc == EAGLE_OK) {
-        rc = eagle_dev_mmt_accumulate(ctx, g->dev, np, g->ld, g->ld, c32.as<int32_t>(), ctx->stream);
-        if (rc) return rc;
-        if (!sel.empty()) {  // :88-92 as an exact rank-k downdate
-            HIPCHK(ctx, dsel.alloc(sizeof(long) * sel.size()));
-            HIPCHK(ctx, hipMemcpyAsync(dsel.p, sel.data(), sizeof(long) * sel.size(), hipMemcpyHostToDevice, ctx->stream));
-            rc = eagle_dev_mmt_downdate(ctx, g->dev, np, g->ld, dsel.as<long>(), (long)sel.size(), c32.as<int32_t>(), ctx->stream);
-            if (rc) return rc;
-        }
-    } else {
-        // M.ascii does not fit (or may not stay) in HBM: stream column windows of every line (= marker chunks) and
-        // accumulate the exact integer partial products, MMt = sum_w M_w M_w^T.
-        const long Lw = stream_chunk_rows(np, eagle_pad(L));  // window width in markers; rows of the window = np
-        HIPCHK(ctx, win.alloc((size_t)2 * np * Lw));
-        ChunkRing ring;
-        if ((rc = ring.init(ctx))) return rc;
-        ring.buf[0] = win.as<int8_t>();
-        ring.buf[1] = win.as<int8_t>() + (size_t)np * Lw;
-        if (!quiet) say(ctx, " M.ascii streamed through HBM in windows of %ld markers", Lw);
-        for (long c0 = 0; c0 < L; c0 += Lw) {
-            const long nc = std::min(Lw, L - c0);
-            int8_t* wtile = nullptr;
-            rc = ring.load(ctx, f_name_ascii, 0, n, c0, nc, Lw, (size_t)np * Lw, max_memory_in_Gbytes, threads, &wtile);
-            if (rc) return rc;
-            rc = eagle_dev_mmt_accumulate(ctx, wtile, np, Lw, Lw, c32.as<int32_t>(), ctx->stream);
-            if (rc) return rc;
-            std::vector<long> in_win;
-            for (long c : sel) if (c >= c0 && c < c0 + nc) in_win.push_back(c - c0);
-            if (!in_win.empty()) {
-                DevBuf dw;
-                HIPCHK(ctx, dw.alloc(sizeof(long) * in_win.size()));
-                HIPCHK(ctx, hipMemcpyAsync(dw.p, in_win.data(), sizeof(long) * in_win.size(), hipMemcpyHostToDevice, ctx->stream));
-                // duplicates of one column must be dropped across the whole list, which k_mmt_downdate does per call:
-                // selected_loci entries are distinct columns in any sane call; duplicates inside one window are handled
-                rc = eagle_dev_mmt_downdate(ctx, wtile, np, Lw, dw.as<long>(), (long)in_win.size(), c32.as<int32_t>(), ctx->stream);
-                if (rc) return rc;
-                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const int nd = ndev_of(ctx);
+    std::vector<long> edge;
+    split_markers(L, nd, edge);
+    const long packed = eagle_upper_tiles_count(np);
+    RcclState* rccl = (RcclState*)ctx->rccl;
+    Rendezvous rv;
+    rv.n = nd;
+    rc = run_on_devices(ctx, [&](int k, eagle_ctx* c) -> int {
+        hipError_t e = hipSetDevice(c->device);
+        int r = e == hipSuccess ? mmt_range(c, f_name_ascii, n, L, edge[k], edge[k + 1], sel, max_memory_in_Gbytes, threads, quiet)
+                                : eagle_fail_hip(c, e, "hipSetDevice");
+        if (nd == 1) return r;
+        // ONE sum of the partials: the upper 256-tiles of every device's accumulator, packed, to the lead
+        if (!r) r = ensure_buf(c, &c->d_pack, &c->pack_cap, sizeof(int32_t) * (size_t)packed, "packed MM^T hipMalloc");
+        if (!r) r = eagle_dev_tiles_pack(c, c->d_c32, np, c->d_pack, 0, c->stream);
+        if (!r && (e = hipStreamSynchronize(c->stream)) != hipSuccess) r = eagle_fail_hip(c, e, "MM^T partial");
+        if (!rv.arrive(r == 0)) return r ? r : eagle_fail(c, EAGLE_ERR_HIP, "another device failed before the MM^T sum");
+        if (rccl) {
+            ncclResult_t nr = rccl->Reduce(c->d_pack, c->d_pack, (size_t)packed, ncclInt32, ncclSum, 0, rccl->comms[k], c->stream);
+            if (nr != ncclSuccess) r = failf(c, EAGLE_ERR_HIP, "ncclReduce: %s", rccl->GetErrorString(nr));
+            else if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) r = eagle_fail_hip(c, e, "ncclReduce sync");
+        } else if (k == 0) {  // host-staged stand-in: the peers' packed tiles are copied to the lead and added, one by one
+            r = ensure_buf(c, &c->d_pack2, &c->pack2_cap, sizeof(int32_t) * (size_t)packed, "packed MM^T landing buffer");
+            for (int p = 1; p < nd && !r; p++) {
+                eagle_ctx* pc = dev_ctx(ctx, p);
+                e = pc->device == c->device ? hipMemcpyAsync(c->d_pack2, pc->d_pack, sizeof(int32_t) * (size_t)packed, hipMemcpyDeviceToDevice, c->stream)
+                                            : hipMemcpyPeerAsync(c->d_pack2, c->device, pc->d_pack, pc->device, sizeof(int32_t) * (size_t)packed, c->stream);
+                if (e != hipSuccess) { r = eagle_fail_hip(c, e, "peer copy of a partial MM^T"); break; }
+                r = eagle_dev_add_i32(c, c->d_pack, c->d_pack2, packed, c->stream);
             }
-            if ((rc = ring.computed(ctx))) return rc;
+            if (!r && (e = hipStreamSynchronize(c->stream)) != hipSuccess) r = eagle_fail_hip(c, e, "staged MM^T sum");
         }
-    }
+        rv.arrive(r == 0);  // the peers keep their buffers until the lead has read them
+        return r;
+    });
+    if (rc) return rc;
+    if (nd > 1 && (rc = eagle_dev_tiles_pack(ctx, ctx->d_c32, np, ctx->d_pack, 1, ctx->stream))) return rc;
     if (ctx->mmt_n != n) {
         if (ctx->d_mmt) { (void)hipFree(ctx->d_mmt); ctx->d_mmt = nullptr; }
         ctx->mmt_n = 0;
@@ -705,7 +921,7 @@ extern "C" int eagle_calculateMMt(eagle_ctx* ctx, const char* f_name_ascii, doub
         ctx->mmt_n = n;
     }
     if (!ctx->d_mmt_max) HIPCHK(ctx, hipMalloc((void**)&ctx->d_mmt_max, sizeof(double)));
-    rc = eagle_dev_mmt_finish(ctx, c32.as<int32_t>(), n, np, ctx->d_mmt, n, ctx->d_mmt_max, ctx->stream);
+    rc = eagle_dev_mmt_finish(ctx, ctx->d_c32, n, np, ctx->d_mmt, n, ctx->d_mmt_max, ctx->stream);
     if (rc) return rc;
     HIPCHK(ctx, hipMemcpyAsync(MMt_out, ctx->d_mmt, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -738,6 +954,202 @@ static int ensure_scan_out(eagle_ctx* ctx, long L_pad) {
     return EAGLE_OK;
 }
 
+// The scan of the markers [m0, m1) of Mt.ascii on ctx's device: a, vara into ctx->d_a / d_vara (and the host ranges
+// a_out[m0..m1), vara_out[m0..m1)).  k of nd devices; rv / rccl: the meeting point and the communicators of a multi-device call
+// (NULL for one device).  Every device passes the same rendezvous in the same order, failed or not.
+static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, long m0, long m1, const std::vector<long>& sel,
+                      const double* inv_MMt_sqrt, const double* dim_reduced_vara, const double* a, double max_memory_in_Gbytes, int quiet,
+                      double* a_out, double* vara_out, int k, int nd, Rendezvous* rv, RcclState* rccl) {
+    const long Lr = m1 - m0;
+    const long np = eagle_pad(n), Lp = eagle_pad(Lr > 0 ? Lr : 1);
+    const size_t sq = sizeof(double) * (size_t)np * np;
+    const bool use_i8 = ctx->scan_mode == 1 && 64.0 * 512.0 * (double)np < 2147483648.0;
+    const int nslices = ctx->scan_slices;
+    const bool share_w = nd > 1 && rccl && (np / 128) % nd == 0;  // the same answer on every device
+    int rc = EAGLE_OK;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) rc = eagle_fail_hip(ctx, e, "hipSetDevice");
+#define EAGLE_ARRIVE(v)                                                                                            \
+    do {                                                                                                           \
+        if (rv && !rv->arrive(rc == EAGLE_OK, (v))) return rc ? rc : eagle_fail(ctx, EAGLE_ERR_HIP, "another device of the scan failed"); \
+        if (!rv && rc) return rc;                                                                                  \
+    } while (0)
+    GenoEntry* g = nullptr;
+    bool streamed = false;
+    if (!rc && Lr > 0) {
+        int r = get_resident(ctx, f_name_ascii, m0, Lr, 0, n, max_memory_in_Gbytes, host_threads(), &g,
+                             4 * sq + (use_i8 ? (size_t)eagle_vara_i8_workspace_bytes(np, Lp, nslices) + (size_t)Lp * np + 5 * (size_t)Lp +
+                                                    (size_t)eagle_scan_certify_workspace_bytes(np) : 0) +
+                                 ((size_t)1 << 30));  // operands, digit + certification workspaces, the re-centred image of the shard
+        if (r < 0) rc = r;
+        streamed = (r == EAGLE_STREAM);
+    }
+    EAGLE_ARRIVE(streamed ? 1.0 : 0.0);
+    // certification against the maximum over ALL devices' shards needs every shard resident (one block per device)
+    const bool global_cert = rv && use_i8 && rv->vmax < 0.5;
+    const long Lc = streamed ? stream_chunk_rows(np, Lp) : Lp;  // marker rows per pass
+    DevBuf dsel;
+    const size_t wsb = use_i8 ? (size_t)eagle_vara_i8_workspace_bytes(np, Lc, nslices) : 0;
+    const size_t certb = use_i8 ? (size_t)eagle_scan_certify_workspace_bytes(np) : 0;
+    const double t0 = now_s();
+    double *Sa = nullptr, *Va = nullptr, *tmp = nullptr, *Wu = nullptr, *ah = nullptr, *v = nullptr;
+    void *ws = nullptr, *cert = nullptr;
+    long* cert_totals = (long*)((char*)ctx->d_scratch + 256);  // {re-evaluated, flagged, fell back}, summed over marker blocks
+    ChunkRing ring;
+    int8_t* shifted[2] = {nullptr, nullptr};
+    int8_t* cs[2] = {nullptr, nullptr};
+    int32_t* l1s[2] = {nullptr, nullptr};
+    auto setup = [&]() -> int {
+        int r = arena_reserve(ctx, 4 * arena_round(sq) + 2 * arena_round(sizeof(double) * np) + arena_round(wsb) + arena_round(certb) +
+                                       (streamed ? (use_i8 ? 4 : 2) * arena_round((size_t)Lc * np) + 2 * arena_round((size_t)Lc) +
+                                                       2 * arena_round(sizeof(int32_t) * (size_t)Lc) : 0));
+        if (r) return r;
+        Sa = arena_take<double>(ctx, sq);
+        Va = arena_take<double>(ctx, sq);
+        tmp = arena_take<double>(ctx, sq);
+        Wu = arena_take<double>(ctx, sq);
+        ah = arena_take<double>(ctx, sizeof(double) * np);
+        v = arena_take<double>(ctx, sizeof(double) * np);
+        ws = arena_take<char>(ctx, wsb);
+        cert = arena_take<char>(ctx, certb);
+        if (streamed) {
+            if ((r = ring.init(ctx))) return r;
+            ring.buf[0] = arena_take<int8_t>(ctx, (size_t)Lc * np);
+            ring.buf[1] = arena_take<int8_t>(ctx, (size_t)Lc * np);
+            for (int b = 0; b < 2 && use_i8; b++) {
+                shifted[b] = arena_take<int8_t>(ctx, (size_t)Lc * np);
+                cs[b] = arena_take<int8_t>(ctx, (size_t)Lc);
+                l1s[b] = arena_take<int32_t>(ctx, sizeof(int32_t) * (size_t)Lc);
+            }
+        }
+        if ((r = upload_square(ctx, inv_MMt_sqrt, n, np, Sa))) return r;
+        if ((r = upload_square(ctx, dim_reduced_vara, n, np, Va))) return r;
+        if ((r = upload_vec(ctx, a, n, np, ah))) return r;
+        if ((r = ensure_scan_out(ctx, Lp))) return r;
+        HIPCHK(ctx, hipMemsetAsync(cert_totals, 0, 3 * sizeof(long), ctx->stream));
+        return EAGLE_OK;
+    };
+    if (!rc) rc = setup();
+    double t1 = 0;
+    if (timing_on() && !rc) { (void)hipStreamSynchronize(ctx->stream); t1 = now_s(); }
+    // W = S (V S) and v = S a_hat.  Several devices: each computes 1/nd of the rows of W's image and ONE all-gather completes
+    // it everywhere (the n^3 part would otherwise not scale); without device collectives every device computes all of it.
+    if (share_w) {
+        const long rows = np / nd, r0 = k * rows;
+        if (!rc) rc = eagle_dev_scan_operands_rows(ctx, Sa, Va, ah, n, np, r0, r0 + rows, v, Wu, tmp, ctx->stream);
+        if (!rc && (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) rc = eagle_fail_hip(ctx, e, "rows of W");
+        EAGLE_ARRIVE(0.0);
+        ncclResult_t nr = rccl->AllGather(Wu + r0 * np, Wu, (size_t)(rows * np), ncclDouble, rccl->comms[k], ctx->stream);
+        if (nr != ncclSuccess) rc = failf(ctx, EAGLE_ERR_HIP, "ncclAllGather: %s", rccl->GetErrorString(nr));
+        if (!rc) rc = eagle_dev_fold_upper(ctx, Wu, np, ctx->stream);
+    } else if (!rc) {
+        rc = eagle_dev_scan_operands(ctx, Sa, Va, ah, n, np, v, Wu, tmp, ctx->stream);
+    }
+    if (!rc && streamed && !quiet) say(ctx, " Mt.ascii streamed through HBM in blocks of %ld markers", Lc);
+    // one pass per marker block: the whole shard when it is resident, else chunks read back from the file
+    for (long r0 = 0; r0 < Lr && !rc; r0 += Lc) {
+        const long nr = std::min(Lc, Lr - r0), nrp = eagle_pad(nr);
+        const int8_t* Mt8 = streamed ? nullptr : g->dev;
+        const long ldm = streamed ? np : g->ld;
+        if (streamed) {
+            int8_t* tile = nullptr;
+            rc = ring.load(ctx, f_name_ascii, m0 + r0, nr, 0, n, np, (size_t)nrp * np, max_memory_in_Gbytes, host_threads(), &tile);
+            if (rc) break;
+            Mt8 = tile;
+        }
+        if (use_i8) {
+            // re-centred image of the markers (kept with a resident file, rebuilt per chunk when streaming)
+            const int8_t* Ms = nullptr;
+            const int8_t* cv = nullptr;
+            const int32_t* l1 = nullptr;
+            if (streamed) {
+                const int b = (int)(ring.k & 1);
+                rc = eagle_dev_marker_shift(ctx, Mt8, nrp, n, np, ldm, shifted[b], cs[b], l1s[b], ctx->stream);
+                if (rc) break;
+                Ms = shifted[b]; cv = cs[b]; l1 = l1s[b];
+            } else {
+                if (!g->dev_s) {
+                    e = hipMalloc((void**)&g->dev_s, (size_t)g->rows_pad * g->ld);
+                    if (e == hipSuccess) e = hipMalloc((void**)&g->cshift, (size_t)g->rows_pad);
+                    if (e == hipSuccess) e = hipMalloc((void**)&g->l1, sizeof(int32_t) * (size_t)g->rows_pad);
+                    rc = e == hipSuccess ? eagle_dev_marker_shift(ctx, g->dev, g->rows_pad, n, np, g->ld, g->dev_s, g->cshift, g->l1, ctx->stream)
+                                         : eagle_fail_hip(ctx, e, "re-centred image hipMalloc");
+                    if (rc) {  // never leave a half-made image behind: the next call would scan garbage
+                        if (g->dev_s) (void)hipFree(g->dev_s);
+                        if (g->cshift) (void)hipFree(g->cshift);
+                        if (g->l1) (void)hipFree(g->l1);
+                        g->dev_s = nullptr; g->cshift = nullptr; g->l1 = nullptr;
+                        break;
+                    }
+                }
+                Ms = g->dev_s; cv = g->cshift; l1 = g->l1;
+            }
+            // one pass over the genotypes gives a = Mt v and the diagonal term of vara; then the int8 MFMA kernel
+            rc = eagle_dev_vara_i8_prepare(ctx, Mt8, nrp, np, ldm, Wu, nslices, ws, v, ctx->d_a + r0, ctx->stream);
+            if (rc) break;
+            rc = eagle_dev_vara_i8_mfma_shifted(ctx, Ms, cv, nrp, np, ldm, nslices, ws, ctx->d_vara + r0, nullptr, ctx->stream);
+            if (rc) break;
+            // a-posteriori certificate: markers the digit bounds cannot settle are re-evaluated by the fp64 kernel, so that
+            // which(tsq == max(tsq))[1] on the returned arrays is the marker the fp64 scan selects (find_qtl.R:71-83).  A
+            // streamed file is certified block by block against the block's own maximum (a superset of the global candidates);
+            // resident shards of a multi-device scan exchange their lower bounds first (below), so that the candidates -- and
+            // with them every returned bit -- are those of the single-device scan.
+            if (global_cert) {
+                rc = eagle_dev_scan_certify_lb(ctx, nr, nrp, np, cv, l1, nslices, ws, ctx->d_a + r0, ctx->d_vara + r0, cert, ctx->stream);
+            } else {
+                rc = eagle_dev_scan_certify(ctx, Mt8, nr, nrp, np, ldm, cv, l1, nslices, ws, Wu, ctx->d_a + r0, ctx->d_vara + r0, cert, ctx->stream);
+                if (!rc) rc = eagle_dev_cert_accumulate(ctx, cert, cert_totals, ctx->stream);
+            }
+        } else {
+            rc = eagle_dev_gemv_i8(ctx, Mt8, nrp, np, ldm, v, 1.0, ctx->d_a + r0, ctx->stream);
+            if (rc) break;
+            rc = eagle_dev_vara_f64(ctx, Mt8, nrp, np, ldm, Wu, ctx->d_vara + r0, ctx->stream);
+        }
+        if (rc) break;
+        if (streamed && (rc = ring.computed(ctx))) break;
+    }
+    if (global_cert) {
+        double lb = 0.0;  // this shard's lower bound of the maximum tsq (0 for an empty shard)
+        if (!rc && Lr > 0) {
+            e = hipMemcpyAsync(&lb, cert, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) rc = eagle_fail_hip(ctx, e, "lower bound of the shard's maximum");
+        }
+        EAGLE_ARRIVE(lb);
+        if (Lr > 0) {
+            rc = eagle_dev_scan_certify_apply(ctx, g->dev, Lr, Lp, np, g->ld, g->cshift, g->l1, nslices, ws, Wu, ctx->d_a, ctx->d_vara, cert,
+                                              rv->vmax, ctx->stream);
+            if (!rc) rc = eagle_dev_cert_accumulate(ctx, cert, cert_totals, ctx->stream);
+        }
+    }
+#undef EAGLE_ARRIVE
+    if (timing_on() && !rc) {
+        (void)hipStreamSynchronize(ctx->stream);
+        fprintf(stderr, "[eaglehip] scan n=%ld markers [%ld, %ld) of %ld on device %d%s: alloc+upload %.1f ms, device compute %.1f ms\n", n, m0, m1, L,
+                ctx->device, streamed ? " (streamed)" : "", (t1 - t0) * 1e3, (now_s() - t1) * 1e3);
+    }
+    if (rc) return rc;
+    std::vector<long> in_range;
+    for (long r : sel) if (r >= m0 && r < m1) in_range.push_back(r - m0);
+    if (!in_range.empty()) {  // :79-84: a zeroed marker row gives a = 0 and vara = 0 exactly
+        HIPCHK(ctx, dsel.alloc(sizeof(long) * in_range.size()));
+        HIPCHK(ctx, hipMemcpyAsync(dsel.p, in_range.data(), sizeof(long) * in_range.size(), hipMemcpyHostToDevice, ctx->stream));
+        rc = eagle_dev_zero_rows(ctx, ctx->d_a, ctx->d_vara, Lr, dsel.as<long>(), (long)in_range.size(), 0, ctx->stream);
+        if (rc) return rc;
+    }
+    ctx->scan_L = Lr;
+    ctx->scan_first = m0;
+    long totals[3] = {0, 0, 0};
+    if (Lr > 0) {
+        HIPCHK(ctx, hipMemcpyAsync(a_out + m0, ctx->d_a, sizeof(double) * (size_t)Lr, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(vara_out + m0, ctx->d_vara, sizeof(double) * (size_t)Lr, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(totals, cert_totals, sizeof totals, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->cert_reevaluated = totals[0]; ctx->cert_flagged = totals[1]; ctx->cert_fell_back = totals[2] != 0;
+    return EAGLE_OK;
+}
+
 extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_ascii, const double* selected_loci,
                                           long n_selected, const double* inv_MMt_sqrt, const double* dim_reduced_vara,
                                           double max_memory_in_Gbytes, const long dims[2], const double* a, int quiet,
@@ -765,135 +1177,20 @@ extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_asc
         }
         if (rows_in_block == 0) return eagle_fail(ctx, EAGLE_ERR_ARG, "availmemGb too small: zero rows per block");
     }
-    const long np = eagle_pad(n), Lp = eagle_pad(L);
-    const size_t sq = sizeof(double) * (size_t)np * np;
-    const bool use_i8 = ctx->scan_mode == 1 && 64.0 * 512.0 * (double)np < 2147483648.0;
-    const int nslices = ctx->scan_slices;
-    GenoEntry* g = nullptr;
-    rc = get_resident(ctx, f_name_ascii, L, n, max_memory_in_Gbytes, host_threads(), &g,
-                      4 * sq + (use_i8 ? (size_t)eagle_vara_i8_workspace_bytes(np, Lp, nslices) + (size_t)Lp * np + 5 * (size_t)Lp +
-                                             (size_t)eagle_scan_certify_workspace_bytes(np) : 0) +
-                          ((size_t)1 << 30));  // operands, digit + certification workspaces, the re-centred image of the file
-    if (rc < 0) return rc;
-    const bool streamed = (rc == EAGLE_STREAM);
-    const long Lc = streamed ? stream_chunk_rows(np, Lp) : Lp;  // marker rows per pass
-    DevBuf dsel;
-    const size_t wsb = use_i8 ? (size_t)eagle_vara_i8_workspace_bytes(np, Lc, nslices) : 0;
-    const size_t certb = use_i8 ? (size_t)eagle_scan_certify_workspace_bytes(np) : 0;
-    const double t0 = now_s();
-    if ((rc = arena_reserve(ctx, 4 * arena_round(sq) + 2 * arena_round(sizeof(double) * np) + arena_round(wsb) + arena_round(certb) +
-                                     (streamed ? (use_i8 ? 4 : 2) * arena_round((size_t)Lc * np) + 2 * arena_round((size_t)Lc) +
-                                                     2 * arena_round(sizeof(int32_t) * (size_t)Lc) : 0))))
-        return rc;
-    double* Sa = arena_take<double>(ctx, sq);
-    double* Va = arena_take<double>(ctx, sq);
-    double* tmp = arena_take<double>(ctx, sq);
-    double* Wu = arena_take<double>(ctx, sq);
-    double* ah = arena_take<double>(ctx, sizeof(double) * np);
-    double* v = arena_take<double>(ctx, sizeof(double) * np);
-    void* ws = arena_take<char>(ctx, wsb);
-    void* cert = arena_take<char>(ctx, certb);
-    long* cert_totals = (long*)((char*)ctx->d_scratch + 256);  // {re-evaluated, flagged, fell back}, summed over marker blocks
-    ChunkRing ring;
-    int8_t* shifted[2] = {nullptr, nullptr};
-    int8_t* cs[2] = {nullptr, nullptr};
-    int32_t* l1s[2] = {nullptr, nullptr};
-    if (streamed) {
-        if ((rc = ring.init(ctx))) return rc;
-        ring.buf[0] = arena_take<int8_t>(ctx, (size_t)Lc * np);
-        ring.buf[1] = arena_take<int8_t>(ctx, (size_t)Lc * np);
-        for (int b = 0; b < 2 && use_i8; b++) {
-            shifted[b] = arena_take<int8_t>(ctx, (size_t)Lc * np);
-            cs[b] = arena_take<int8_t>(ctx, (size_t)Lc);
-            l1s[b] = arena_take<int32_t>(ctx, sizeof(int32_t) * (size_t)Lc);
-        }
-    }
-    if ((rc = upload_square(ctx, inv_MMt_sqrt, n, np, Sa))) return rc;
-    if ((rc = upload_square(ctx, dim_reduced_vara, n, np, Va))) return rc;
-    if ((rc = upload_vec(ctx, a, n, np, ah))) return rc;
-    if ((rc = ensure_scan_out(ctx, Lp))) return rc;
-    HIPCHK(ctx, hipMemsetAsync(cert_totals, 0, 3 * sizeof(long), ctx->stream));
-    double t1 = 0;
-    if (timing_on()) { (void)hipStreamSynchronize(ctx->stream); t1 = now_s(); }
-    rc = eagle_dev_scan_operands(ctx, Sa, Va, ah, n, np, v, Wu, tmp, ctx->stream);
+    const int nd = ndev_of(ctx);
+    std::vector<long> edge;
+    split_markers(L, nd, edge);
+    Rendezvous rv;
+    rv.n = nd;
+    RcclState* rccl = (RcclState*)ctx->rccl;
+    rc = run_on_devices(ctx, [&](int k, eagle_ctx* c) -> int {
+        return scan_range(c, f_name_ascii, L, n, edge[k], edge[k + 1], sel, inv_MMt_sqrt, dim_reduced_vara, a, max_memory_in_Gbytes, quiet,
+                          a_out, vara_out, k, nd, nd > 1 ? &rv : nullptr, rccl);
+    });
     if (rc) return rc;
-    if (streamed && !quiet) say(ctx, " Mt.ascii streamed through HBM in blocks of %ld markers", Lc);
-    // one pass per marker block: the whole file when it is resident, else chunks read back from the file
-    for (long r0 = 0; r0 < L; r0 += Lc) {
-        const long nr = std::min(Lc, L - r0), nrp = eagle_pad(nr);
-        const int8_t* Mt8 = streamed ? nullptr : g->dev;
-        const long ldm = streamed ? np : g->ld;
-        if (streamed) {
-            int8_t* tile = nullptr;
-            rc = ring.load(ctx, f_name_ascii, r0, nr, 0, n, np, (size_t)nrp * np, max_memory_in_Gbytes, host_threads(), &tile);
-            if (rc) return rc;
-            Mt8 = tile;
-        }
-        if (use_i8) {
-            // re-centred image of the markers (kept with a resident file, rebuilt per chunk when streaming)
-            const int8_t* Ms = nullptr;
-            const int8_t* cv = nullptr;
-            const int32_t* l1 = nullptr;
-            if (streamed) {
-                const int b = (int)(ring.k & 1);
-                rc = eagle_dev_marker_shift(ctx, Mt8, nrp, n, np, ldm, shifted[b], cs[b], l1s[b], ctx->stream);
-                if (rc) return rc;
-                Ms = shifted[b]; cv = cs[b]; l1 = l1s[b];
-            } else {
-                if (!g->dev_s) {
-                    hipError_t e = hipMalloc((void**)&g->dev_s, (size_t)g->rows_pad * g->ld);
-                    if (e == hipSuccess) e = hipMalloc((void**)&g->cshift, (size_t)g->rows_pad);
-                    if (e == hipSuccess) e = hipMalloc((void**)&g->l1, sizeof(int32_t) * (size_t)g->rows_pad);
-                    rc = e == hipSuccess ? eagle_dev_marker_shift(ctx, g->dev, g->rows_pad, n, np, g->ld, g->dev_s, g->cshift, g->l1, ctx->stream)
-                                         : eagle_fail_hip(ctx, e, "re-centred image hipMalloc");
-                    if (rc) {  // never leave a half-made image behind: the next call would scan garbage
-                        if (g->dev_s) (void)hipFree(g->dev_s);
-                        if (g->cshift) (void)hipFree(g->cshift);
-                        if (g->l1) (void)hipFree(g->l1);
-                        g->dev_s = nullptr; g->cshift = nullptr; g->l1 = nullptr;
-                        return rc;
-                    }
-                }
-                Ms = g->dev_s; cv = g->cshift; l1 = g->l1;
-            }
-            // one pass over the genotypes gives a = Mt v and the diagonal term of vara; then the int8 MFMA kernel
-            rc = eagle_dev_vara_i8_prepare(ctx, Mt8, nrp, np, ldm, Wu, nslices, ws, v, ctx->d_a + r0, ctx->stream);
-            if (rc) return rc;
-            rc = eagle_dev_vara_i8_mfma_shifted(ctx, Ms, cv, nrp, np, ldm, nslices, ws, ctx->d_vara + r0, nullptr, ctx->stream);
-            if (rc) return rc;
-            // a-posteriori certificate: markers the digit bounds cannot settle are re-evaluated by the fp64 kernel, so that
-            // which(tsq == max(tsq))[1] on the returned arrays is the marker the fp64 scan selects (find_qtl.R:71-83).  A
-            // streamed file is certified block by block against the block's own maximum (a superset of the global candidates).
-            rc = eagle_dev_scan_certify(ctx, Mt8, nr, nrp, np, ldm, cv, l1, nslices, ws, Wu, ctx->d_a + r0, ctx->d_vara + r0, cert, ctx->stream);
-            if (rc) return rc;
-            rc = eagle_dev_cert_accumulate(ctx, cert, cert_totals, ctx->stream);
-        } else {
-            rc = eagle_dev_gemv_i8(ctx, Mt8, nrp, np, ldm, v, 1.0, ctx->d_a + r0, ctx->stream);
-            if (rc) return rc;
-            rc = eagle_dev_vara_f64(ctx, Mt8, nrp, np, ldm, Wu, ctx->d_vara + r0, ctx->stream);
-        }
-        if (rc) return rc;
-        if (streamed && (rc = ring.computed(ctx))) return rc;
+    for (eagle_ctx* p : ctx->peers) {
+        ctx->cert_reevaluated += p->cert_reevaluated; ctx->cert_flagged += p->cert_flagged; ctx->cert_fell_back |= p->cert_fell_back;
     }
-    if (timing_on()) {
-        (void)hipStreamSynchronize(ctx->stream);
-        fprintf(stderr, "[eaglehip] scan n=%ld L=%ld%s: alloc+upload %.1f ms, device compute %.1f ms\n", n, L,
-                streamed ? " (streamed)" : "", (t1 - t0) * 1e3, (now_s() - t1) * 1e3);
-    }
-    if (rc) return rc;
-    if (!sel.empty()) {  // :79-84: a zeroed marker row gives a = 0 and vara = 0 exactly
-        HIPCHK(ctx, dsel.alloc(sizeof(long) * sel.size()));
-        HIPCHK(ctx, hipMemcpyAsync(dsel.p, sel.data(), sizeof(long) * sel.size(), hipMemcpyHostToDevice, ctx->stream));
-        rc = eagle_dev_zero_rows(ctx, ctx->d_a, ctx->d_vara, L, dsel.as<long>(), (long)sel.size(), 0, ctx->stream);
-        if (rc) return rc;
-    }
-    ctx->scan_L = L;
-    long totals[3] = {0, 0, 0};
-    HIPCHK(ctx, hipMemcpyAsync(a_out, ctx->d_a, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(vara_out, ctx->d_vara, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(totals, cert_totals, sizeof totals, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->cert_reevaluated = totals[0]; ctx->cert_flagged = totals[1]; ctx->cert_fell_back = totals[2] != 0;
     return EAGLE_OK;
 }
 
@@ -914,16 +1211,22 @@ extern "C" int eagle_extract_geno(eagle_ctx* ctx, const char* f_name_ascii, doub
     struct stat st;
     if (stat(f_name_ascii, &st) != 0) return failf(ctx, EAGLE_ERR_OPEN, "ERROR: Could not open  %s", f_name_ascii);
     const long mt = (long)st.st_mtim.tv_sec * 1000000000L + st.st_mtim.tv_nsec;
-    for (auto& g : ctx->cache)
-        if (g.path == f_name_ascii && g.size == st.st_size && g.mtime_ns == mt && g.rows == n && g.cols == L) {
-            DevBuf col;
-            HIPCHK(ctx, col.alloc(sizeof(int) * (size_t)n));
-            int rc = eagle_dev_extract_col(ctx, g.dev, n, g.ld, selected_locus, col.as<int>(), ctx->stream);
-            if (rc) return rc;
-            HIPCHK(ctx, hipMemcpyAsync(column_out, col.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            return EAGLE_OK;
-        }
+    for (int k = 0; k < ndev_of(ctx); k++) {  // whichever device holds the marker's column of M.ascii (a shard is a column window)
+        eagle_ctx* c = dev_ctx(ctx, k);
+        for (auto& g : c->cache)
+            if (g.path == f_name_ascii && g.size == st.st_size && g.mtime_ns == mt && g.row0 == 0 && g.rows == n && selected_locus >= g.col0 &&
+                selected_locus < g.col0 + g.cols) {
+                HIPCHK(ctx, hipSetDevice(c->device));
+                DevBuf col;
+                HIPCHK(ctx, col.alloc(sizeof(int) * (size_t)n));
+                int rc = eagle_dev_extract_col(c, g.dev, n, g.ld, selected_locus - g.col0, col.as<int>(), c->stream);
+                if (rc) return rc;
+                HIPCHK(ctx, hipMemcpyAsync(column_out, col.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(ctx, hipStreamSynchronize(c->stream));
+                (void)hipSetDevice(ctx->device);
+                return EAGLE_OK;
+            }
+    }
     // not resident: one character per line straight from the file (no n x L parse)
     FileInfo fi;
     int rc = open_file(ctx, f_name_ascii, fi);
@@ -957,8 +1260,9 @@ extern "C" int eagle_extract_geno(eagle_ctx* ctx, const char* f_name_ascii, doub
     return rc;
 }
 
-extern "C" int eagle_last_scan_argmax(eagle_ctx* ctx, long* index_out, double* tsqmax_out, long* n_near_ties) {
-    if (!ctx || !ctx->d_a || ctx->scan_L <= 0) return eagle_fail(ctx, EAGLE_ERR_ARG, "no scan result held");
+static int local_scan_argmax(eagle_ctx* ctx, eagle_best* h) {
+    h->tsqmax = 0.0; h->index0 = -1; h->near_ties = 0;
+    if (!ctx->d_a || ctx->scan_L <= 0) return EAGLE_OK;  // an empty shard
     HIPCHK(ctx, hipSetDevice(ctx->device));
     DevBuf scratch, best;
     HIPCHK(ctx, scratch.alloc(sizeof(double) * 3 * 1024));
@@ -966,12 +1270,85 @@ extern "C" int eagle_last_scan_argmax(eagle_ctx* ctx, long* index_out, double* t
     int rc = eagle_dev_tsq_argmax(ctx, ctx->d_a, ctx->d_vara, ctx->scan_L, nullptr, best.as<eagle_best>(), scratch.as<double>(),
                                   ctx->stream);
     if (rc) return rc;
-    eagle_best h;
-    HIPCHK(ctx, hipMemcpyAsync(&h, best.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h, best.p, sizeof *h, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (h->index0 >= 0) h->index0 += ctx->scan_first;  // global marker index
+    return EAGLE_OK;
+}
+extern "C" int eagle_last_scan_argmax(eagle_ctx* ctx, long* index_out, double* tsqmax_out, long* n_near_ties) {
+    if (!ctx || !ctx->d_a || (ctx->scan_L <= 0 && ctx->peers.empty())) return eagle_fail(ctx, EAGLE_ERR_ARG, "no scan result held");
+    // per-device (max tsq, first index) of the shards, merged on the host: the largest tsq, ties -> the smallest global
+    // index = which(tsq == max)[1] (find_qtl.R:76-80)
+    eagle_best h;
+    int rc = local_scan_argmax(ctx, &h);
+    if (rc) return rc;
+    for (eagle_ctx* p : ctx->peers) {
+        eagle_best o;
+        if ((rc = local_scan_argmax(p, &o))) { snprintf(ctx->err, sizeof ctx->err, "%s", p->err); return rc; }
+        if (o.index0 < 0) continue;
+        const double thr = h.index0 >= 0 ? std::max(h.tsqmax, o.tsqmax) * (1.0 - 1e-9) : 0.0;
+        const long near = (h.index0 >= 0 && h.tsqmax >= thr ? h.near_ties : 0) + (o.tsqmax >= thr ? o.near_ties : 0);
+        if (h.index0 < 0 || o.tsqmax > h.tsqmax || (o.tsqmax == h.tsqmax && o.index0 < h.index0)) { h.tsqmax = o.tsqmax; h.index0 = o.index0; }
+        h.near_ties = near;
+    }
+    (void)hipSetDevice(ctx->device);
+    if (h.index0 < 0) h.tsqmax = __builtin_nan("");
     if (index_out) *index_out = h.index0 + 1;  // R is 1-based; 0 = every tsq was NaN
     if (tsqmax_out) *tsqmax_out = h.tsqmax;
     if (n_near_ties) *n_near_ties = h.near_ties;
+    return EAGLE_OK;
+}
+
+// ar[m0..m1) = varG * Mt[m0..m1) (P y) on ctx's device (calculate_reduced_a_rcpp.cpp:82-84)
+static int reduced_a_range(eagle_ctx* ctx, const char* f_name_ascii, long n, long L, long m0, long m1, const std::vector<long>& sel, double varG,
+                           const double* P, const double* y, double max_memory_in_Gbytes, double* ar_out) {
+    const long Lr = m1 - m0;
+    if (Lr <= 0) return EAGLE_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const long np = eagle_pad(n), Lp = eagle_pad(Lr);
+    GenoEntry* g = nullptr;
+    int rc = get_resident(ctx, f_name_ascii, m0, Lr, 0, n, max_memory_in_Gbytes, host_threads(), &g,
+                          sizeof(double) * (size_t)np * np + ((size_t)1 << 30));
+    if (rc < 0) return rc;
+    const bool streamed = (rc == EAGLE_STREAM);
+    const long Lc = streamed ? stream_chunk_rows(np, Lp) : Lp;
+    DevBuf Pa, yv, py, out, dsel, chunk;
+    HIPCHK(ctx, Pa.alloc(sizeof(double) * (size_t)np * np));
+    HIPCHK(ctx, yv.alloc(sizeof(double) * np)); HIPCHK(ctx, py.alloc(sizeof(double) * np));
+    HIPCHK(ctx, out.alloc(sizeof(double) * Lp));
+    ChunkRing ring;
+    if (streamed) {
+        HIPCHK(ctx, chunk.alloc((size_t)2 * Lc * np));
+        if ((rc = ring.init(ctx))) return rc;
+        ring.buf[0] = chunk.as<int8_t>();
+        ring.buf[1] = chunk.as<int8_t>() + (size_t)Lc * np;
+    }
+    if ((rc = upload_square(ctx, P, n, np, Pa.as<double>()))) return rc;
+    if ((rc = upload_vec(ctx, y, n, np, yv.as<double>()))) return rc;
+    rc = eagle_dev_colgemv(ctx, Pa.as<double>(), n, np, yv.as<double>(), py.as<double>(), ctx->stream);  // :82
+    if (rc) return rc;
+    for (long r0 = 0; r0 < Lr; r0 += Lc) {  // :83-84, one pass per marker block (the whole shard when resident)
+        const long nr = std::min(Lc, Lr - r0), nrp = eagle_pad(nr);
+        int8_t* tile = nullptr;
+        if (streamed) {
+            rc = ring.load(ctx, f_name_ascii, m0 + r0, nr, 0, n, np, (size_t)nrp * np, max_memory_in_Gbytes, host_threads(), &tile);
+            if (rc) return rc;
+        }
+        rc = eagle_dev_gemv_i8(ctx, streamed ? tile : g->dev, nrp, np, streamed ? np : g->ld, py.as<double>(), varG,
+                               out.as<double>() + r0, ctx->stream);
+        if (rc) return rc;
+        if (streamed && (rc = ring.computed(ctx))) return rc;
+    }
+    std::vector<long> in_range;
+    for (long r : sel) if (r >= m0 && r < m1) in_range.push_back(r - m0);
+    if (!in_range.empty()) {  // :74-78
+        HIPCHK(ctx, dsel.alloc(sizeof(long) * in_range.size()));
+        HIPCHK(ctx, hipMemcpyAsync(dsel.p, in_range.data(), sizeof(long) * in_range.size(), hipMemcpyHostToDevice, ctx->stream));
+        rc = eagle_dev_zero_rows(ctx, out.as<double>(), nullptr, Lr, dsel.as<long>(), (long)in_range.size(), 0, ctx->stream);
+        if (rc) return rc;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ar_out + m0, out.p, sizeof(double) * (size_t)Lr, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return EAGLE_OK;
 }
 
@@ -998,47 +1375,10 @@ extern "C" int eagle_calculate_reduced_a(eagle_ctx* ctx, const char* f_name_asci
         eagle_fail(ctx, EAGLE_SOFT_SENTINEL, "availmemGb: cannot even read in a single row of data into memory");
         return EAGLE_SOFT_SENTINEL;
     }
-    const long np = eagle_pad(n), Lp = eagle_pad(L);
-    GenoEntry* g = nullptr;
-    rc = get_resident(ctx, f_name_ascii, L, n, max_memory_in_Gbytes, host_threads(), &g,
-                      sizeof(double) * (size_t)np * np + ((size_t)1 << 30));
-    if (rc < 0) return rc;
-    const bool streamed = (rc == EAGLE_STREAM);
-    const long Lc = streamed ? stream_chunk_rows(np, Lp) : Lp;
-    DevBuf Pa, yv, py, out, dsel, chunk;
-    HIPCHK(ctx, Pa.alloc(sizeof(double) * (size_t)np * np));
-    HIPCHK(ctx, yv.alloc(sizeof(double) * np)); HIPCHK(ctx, py.alloc(sizeof(double) * np));
-    HIPCHK(ctx, out.alloc(sizeof(double) * Lp));
-    ChunkRing ring;
-    if (streamed) {
-        HIPCHK(ctx, chunk.alloc((size_t)2 * Lc * np));
-        if ((rc = ring.init(ctx))) return rc;
-        ring.buf[0] = chunk.as<int8_t>();
-        ring.buf[1] = chunk.as<int8_t>() + (size_t)Lc * np;
-    }
-    if ((rc = upload_square(ctx, P, n, np, Pa.as<double>()))) return rc;
-    if ((rc = upload_vec(ctx, y, n, np, yv.as<double>()))) return rc;
-    rc = eagle_dev_colgemv(ctx, Pa.as<double>(), n, np, yv.as<double>(), py.as<double>(), ctx->stream);  // :82
-    if (rc) return rc;
-    for (long r0 = 0; r0 < L; r0 += Lc) {  // :83-84, one pass per marker block (the whole file when resident)
-        const long nr = std::min(Lc, L - r0), nrp = eagle_pad(nr);
-        int8_t* tile = nullptr;
-        if (streamed) {
-            rc = ring.load(ctx, f_name_ascii, r0, nr, 0, n, np, (size_t)nrp * np, max_memory_in_Gbytes, host_threads(), &tile);
-            if (rc) return rc;
-        }
-        rc = eagle_dev_gemv_i8(ctx, streamed ? tile : g->dev, nrp, np, streamed ? np : g->ld, py.as<double>(), varG,
-                               out.as<double>() + r0, ctx->stream);
-        if (rc) return rc;
-        if (streamed && (rc = ring.computed(ctx))) return rc;
-    }
-    if (!sel.empty()) {  // :74-78
-        HIPCHK(ctx, dsel.alloc(sizeof(long) * sel.size()));
-        HIPCHK(ctx, hipMemcpyAsync(dsel.p, sel.data(), sizeof(long) * sel.size(), hipMemcpyHostToDevice, ctx->stream));
-        rc = eagle_dev_zero_rows(ctx, out.as<double>(), nullptr, L, dsel.as<long>(), (long)sel.size(), 0, ctx->stream);
-        if (rc) return rc;
-    }
-    HIPCHK(ctx, hipMemcpyAsync(ar_out, out.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return EAGLE_OK;
+    const int nd = ndev_of(ctx);
+    std::vector<long> edge;
+    split_markers(L, nd, edge);
+    return run_on_devices(ctx, [&](int k, eagle_ctx* c) -> int {
+        return reduced_a_range(c, f_name_ascii, n, L, edge[k], edge[k + 1], sel, varG, P, y, max_memory_in_Gbytes, ar_out);
+    });
 }

@@ -9,6 +9,8 @@
 #include <stdlib.h>
 #include <sys/types.h>
 
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -20,7 +22,8 @@ struct GenoEntry {
     std::string path;
     off_t size = 0;
     long mtime_ns = 0;
-    long rows = 0, cols = 0;          // logical tile held: all `rows` lines, first `cols` characters
+    long rows = 0, cols = 0;          // logical tile held: `rows` lines from line row0, `cols` characters from character col0
+    long row0 = 0, col0 = 0;          // (0, 0) and the whole file for a single-device ctx; a marker shard in a multi-device one
     long rows_pad = 0, ld = 0;
     int8_t* dev = nullptr;
     int8_t* dev_s = nullptr;    // re-centred image m - c_i (eagle_dev_marker_shift), made on the first digit-slice scan of the file
@@ -28,8 +31,42 @@ struct GenoEntry {
     int32_t* l1 = nullptr;      // sum_j |m_ij - c_i| per row (error bound of the digit-slice scan)
 };
 
+// Meeting point of the per-device worker threads of one multi-device call.  arrive(ok, v) blocks until every device has
+// arrived, returns false if any of them reported a failure (then nobody enters the collective that follows), and leaves the
+// largest v of this round in `vmax`.  Every worker calls it the same number of times, failed or not.
+struct Rendezvous {
+    std::mutex mu;
+    std::condition_variable cv;
+    int n = 1, waiting = 0;
+    long gen = 0;
+    bool failed = false;
+    double acc = -1.0 / 0.0, vmax = -1.0 / 0.0;
+    bool arrive(bool ok, double v = -1.0 / 0.0) {
+        std::unique_lock<std::mutex> lk(mu);
+        if (!ok) failed = true;
+        if (v == v && v > acc) acc = v;
+        const long g = gen;
+        if (++waiting == n) {
+            waiting = 0; vmax = acc; acc = -1.0 / 0.0; gen++;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return gen != g; });
+        }
+        return !failed;
+    }
+};
+
 struct eagle_ctx {
     int device = -1;
+    // multi-device: the ctx eagle_open_devices returns is the LEAD (first device); it owns one sub-context per further device.
+    std::vector<eagle_ctx*> peers;
+    eagle_ctx* lead = nullptr;           // set in sub-contexts
+    void* blas_handle = nullptr;         // rocblas_handle of the opt-in device model algebra (eagle_linalg.cpp)
+    void* rccl = nullptr;                // RcclState* of the lead (communicators, one per device), or NULL: host-staged sums
+    long scan_first = 0;                 // global index of the first marker of this device's last scan
+    int32_t* d_c32 = nullptr; size_t c32_cap = 0;      // partial MM^T accumulator (grow-only, kept between calls)
+    int32_t* d_pack = nullptr; size_t pack_cap = 0;    // packed upper tiles of it (multi-device sum)
+    int32_t* d_pack2 = nullptr; size_t pack2_cap = 0;  // lead: landing buffer of a peer's packed tiles (host-staged sum)
     hipStream_t stream = nullptr;
     hipStream_t load_stream = nullptr;  // tile loads of the streamed (out-of-core) paths run here, under the kernels of `stream`
     char err[1024] = {0};

@@ -822,9 +822,13 @@ __global__ __launch_bounds__(256) void k_cert_lb(const double* __restrict__ a, c
 __global__ __launch_bounds__(256) void k_cert_select(const double* __restrict__ a, const double* __restrict__ vara, long L,
                                                      const int32_t* __restrict__ l1, const int8_t* __restrict__ cshift,
                                                      const double* __restrict__ vdiag, const double* __restrict__ mrho,
-                                                     const VaraHdr* __restrict__ hdr, CertHdr* __restrict__ ch, long* __restrict__ idx) {
+                                                     const VaraHdr* __restrict__ hdr, CertHdr* __restrict__ ch, long* __restrict__ idx,
+                                                     double lb_override) {
     const CertCtx cc = cert_ctx(hdr);
-    const double thr = __longlong_as_double((long long)ch->lb_bits) * (1.0 - 1e-9);
+    // lb_override (not NaN): the lower bound of the maximum over ALL shards of a multi-device scan (exchanged on the host),
+    // so that every device selects exactly the candidates a single-device scan of the whole file selects
+    const double lb = lb_override == lb_override ? lb_override : __longlong_as_double((long long)ch->lb_bits);
+    const double thr = lb * (1.0 - 1e-9);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L; i += (long)gridDim.x * 256) {
         const double x = a[i], v = vara[i];
         if (!(isfinite(x) && isfinite(v))) continue;  // NaN / Inf operands: the fp64 kernel gives the same
@@ -876,10 +880,10 @@ static size_t cert_part_off(long n_pad) { return (cert_rows_off() + (size_t)CERT
 extern "C" int64_t eagle_scan_certify_workspace_bytes(long n_pad) {
     return (int64_t)(cert_part_off(n_pad) + (size_t)(CERT_CAP / 128) * (size_t)(n_pad / 128) * 256 * sizeof(double));
 }
-extern "C" int eagle_dev_scan_certify(eagle_ctx* ctx, const int8_t* Mt8, long L, long L_pad, long n_pad, long ld, const int8_t* cshift,
-                                      const int32_t* l1norm, int nslices, void* vara_ws, const double* Wu, const double* a, double* vara,
-                                      void* cert_ws, void* stream) {
-    if (n_pad % T8 || L_pad % T8 || ld % 16 || n_pad > ld || L < 0 || L > L_pad || !cshift || !l1norm || !cert_ws)
+// Phase 1: lower bound of the block's maximum tsq into the head of cert_ws (eagle_cert_info.lower_bound).
+extern "C" int eagle_dev_scan_certify_lb(eagle_ctx* ctx, long L, long L_pad, long n_pad, const int8_t* cshift, const int32_t* l1norm,
+                                         int nslices, void* vara_ws, const double* a, const double* vara, void* cert_ws, void* stream) {
+    if (n_pad % T8 || L_pad % T8 || L < 0 || L > L_pad || !cshift || !l1norm || !cert_ws)
         return eagle_fail(ctx, EAGLE_ERR_ARG, "scan_certify: layout contract violated");
     hipStream_t s = (hipStream_t)stream;
     CertHdr* ch = (CertHdr*)cert_ws;
@@ -890,20 +894,47 @@ extern "C" int eagle_dev_scan_certify(eagle_ctx* ctx, const int8_t* Mt8, long L,
     const VaraHdr* hdr = (const VaraHdr*)vara_ws;
     const double* vdiag = (const double*)((const char*)vara_ws + ws_vd_off(n_pad, L_pad, smax));
     const double* mrho = (const double*)((const char*)vara_ws + ws_mr_off(n_pad, L_pad, smax));
+    unsigned blocks = (unsigned)((L + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_cert_lb, dim3(blocks), dim3(256), 0, s, a, vara, L, l1norm, cshift, vdiag, mrho, hdr, ch);
+    e = hipGetLastError();
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "k_cert_lb");
+    return EAGLE_OK;
+}
+// Phase 2: select (against the block's own lower bound, or lb_override if it is not NaN), gather, re-evaluate, write back.
+extern "C" int eagle_dev_scan_certify_apply(eagle_ctx* ctx, const int8_t* Mt8, long L, long L_pad, long n_pad, long ld, const int8_t* cshift,
+                                            const int32_t* l1norm, int nslices, void* vara_ws, const double* Wu, const double* a, double* vara,
+                                            void* cert_ws, double lb_override, void* stream) {
+    if (n_pad % T8 || L_pad % T8 || ld % 16 || n_pad > ld || L < 0 || L > L_pad || !cshift || !l1norm || !cert_ws)
+        return eagle_fail(ctx, EAGLE_ERR_ARG, "scan_certify: layout contract violated");
+    if (L == 0) return EAGLE_OK;
+    hipStream_t s = (hipStream_t)stream;
+    CertHdr* ch = (CertHdr*)cert_ws;
+    const int smax = ws_smax(nslices);
+    const VaraHdr* hdr = (const VaraHdr*)vara_ws;
+    const double* vdiag = (const double*)((const char*)vara_ws + ws_vd_off(n_pad, L_pad, smax));
+    const double* mrho = (const double*)((const char*)vara_ws + ws_mr_off(n_pad, L_pad, smax));
     long* idx = (long*)((char*)cert_ws + cert_idx_off());
     int8_t* rows = (int8_t*)cert_ws + cert_rows_off();
     double* partial = (double*)((char*)cert_ws + cert_part_off(n_pad));
     unsigned blocks = (unsigned)((L + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_cert_lb, dim3(blocks), dim3(256), 0, s, a, vara, L, l1norm, cshift, vdiag, mrho, hdr, ch);
-    hipLaunchKernelGGL(k_cert_select, dim3(blocks), dim3(256), 0, s, a, vara, L, l1norm, cshift, vdiag, mrho, hdr, ch, idx);
+    hipLaunchKernelGGL(k_cert_select, dim3(blocks), dim3(256), 0, s, a, vara, L, l1norm, cshift, vdiag, mrho, hdr, ch, idx, lb_override);
     hipLaunchKernelGGL(k_cert_gather, dim3(CERT_CAP), dim3(256), 0, s, Mt8, ld, n_pad, ch, idx, rows);
-    e = hipGetLastError();
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "scan_certify");
     int rc = eagle_dev_vara_f64_split(ctx, rows, CERT_CAP, n_pad, n_pad, Wu, &ch->count, idx, partial, vara, stream);
     if (rc) return rc;
     // more than CERT_CAP markers qualified: the whole block in fp64 (dropped on the device otherwise)
     return eagle_dev_vara_f64_gated(ctx, Mt8, L_pad, n_pad, ld, Wu, vara, &ch->overflow, stream);
+}
+extern "C" int eagle_dev_scan_certify(eagle_ctx* ctx, const int8_t* Mt8, long L, long L_pad, long n_pad, long ld, const int8_t* cshift,
+                                      const int32_t* l1norm, int nslices, void* vara_ws, const double* Wu, const double* a, double* vara,
+                                      void* cert_ws, void* stream) {
+    int rc = eagle_dev_scan_certify_lb(ctx, L, L_pad, n_pad, cshift, l1norm, nslices, vara_ws, a, vara, cert_ws, stream);
+    if (rc) return rc;
+    return eagle_dev_scan_certify_apply(ctx, Mt8, L, L_pad, n_pad, ld, cshift, l1norm, nslices, vara_ws, Wu, a, vara, cert_ws,
+                                        __builtin_nan(""), stream);
 }
 
 __global__ void k_vara_i8_bound(const VaraHdr* __restrict__ hdr, double* __restrict__ out, int* __restrict__ slices_out) {
@@ -995,7 +1026,10 @@ extern "C" int eagle_dev_vara_i8_mfma_shifted(eagle_ctx* ctx, const int8_t* Mt8s
         if (ea != hipSuccess) return eagle_fail_hip(ctx, ea, "hipFuncSetAttribute(k_vara_i8)");
         ctx->attr_vara_i8 = true;
     }
-    if (ctx->tune == 9 && n_pad < 32768) {  // the 384 x 256 tile form (A/B switch while it is being measured)
+    // The 384 x 256 tile form is the default (C2: 23.05 -> 21.91 ms, C3 shape: 45.2 -> 43.1 ms per 262144 markers, bit-identical
+    // q; profiles/r02_ab_vara_tile.txt); the 256 x 256 form serves n_pad >= 32768 (its int32 butterfly spans 64 columns per wave
+    // instead of 128) and stays reachable for A/B runs with tune = 8.
+    if (ctx->tune != 8 && n_pad < 32768) {
         if (!ctx->attr_vara_i8w) {
             hipError_t ea = hipFuncSetAttribute((const void*)k_vara_i8w, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TW_ABYTES + TILE_BYTES));
             if (ea != hipSuccess) return eagle_fail_hip(ctx, ea, "hipFuncSetAttribute(k_vara_i8w)");

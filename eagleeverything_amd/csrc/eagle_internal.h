@@ -26,7 +26,16 @@ int eagle_dev_vara_f64_gated(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long
                              const int* run_if, void* stream);
 int eagle_dev_vara_f64_split(eagle_ctx* ctx, const int8_t* rows8, long rows_cap, long n_pad, long ld, const double* Wu,
                              const int* count_dev, const long* dst_dev, double* partial, double* out, void* stream);
+long eagle_upper_tiles_count(long n_pad);  // int32 elements of the packed upper 256-tiles of an n_pad x n_pad matrix
+int eagle_dev_tiles_pack(eagle_ctx* ctx, int32_t* C32, long n_pad, int32_t* packed, int unpack, void* stream);
+int eagle_dev_add_i32(eagle_ctx* ctx, int32_t* dst, const int32_t* src, long count, void* stream);
 int eagle_dev_cert_accumulate(eagle_ctx* ctx, const void* cert_ws, long* totals_dev, void* stream);
+int eagle_dev_symmetrize(eagle_ctx* ctx, double* A, long n, long ld, void* stream);
+int eagle_dev_symmetrize_mean(eagle_ctx* ctx, double* A, long n, long ld, void* stream);
+int eagle_dev_scale_rows_pow(eagle_ctx* ctx, double* R, long n, long ld, const double* w, double p, void* stream);
+int eagle_dev_transpose_f64(eagle_ctx* ctx, const double* in, double* out, long N, void* stream);
+int eagle_dev_dot_matrices(eagle_ctx* ctx, const double* A, long lda, const double* B, long ldb, long n, double* out, void* stream);
+void eagle_linalg_release(eagle_ctx* ctx);
 int eagle_dev_extract_col(eagle_ctx* ctx, const int8_t* M8, long n, long ld, long col, int* out, void* stream);
 #ifdef __cplusplus
 }

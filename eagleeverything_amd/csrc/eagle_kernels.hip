@@ -623,6 +623,46 @@ extern "C" int eagle_dev_mmt_normalise(eagle_ctx* ctx, double* MMt, long n, long
 }
 
 // ------------------------------------------------------------------------------------------------
+// Partial MM^T of several devices -> one sum.  Only the 256 x 256 tiles on or above the diagonal of C32 are live, so only
+// they travel: packed[t] (t = ti*nt - ti(ti-1)/2 + tj - ti) is the tile (ti, tj) as 65536 contiguous int32.
+//   k_tiles_pack   : C32 upper tiles -> packed          k_tiles_unpack : packed -> C32 upper tiles
+//   k_add_i32      : dst += src (exact integer sum; the host-staged stand-in for the RCCL reduce)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tiles_pack(int32_t* __restrict__ C, long np, int32_t* __restrict__ packed, int nt, int unpack) {
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj < ti) return;
+    const long t = (long)ti * nt - (long)ti * (ti - 1) / 2 + (tj - ti);
+    int32_t* tile = packed + t * 65536;
+    for (int e = threadIdx.x * 4; e < 65536; e += 1024) {
+        const int r = e >> 8, c = e & 255;
+        i32x4* g = (i32x4*)(C + ((long)ti * 256 + r) * np + (long)tj * 256 + c);
+        i32x4* p = (i32x4*)(tile + e);
+        if (unpack) *g = *p; else *p = *g;
+    }
+}
+__global__ __launch_bounds__(256) void k_add_i32(int32_t* __restrict__ dst, const int32_t* __restrict__ src, long count4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count4; i += (long)gridDim.x * 256) {
+        i32x4 a = ((const i32x4*)dst)[i], b = ((const i32x4*)src)[i];
+        ((i32x4*)dst)[i] = a + b;
+    }
+}
+extern "C" long eagle_upper_tiles_count(long n_pad) { const long nt = n_pad / 256; return nt * (nt + 1) / 2 * 65536; }
+extern "C" int eagle_dev_tiles_pack(eagle_ctx* ctx, int32_t* C32, long n_pad, int32_t* packed, int unpack, void* stream) {
+    if (n_pad % 256 || n_pad <= 0 || n_pad / 256 > 65535) return eagle_fail(ctx, EAGLE_ERR_ARG, "tiles_pack: bad padding");
+    const int nt = (int)(n_pad / 256);
+    hipLaunchKernelGGL(k_tiles_pack, dim3(nt, nt), dim3(256), 0, (hipStream_t)stream, C32, n_pad, packed, nt, unpack);
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+extern "C" int eagle_dev_add_i32(eagle_ctx* ctx, int32_t* dst, const int32_t* src, long count, void* stream) {
+    if (count % 4) return eagle_fail(ctx, EAGLE_ERR_ARG, "add_i32: count must be a multiple of 4");
+    if (count == 0) return EAGLE_OK;
+    hipLaunchKernelGGL(k_add_i32, dim3(2048), dim3(256), 0, (hipStream_t)stream, dst, src, count / 4);
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // C = A * B over a LIST of 128 x 128 output tiles, with the last partial wave of workgroups split along K.
 // 512 workgroups are resident (2 per CU); 1600 tiles (np = 5120) are 3.125 waves, so a plain grid leaves 7/8 of the chip
 // idle through a fourth wave.  The first floor(T/512)*512 tiles run whole; each remaining tile is cut into `split` K
@@ -1239,6 +1279,98 @@ extern "C" int eagle_dev_unpack2b(eagle_ctx* ctx, const uint8_t* raw, long rows,
         hipLaunchKernelGGL(k_unpack2b, grid, dim3(256), 0, (hipStream_t)stream, raw + r0 * stride, nr, cols, stride, shift, out + r0 * ld_out,
                            ld_out, bad_dev);
     }
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Small fp64 helpers of the device model algebra (eagle_linalg.cpp).  Matrices are n x n inside a buffer of
+// leading dimension ld; "row-major" below is just the memory order (a symmetric matrix is layout-free).
+// ------------------------------------------------------------------------------------------------
+// mode 0: A[c][r] = A[r][c] for c < r (mirror the triangle potri wrote); mode 1: both = their mean
+__global__ __launch_bounds__(256) void k_symmetrize(double* __restrict__ A, long n, long ld, int mode) {
+    const long bj = (long)blockIdx.y * 32, bk = (long)blockIdx.x * 32;
+    if (bk > bj) return;  // tiles with row block >= column block
+    __shared__ double t1[32][33], t2[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const long i = bj + r, j = bk + tx;
+        t1[r][tx] = (i < n && j < n) ? A[i * ld + j] : 0.0;          // lower-side tile (row block bj, column block bk)
+        const long i2 = bk + r, j2 = bj + tx;
+        t2[r][tx] = (i2 < n && j2 < n) ? A[i2 * ld + j2] : 0.0;      // its mirror tile
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const long i = bj + r, j = bk + tx;                            // element (i, j) of the lower-side tile, mirror (j, i)
+        if (i >= n || j >= n || j >= i) continue;
+        const double lo = t1[r][tx], up = t2[tx][r];
+        const double v = mode ? 0.5 * (lo + up) : lo;
+        A[i * ld + j] = v;
+        A[j * ld + i] = v;
+    }
+}
+__global__ __launch_bounds__(256) void k_scale_rows_pow(double* __restrict__ R, long n, long ld, const double* __restrict__ w, double p) {
+    const long i = blockIdx.y, j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || j >= n) return;
+    R[i * ld + j] *= pow(w[i], p);
+}
+__global__ __launch_bounds__(256) void k_transpose_f64(const double* __restrict__ in, double* __restrict__ out, long N) {
+    __shared__ double t[32][33];
+    const long bi = (long)blockIdx.y * 32, bj = (long)blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) t[r][tx] = in[(bi + r) * N + bj + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) out[(bj + r) * N + bi + tx] = t[tx][r];
+}
+// part[b] = sum over the rows b, b + gridDim.x, ... of sum_j A[i][j] B[i][j]; k_dot_final adds the parts in order
+__global__ __launch_bounds__(256) void k_dot_rows(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb, long n,
+                                                  double* __restrict__ part) {
+    double s = 0.0;
+    for (long i = blockIdx.x; i < n; i += gridDim.x)
+        for (long j = threadIdx.x; j < n; j += 256) s += A[i * lda + j] * B[i * ldb + j];
+    __shared__ double red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ void k_dot_final(const double* __restrict__ part, int nparts, double* __restrict__ out) {
+    double s = 0.0;
+    for (int b = 0; b < nparts; b++) s += part[b];
+    *out = s;
+}
+extern "C" int eagle_dev_symmetrize(eagle_ctx* ctx, double* A, long n, long ld, void* stream) {
+    dim3 grid((unsigned)((n + 31) / 32), (unsigned)((n + 31) / 32));
+    hipLaunchKernelGGL(k_symmetrize, grid, dim3(256), 0, (hipStream_t)stream, A, n, ld, 0);
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+extern "C" int eagle_dev_symmetrize_mean(eagle_ctx* ctx, double* A, long n, long ld, void* stream) {
+    dim3 grid((unsigned)((n + 31) / 32), (unsigned)((n + 31) / 32));
+    hipLaunchKernelGGL(k_symmetrize, grid, dim3(256), 0, (hipStream_t)stream, A, n, ld, 1);
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+extern "C" int eagle_dev_scale_rows_pow(eagle_ctx* ctx, double* R, long n, long ld, const double* w, double p, void* stream) {
+    if (n > 65535) return eagle_fail(ctx, EAGLE_ERR_ARG, "scale_rows: n too large");
+    hipLaunchKernelGGL(k_scale_rows_pow, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, R, n, ld, w, p);
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+extern "C" int eagle_dev_transpose_f64(eagle_ctx* ctx, const double* in, double* out, long N, void* stream) {
+    if (N % 32 || N / 32 > 65535) return eagle_fail(ctx, EAGLE_ERR_ARG, "transpose_f64: bad size");
+    hipLaunchKernelGGL(k_transpose_f64, dim3((unsigned)(N / 32), (unsigned)(N / 32)), dim3(256), 0, (hipStream_t)stream, in, out, N);
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+extern "C" int eagle_dev_dot_matrices(eagle_ctx* ctx, const double* A, long lda, const double* B, long ldb, long n, double* out, void* stream) {
+    double* part = (double*)((char*)eagle_ctx_scratch(ctx) + 1024);  // 256 partial sums in the ctx scratch page
+    hipLaunchKernelGGL(k_dot_rows, dim3(256), dim3(256), 0, (hipStream_t)stream, A, lda, B, ldb, n, part);
+    hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(1), 0, (hipStream_t)stream, part, 256, out);
     LAUNCH_CHECK(ctx);
     return EAGLE_OK;
 }

@@ -4,8 +4,8 @@ north_star keeps calculateH / calculateP / the eigendecomposition of MM^T on hos
 package these are base-R calls.  This numpy restatement exists so that the scan can be driven with
 realistic operands (S = MMt^-1/2, V = Var(a_hat), a_hat) on a box without R.  It is *not* part of
 the GPU hot path and is not a fallback for it.  Host LAPACK is the default; set_algebra("device") moves the
-O(n^3) primitives (eigh, chol2inv, inv, n x n products) to the GPU through torch.linalg -- SURVEY 8 f-4, the Amdahl
-term of a full AM() run once the scan takes 30 ms -- without changing a formula.
+O(n^3) primitives (eigh, chol2inv, inv, n x n products) to the GPU through the C ABI (eagle_sym_eig & co., include/eagle_hip.h
+section 1c) -- SURVEY 8 f-4, the Amdahl term of a full AM() run once the scan takes 30 ms -- without changing a formula.
 
 Reference lines (E/ = MyPackage/Eagle/):
   calculateH ........................ E/R/calculateH.R:36
@@ -42,31 +42,28 @@ class _HostLA:
 
 
 class _DeviceLA:
-    """the same primitives on the GPU through torch.linalg (rocSOLVER syevd / potrf / getrf, rocBLAS dgemm).
-    Library calls, not kernels of this repository; opt-in (set_algebra("device")).  numpy in, numpy out."""
+    """the same primitives on the GPU through the C ABI of libeaglehip.so (include/eagle_hip.h section 1c:
+    eagle_sym_eig / eagle_chol2inv / eagle_inverse on rocSOLVER, eagle_matmul on the library's own fp64 MFMA GEMM) -- what an
+    R caller would bind too.  Opt-in (set_algebra("device")); no torch in this path.  numpy in, numpy out."""
     name = "device"
 
     def __init__(self, device=0):
-        import torch
-        self.torch = torch
-        self.dev = torch.device("cuda", device)
-
-    def _t(self, A):
-        return self.torch.as_tensor(np.ascontiguousarray(A), dtype=self.torch.float64, device=self.dev)
+        from . import rcpp_api
+        self.api = rcpp_api
+        self.device = device
 
     def eigh(self, A):
-        w, U = self.torch.linalg.eigh(self._t(A))
-        return w.cpu().numpy(), U.cpu().numpy()
+        w, U = self.api.sym_eig(A, device=self.device)   # R's order (decreasing); numpy's convention is ascending
+        return w[::-1].copy(), np.ascontiguousarray(U[:, ::-1])
 
     def chol2inv(self, A):
-        c = self.torch.linalg.cholesky(self._t(A))
-        return self.torch.cholesky_inverse(c).cpu().numpy()
+        return np.ascontiguousarray(self.api.chol2inv(A, device=self.device))
 
     def inv(self, A):
-        return self.torch.linalg.inv(self._t(A)).cpu().numpy()
+        return np.ascontiguousarray(self.api.inverse(A, device=self.device))
 
     def mm(self, A, B):
-        return (self._t(A) @ self._t(B)).cpu().numpy()
+        return np.ascontiguousarray(self.api.matmul(A, B, device=self.device))
 
 
 _la = _HostLA()
@@ -104,6 +101,15 @@ def calculateP(H, X):
 
 def calculateMMt_sqrt_and_sqrtinv(MMt, checkres=True):
     """eigen(MMt, symmetric=TRUE); sqrt = U diag(sqrt(l)) U^T ; invsqrt = chol2inv(chol(sqrt))."""
+    if _la.name == "device":  # the whole function in one C-ABI call, the matrices staying in HBM between its steps
+        r = _la.api.mmt_sqrt_and_sqrtinv(MMt, device=_la.device)
+        if r is None:
+            raise ValueError("M %*% t(M) is not positive definite")  # :15-23
+        sq, inv, tr = r
+        if checkres and int(np.trunc(tr)) != MMt.shape[0]:  # :35-46
+            import warnings
+            warnings.warn("sqrt(MMt) %*% invsqrt(MMt) trace = %r, expected %d" % (tr, MMt.shape[0]))
+        return {"sqrt_MMt": np.ascontiguousarray(sq), "inverse_sqrt_MMt": np.ascontiguousarray(inv)}
     evals, U = _la.eigh(MMt)
     if evals.min() <= 0:
         raise ValueError("M %*% t(M) is not positive definite")  # :15-23

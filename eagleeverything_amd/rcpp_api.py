@@ -27,10 +27,16 @@ _callbacks = {}
 
 
 def context(device=0):
-    """The per-device eagle_ctx (opened on first use; fails loudly without a gfx950 device)."""
+    """The eagle_ctx of `device` (opened on first use; fails loudly without a gfx950 device).  `device` may be a tuple of
+    device numbers: ONE context that shards every call's markers over those GPUs (eagle_open_devices; the reference's unused
+    AM(..., ngpu) hook, E/R/AM.R:185-196) -- pass the same tuple as `device=` to the functions below."""
     if device not in _ctx:
         L = _lib.load()
-        h = L.eagle_open(int(device))
+        if isinstance(device, tuple):
+            arr = (C.c_int * len(device))(*[int(d) for d in device])
+            h = L.eagle_open_devices(arr, len(device))
+        else:
+            h = L.eagle_open(int(device))
         if not h:
             raise EagleError(-6, L.eagle_open_error().decode())
         _ctx[device] = h
@@ -228,6 +234,70 @@ def createMt_ASCII_rcpp(f_name, f_name_ascii, type, max_memory_in_Gbytes, dims, 
     _set_message(ctx, message)
     _check(ctx, L.eagle_create_Mt_ascii(ctx, os.fsencode(f_name), os.fsencode(f_name_ascii), str(type).encode(),
                                         float(max_memory_in_Gbytes), _dims(dims), int(bool(quiet))))
+
+
+# ---- the dense model algebra on the device, through the C ABI (opt-in; include/eagle_hip.h section 1c) ----
+def sym_eig(A, only_values=False, device=0):
+    """eigen(A, symmetric=TRUE): (values in decreasing order, vectors in columns) like R."""
+    L = _lib.load()
+    ctx = context(device)
+    A = _f64F(A)
+    n = A.shape[0]
+    w = np.zeros(n)
+    U = None if only_values else np.zeros((n, n), order="F")
+    _check(ctx, L.eagle_sym_eig(ctx, _dp(A), n, _dp(w), None if only_values else _dp(U)))
+    return w, U
+
+
+def chol2inv(A, device=0):
+    """chol2inv(chol(A)); raises EagleError(1, R's chol() message) when A is not positive definite."""
+    L = _lib.load()
+    ctx = context(device)
+    A = _f64F(A)
+    n = A.shape[0]
+    out = np.zeros((n, n), order="F")
+    _check(ctx, L.eagle_chol2inv(ctx, _dp(A), n, _dp(out)))
+    return out
+
+
+def inverse(A, device=0):
+    """solve(A)."""
+    L = _lib.load()
+    ctx = context(device)
+    A = _f64F(A)
+    n = A.shape[0]
+    out = np.zeros((n, n), order="F")
+    _check(ctx, L.eagle_inverse(ctx, _dp(A), n, _dp(out)))
+    return out
+
+
+def matmul(A, B, device=0):
+    """A %*% B on the library's fp64 MFMA GEMM."""
+    L = _lib.load()
+    ctx = context(device)
+    A, B = _f64F(np.atleast_2d(A)), _f64F(np.atleast_2d(B))
+    m, k = A.shape
+    k2, n = B.shape
+    if k != k2:
+        raise ValueError("non-conformable arguments")
+    out = np.zeros((m, n), order="F")
+    _check(ctx, L.eagle_matmul(ctx, _dp(A), _dp(B), m, k, n, _dp(out)))
+    return out
+
+
+def mmt_sqrt_and_sqrtinv(MMt, device=0):
+    """E/R/calculateMMt_sqrt_and_sqrtinv.R:15-47 -> (sqrt, invsqrt, trace of their product), or None where the R function
+    returns NULL (MMt not positive definite)."""
+    L = _lib.load()
+    ctx = context(device)
+    M = _f64F(MMt)
+    n = M.shape[0]
+    sq, inv = np.zeros((n, n), order="F"), np.zeros((n, n), order="F")
+    tr = C.c_double()
+    rc = _check(ctx, L.eagle_mmt_sqrt_and_sqrtinv(ctx, _dp(M), n, _dp(sq), _dp(inv), C.byref(tr)), soft_ok=True)
+    if rc == 1:
+        return None
+    return sq, inv, tr.value
 
 
 def last_error(device=0):

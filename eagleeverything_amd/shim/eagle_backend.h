@@ -6,12 +6,12 @@
 
 #include "eagle_hip.h"
 
-// One context per R session, opened on first use on the device named by EAGLE_HIP_DEVICE (default 0).
+// One context per R session, opened on first use: the GPUs listed in EAGLE_HIP_DEVICES ("0,1,2,3": every call shards its
+// markers over them), else the device named by EAGLE_HIP_DEVICE, else device 0.
 inline eagle_ctx* eagle_backend_ctx() {
     static eagle_ctx* ctx = nullptr;
     if (!ctx) {
-        const char* d = std::getenv("EAGLE_HIP_DEVICE");
-        ctx = eagle_open(d ? std::atoi(d) : 0);
+        ctx = eagle_open_env();
         if (!ctx) Rcpp::stop(std::string("Eagle HIP backend: ") + eagle_open_error());
     }
     return ctx;

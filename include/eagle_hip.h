@@ -48,6 +48,19 @@ typedef void (*eagle_message_fn)(const char* text, void* user);
 /* Opens HIP device `device` (must be gfx950).  Returns NULL on failure; the reason is available from
  * eagle_open_error().  One ctx per device; a process that drives several GPUs opens one ctx each. */
 eagle_ctx* eagle_open(int device);
+/* Several GPUs of one node behind ONE context -- the reference's unused hook is AM(..., ngpu) (E/R/AM.R:185-196, forced to 0 at
+ * :214, handed to .find_qtl at :450-455).  eagle_calculateMMt / eagle_calculate_a_and_vara / eagle_calculate_reduced_a then
+ * split the file's markers into ndev contiguous ranges (boundaries at multiples of 256 markers), one host thread + stream
+ * per device, all joined before the call returns; results land in the caller's arrays exactly as with one device
+ * (bit-identical: integer MM^T, per-marker scan, and a certification that exchanges the shards' bounds).  Exchange steps:
+ * one int32 sum of the partial MM^T to the first device (ncclReduce over xGMI), the rows of W = S V S shared and
+ * all-gathered (ncclAllGather), 8 bytes per device through the host for the certificate.  RCCL is dlopen()ed on first use;
+ * a list that names one device twice (the one-GPU test configuration) or EAGLE_HIP_COLLECTIVES=host stages the sum through
+ * device copies and computes W on every device instead.
+ * eagle_open_env: the devices of EAGLE_HIP_DEVICES="0,1,..." if set, else EAGLE_HIP_DEVICE, else device 0. */
+eagle_ctx* eagle_open_devices(const int* devices, int ndev);
+eagle_ctx* eagle_open_env(void);
+int eagle_device_count(eagle_ctx* ctx);
 const char* eagle_open_error(void);
 void eagle_close(eagle_ctx* ctx);
 const char* eagle_last_error(eagle_ctx* ctx);
@@ -156,6 +169,29 @@ int eagle_create_M_ascii(eagle_ctx* ctx, const char* f_name, const char* f_name_
  * the device from the resident image of M.ascii (loaded if it is not there; column windows if it does not fit). */
 int eagle_create_Mt_ascii(eagle_ctx* ctx, const char* f_name, const char* f_name_ascii, const char* type,
                           double max_memory_in_Gbytes, const long dims[2], int quiet);
+
+/* ---------------------------------------------------------------------------------------------
+ * 1c. Dense n x n model algebra on the device (OPT-IN: north_star keeps calculateH / calculateP / emma.* on
+ *     host LAPACK, and nothing above calls these).  Once the scan takes tens of milliseconds the ~10-15 O(n^3) base-R calls
+ *     of a find_qtl iteration are the whole run time (the author's note MyPackage/MyREADME:1 names eigen(); his MAGMA
+ *     attempt is E/R/emma_eigen_R_wo_Z.R:9-15).  Column-major host matrices in and out, as R holds them.  The
+ *     factorisations are rocSOLVER library calls (dlopen()ed on first use), the products this library's fp64 MFMA GEMM.
+ * ------------------------------------------------------------------------------------------- */
+/* eigen(A, symmetric = TRUE): values in DEcreasing order as R returns them, the matching eigenvectors in the columns of
+ * vectors_out (NULL: only.values = TRUE).  Used by E/R/emma_eigen_L_wo_Z.R:3, emma_eigen_R_wo_Z.R:17, calculateMMt_sqrt_and_sqrtinv.R:25. */
+int eagle_sym_eig(eagle_ctx* ctx, const double* A, long n, double* values_out, double* vectors_out);
+/* chol2inv(chol(A)) (calculateMMt_sqrt_and_sqrtinv.R:30, calculateP.R:27, calculate_reduced_vara.R:27).  Returns
+ * EAGLE_SOFT_SENTINEL when A is not positive definite (R's chol() error text in eagle_last_error). */
+int eagle_chol2inv(eagle_ctx* ctx, const double* A, long n, double* Ainv_out);
+/* solve(A) (calculate_reduced_vara.R:31-33, calculateP.R:28).  EAGLE_SOFT_SENTINEL for a singular matrix. */
+int eagle_inverse(eagle_ctx* ctx, const double* A, long n, double* Ainv_out);
+/* C (m x n) = A (m x k) %*% B (k x n) on the fp64 MFMA GEMM of the scan operands (v_mfma_f64_16x16x4_f64). */
+int eagle_matmul(eagle_ctx* ctx, const double* A, const double* B, long m, long k, long n, double* C);
+/* E/R/calculateMMt_sqrt_and_sqrtinv.R:15-47 in one call: EAGLE_SOFT_SENTINEL if MMt is not positive definite by
+ * matrixcalc::is.positive.definite's rule (:15; eigenvalues below 1e-8 in magnitude count as 0); sqrt_out = U sqrt(L) U^T
+ * (:25-27), invsqrt_out = chol2inv(chol(sqrt)) (:30), *trace_out = sum(diag(sqrt %*% invsqrt)), whose truncation the R code
+ * compares with nrow(MMt) (:35-46; may be NULL). */
+int eagle_mmt_sqrt_and_sqrtinv(eagle_ctx* ctx, const double* MMt, long n, double* sqrt_out, double* invsqrt_out, double* trace_out);
 
 /* Replaces the R tail of .find_qtl:  tsq <- a^2/vara ; which(tsq == max(tsq, na.rm=TRUE))[1]
  *                                                E/R/find_qtl.R:71-83
@@ -275,6 +311,15 @@ int64_t eagle_scan_certify_workspace_bytes(long n_pad);
 int eagle_dev_scan_certify(eagle_ctx* ctx, const int8_t* Mt8, long L, long L_pad, long n_pad, long ld, const int8_t* cshift,
                            const int32_t* l1norm, int nslices, void* vara_ws, const double* Wu, const double* a, double* vara,
                            void* cert_ws, void* stream);
+/* The same in two phases, for scans whose markers are spread over several devices / ranks: _lb leaves the lower bound of
+ * this block's maximum tsq in cert_ws (eagle_cert_info.lower_bound); the caller takes the maximum over all blocks and hands
+ * it to _apply as lb_override (NaN: the block's own), so that every block selects exactly the candidates a single scan of
+ * all markers would. */
+int eagle_dev_scan_certify_lb(eagle_ctx* ctx, long L, long L_pad, long n_pad, const int8_t* cshift, const int32_t* l1norm, int nslices,
+                              void* vara_ws, const double* a, const double* vara, void* cert_ws, void* stream);
+int eagle_dev_scan_certify_apply(eagle_ctx* ctx, const int8_t* Mt8, long L, long L_pad, long n_pad, long ld, const int8_t* cshift,
+                                 const int32_t* l1norm, int nslices, void* vara_ws, const double* Wu, const double* a, double* vara,
+                                 void* cert_ws, double lb_override, void* stream);
 /* Certification counters of the LAST eagle_calculate_a_and_vara call of this ctx in digit-slice mode (summed over the
  * marker blocks of a streamed file): markers re-evaluated in fp64, of which flagged by their own error bound, and
  * whether a block fell back to the fp64 kernel entirely. */

@@ -1,0 +1,115 @@
+"""Several GPUs behind the reference-shaped C ABI (eagle_open_devices; the reference's unused AM(..., ngpu) hook,
+E/R/AM.R:185-196): every call shards the file's markers over the devices of the context, one worker thread per device.
+
+The build box has ONE card, so the device list names it two / three times: the same code path -- marker ranges, worker
+threads, rendezvous, partial MM^T packed and summed, lower bounds of the shards' maxima exchanged for the certificate,
+per-device results merged -- with the device-copy sum standing in for ncclReduce and W computed on every device instead of
+shared through ncclAllGather (the RCCL leg needs distinct devices and is not exercised here).
+Everything must come back bit for bit as from a single-device context.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from eagleeverything_amd import synth
+
+pytestmark = pytest.mark.gpu
+NA = np.nan
+
+
+@pytest.fixture(scope="module")
+def api():
+    from eagleeverything_amd import rcpp_api
+    assert rcpp_api.device_info()["arch"].startswith("gfx950")
+    yield rcpp_api
+    rcpp_api.close_all()
+
+
+def _all_calls(api, geno, n, L, S, V, ahat, P, y, sel, device):
+    out = {}
+    out["mmt"] = api.calculateMMt_rcpp(geno["asciifileM"], 8.0, 4, NA, (n, L), device=device)
+    out["mmt_masked"] = api.calculateMMt_rcpp(geno["asciifileM"], 8.0, 4, sel, (n, L), device=device)
+    for mode in (1, 0):
+        api.set_scan_mode(mode, device=device)
+        r = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat, device=device)
+        out["a%d" % mode], out["vara%d" % mode] = r["a"], r["vara"]
+        out["best%d" % mode] = api.last_scan_argmax(device=device)
+    api.set_scan_mode(1, device=device)
+    r = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], sel, S, V, 8.0, (L, n), ahat, device=device)
+    out["a_masked"], out["vara_masked"] = r["a"], r["vara"]
+    out["best_masked"] = api.last_scan_argmax(device=device)
+    out["ar"] = api.calculate_reduced_a_rcpp(geno["asciifileMt"], 0.7, P, y, 8.0, (n, L), sel, device=device)
+    out["geno"] = [api.extract_geno_rcpp(geno["asciifileM"], 8.0, c, (n, L), device=device) for c in (0, L // 2 + 3, L - 1)]
+    return out
+
+
+@pytest.mark.parametrize("devices", [(0, 0), (0, 0, 0)])
+def test_contexts_sharing_one_card_reproduce_the_single_device_results(devices, api, oracle, tmp_path):
+    from eagleeverything_amd import _lib
+    n, L = 700, 6001
+    rng = np.random.default_rng(3)
+    Mt8 = synth.genotypes_marker_major(n, L, seed=21)
+    Mt8[5000] = Mt8[40]                       # an exact tie across two shards: the smaller global index must win
+    geno = synth.write_geno_pair(str(tmp_path), Mt8)
+    A = rng.standard_normal((n, 40)) / 6.0
+    S = np.eye(n) + A @ A.T
+    V = 0.7 * np.eye(n) - 0.03 * (A[:, :3] @ A[:, :3].T)
+    ahat = rng.standard_normal(n)
+    P = 0.3 * np.eye(n) + 0.01 * (A @ A.T)
+    y = rng.standard_normal((n, 1))
+    sel = np.array([7.0, 3000.0, 5999.0])     # masked markers in different shards
+    one = _all_calls(api, geno, n, L, S, V, ahat, P, y, sel, device=0)
+    api.drop_cache(device=0)
+    many = _all_calls(api, geno, n, L, S, V, ahat, P, y, sel, device=devices)
+    assert _lib.load().eagle_device_count(api.context(devices)) == len(devices)
+    G = Mt8.astype(np.float64)
+    np.testing.assert_array_equal(one["mmt"], G.T @ G)
+    for key in one:
+        if key == "geno":
+            for x, z in zip(one[key], many[key]):
+                np.testing.assert_array_equal(x, z)
+        elif key.startswith("best"):
+            assert one[key][:2] == many[key][:2], key
+        else:
+            np.testing.assert_array_equal(one[key], many[key], err_msg=key)
+    # and both agree with the oracle
+    ref = oracle.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat)
+    np.testing.assert_allclose(many["vara1"].ravel(), ref["vara"].ravel(), rtol=1e-7)
+    assert many["best1"][0] == oracle.tsq_argmax(ref["a"], ref["vara"])[1]
+    # certification counters are summed over the devices
+    nre, nfl, fell = C.c_long(), C.c_long(), C.c_int()
+    api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat, device=devices)
+    assert _lib.load().eagle_last_scan_certificate(api.context(devices), C.byref(nre), C.byref(nfl), C.byref(fell)) == 0
+    assert nre.value >= 2 and fell.value == 0   # the tied pair at least
+    api.drop_cache(device=devices)
+
+
+def test_multi_device_streamed_shards(api, oracle, tmp_path, monkeypatch):
+    """Shards that may not stay resident are streamed per device; MM^T stays exact, a identical, vara identical except where a
+    block's own certification re-evaluated a few more markers in fp64, the selected marker identical."""
+    n, L = 520, 9000
+    rng = np.random.default_rng(8)
+    Mt8 = synth.genotypes_marker_major(n, L, seed=33)
+    geno = synth.write_geno_pair(str(tmp_path), Mt8)
+    A = rng.standard_normal((n, 30)) / 6.0
+    S = np.eye(n) + A @ A.T
+    V = 0.7 * np.eye(n) - 0.03 * (A[:, :3] @ A[:, :3].T)
+    ahat = rng.standard_normal(n)
+    one = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat, device=0)
+    best_one = api.last_scan_argmax(device=0)
+    mmt_one = api.calculateMMt_rcpp(geno["asciifileM"], 8.0, 4, NA, (n, L), device=0)
+    monkeypatch.setenv("EAGLE_HIP_MAX_RESIDENT_GB", "0.0008")   # 3072 x 768 bytes per shard do not fit: two blocks each
+    dev = (0, 0)
+    api.drop_cache(device=dev)
+    many = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat, device=dev)
+    best_many = api.last_scan_argmax(device=dev)
+    mmt_many = api.calculateMMt_rcpp(geno["asciifileM"], 8.0, 4, NA, (n, L), device=dev)
+    monkeypatch.delenv("EAGLE_HIP_MAX_RESIDENT_GB")
+    np.testing.assert_array_equal(mmt_one, mmt_many)
+    np.testing.assert_array_equal(one["a"], many["a"])
+    differ = np.flatnonzero(one["vara"].ravel() != many["vara"].ravel())
+    assert differ.size <= 64
+    np.testing.assert_allclose(many["vara"].ravel()[differ], one["vara"].ravel()[differ], rtol=1e-9)
+    assert best_one[0] == best_many[0]
+    api.drop_cache(device=dev)

@@ -10,7 +10,7 @@ from eagleeverything_amd.sharded import DeviceShard
 
 n, L = int(os.environ.get("N", 5000)), int(os.environ.get("LM", 131072))
 S = int(os.environ.get("SLICES", 5))
-variants = [int(v) for v in os.environ.get("VARIANTS", "0,7").split(",")]
+variants = [int(v) for v in os.environ.get("VARIANTS", "0,8").split(",")]  # 0 = shipped (384 x 256 tile), 8 = the 256 x 256 tile form
 lib = _lib.load()
 sh = DeviceShard(n, L)
 sh.fill_synthetic()
