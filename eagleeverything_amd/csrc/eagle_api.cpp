@@ -297,6 +297,12 @@ extern "C" int eagle_set_scan_mode(eagle_ctx* ctx, int mode) {
     for (eagle_ctx* p : ctx->peers) p->scan_mode = mode;
     return EAGLE_OK;
 }
+extern "C" int eagle_set_scan_rounding(eagle_ctx* ctx, int stochastic) {
+    if (!ctx || stochastic < 0 || stochastic > 1) return EAGLE_ERR_ARG;
+    ctx->scan_stochastic = stochastic;
+    for (eagle_ctx* p : ctx->peers) p->scan_stochastic = stochastic;
+    return EAGLE_OK;
+}
 extern "C" int eagle_set_scan_slices(eagle_ctx* ctx, int nslices) {
     if (!ctx || nslices < 0 || nslices > 8) return EAGLE_ERR_ARG;
     ctx->scan_slices = nslices;
@@ -964,7 +970,7 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
     const long np = eagle_pad(n), Lp = eagle_pad(Lr > 0 ? Lr : 1);
     const size_t sq = sizeof(double) * (size_t)np * np;
     const bool use_i8 = ctx->scan_mode == 1 && 64.0 * 512.0 * (double)np < 2147483648.0;
-    const int nslices = ctx->scan_slices;
+    const int nslices = ctx->scan_slices | (ctx->scan_stochastic ? EAGLE_SLICES_STOCHASTIC : 0);
     const bool share_w = nd > 1 && rccl && (np / 128) % nd == 0;  // the same answer on every device
     int rc = EAGLE_OK;
     hipError_t e = hipSetDevice(ctx->device);
@@ -978,7 +984,7 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
     bool streamed = false;
     if (!rc && Lr > 0) {
         int r = get_resident(ctx, f_name_ascii, m0, Lr, 0, n, max_memory_in_Gbytes, host_threads(), &g,
-                             4 * sq + (use_i8 ? (size_t)eagle_vara_i8_workspace_bytes(np, Lp, nslices) + (size_t)Lp * np + 5 * (size_t)Lp +
+                             4 * sq + (use_i8 ? (size_t)eagle_vara_i8_workspace_bytes(np, Lp, nslices) + (size_t)Lp * np + 9 * (size_t)Lp +
                                                     (size_t)eagle_scan_certify_workspace_bytes(np) : 0) +
                                  ((size_t)1 << 30));  // operands, digit + certification workspaces, the re-centred image of the shard
         if (r < 0) rc = r;
@@ -1002,7 +1008,7 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
     auto setup = [&]() -> int {
         int r = arena_reserve(ctx, 4 * arena_round(sq) + 2 * arena_round(sizeof(double) * np) + arena_round(wsb) + arena_round(certb) +
                                        (streamed ? (use_i8 ? 4 : 2) * arena_round((size_t)Lc * np) + 2 * arena_round((size_t)Lc) +
-                                                       2 * arena_round(sizeof(int32_t) * (size_t)Lc) : 0));
+                                                       2 * arena_round(2 * sizeof(int32_t) * (size_t)Lc) : 0));
         if (r) return r;
         Sa = arena_take<double>(ctx, sq);
         Va = arena_take<double>(ctx, sq);
@@ -1019,7 +1025,7 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
             for (int b = 0; b < 2 && use_i8; b++) {
                 shifted[b] = arena_take<int8_t>(ctx, (size_t)Lc * np);
                 cs[b] = arena_take<int8_t>(ctx, (size_t)Lc);
-                l1s[b] = arena_take<int32_t>(ctx, sizeof(int32_t) * (size_t)Lc);
+                l1s[b] = arena_take<int32_t>(ctx, 2 * sizeof(int32_t) * (size_t)Lc);
             }
         }
         if ((r = upload_square(ctx, inv_MMt_sqrt, n, np, Sa))) return r;
@@ -1071,7 +1077,7 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
                 if (!g->dev_s) {
                     e = hipMalloc((void**)&g->dev_s, (size_t)g->rows_pad * g->ld);
                     if (e == hipSuccess) e = hipMalloc((void**)&g->cshift, (size_t)g->rows_pad);
-                    if (e == hipSuccess) e = hipMalloc((void**)&g->l1, sizeof(int32_t) * (size_t)g->rows_pad);
+                    if (e == hipSuccess) e = hipMalloc((void**)&g->l1, 2 * sizeof(int32_t) * (size_t)g->rows_pad);
                     rc = e == hipSuccess ? eagle_dev_marker_shift(ctx, g->dev, g->rows_pad, n, np, g->ld, g->dev_s, g->cshift, g->l1, ctx->stream)
                                          : eagle_fail_hip(ctx, e, "re-centred image hipMalloc");
                     if (rc) {  // never leave a half-made image behind: the next call would scan garbage

@@ -28,7 +28,7 @@ struct GenoEntry {
     int8_t* dev = nullptr;
     int8_t* dev_s = nullptr;    // re-centred image m - c_i (eagle_dev_marker_shift), made on the first digit-slice scan of the file
     int8_t* cshift = nullptr;   // c_i per row
-    int32_t* l1 = nullptr;      // sum_j |m_ij - c_i| per row (error bound of the digit-slice scan)
+    int32_t* l1 = nullptr;      // {sum_j |m_ij - c_i|, sum_j (m_ij - c_i)^2} per row (error bounds of the digit-slice scan)
 };
 
 // Meeting point of the per-device worker threads of one multi-device call.  arrive(ok, v) blocks until every device has
@@ -74,6 +74,7 @@ struct eagle_ctx {
     void* msg_user = nullptr;
     int scan_mode = 1;   // 1 = int8 digit slices on the int8 MFMA (default), 0 = fp64 MFMA
     int scan_slices = 0; // 0 = chosen per call from the error bound (3..7), 1..8 = fixed
+    int scan_stochastic = 0;  // 1 = digits of W rounded at random (unbiased): probabilistic certificate, one digit fewer (opt-in)
     std::vector<GenoEntry> cache;
     // results of the last calls, kept in HBM
     double* d_mmt = nullptr; long mmt_n = 0; double* d_mmt_max = nullptr;

@@ -313,9 +313,21 @@ __global__ __launch_bounds__(256) void k_absmax_offdiag(const double* __restrict
 // Measured errors sit three orders below the bound (C2, S = 4: bound 1.7e-8, largest error against an fp64 evaluation
 // 1.5e-11).  eagle_set_scan_slices forces more digits.
 #define VARA_DIGIT_BUDGET 1e-7
+// Stochastic rounding (EAGLE_SLICES_STOCHASTIC, opt-in).  With round-to-nearest the truncation errors R_jk of the digits are
+// only known to lie in [-delta, delta], delta = 2^(e+1-8S), and the guaranteed bound must add them up in absolute value:
+// l1^2/2 * delta.  If instead each entry is rounded down or up AT RANDOM with the probabilities that make the rounding
+// unbiased (a counter-based generator keyed by the entry's position, independent of the data), the R_jk are independent,
+// zero-mean and confined to an interval of width 2 delta, and Hoeffding's inequality bounds their weighted sum:
+//     P( |sum_{j<k} m'_j m'_k R_jk| >= t )  <=  2 exp( -2 t^2 / sum_{j<k} (2 delta m'_j m'_k)^2 )  <=  2 exp( -(t / (delta q2))^2 ),
+// q2 = sum_j m'_j^2.  With t = 8.355 delta q2 the right side is 1e-30 per marker -- below 1e-22 over every marker of every
+// scan of an AM() run -- and the bound grows with the marker's non-zero count instead of its square: one digit fewer carries
+// the same 1e-7 budget (n = 5000 .. 10000).  The certificate becomes a probabilistic one (over the library's own random
+// bits, for any input); everything downstream -- per-marker flagging, fp64 re-evaluation of the candidates -- is unchanged.
+#define VARA_HOEFFDING_K 8.355  /* sqrt(ln(2 / 1e-30)) */
 // One block: dW[k] = Wu[k][k] (contiguous copy), sumdiag in a fixed order, then the slice count (forced = 1..8: that S).
-__global__ __launch_bounds__(256) void k_vara_prep(const double* __restrict__ Wu, long n_pad, int forced, VaraHdr* __restrict__ hdr,
+__global__ __launch_bounds__(256) void k_vara_prep(const double* __restrict__ Wu, long n_pad, int forced_arg, VaraHdr* __restrict__ hdr,
                                                    double* __restrict__ dW) {
+    const int forced = forced_arg & 0xff, stochastic = (forced_arg & EAGLE_SLICES_STOCHASTIC) ? 1 : 0;
     double s = 0.0;
     for (long k = threadIdx.x; k < n_pad; k += 256) {
         double d = Wu[k * n_pad + k];
@@ -338,13 +350,17 @@ __global__ __launch_bounds__(256) void k_vara_prep(const double* __restrict__ Wu
         if (S <= 0) {
             const double target = VARA_DIGIT_BUDGET * 0.5 * red[0];
             S = 7;
-            for (int c = 3; c <= 7; c++)
-                if (ldexp(nn, e + 1 - 8 * c) <= target) { S = c; break; }
+            for (int c = stochastic ? 2 : 3; c <= 7; c++) {
+                // worst case over markers: every entry non-zero (nearest: errors aligned; stochastic: q2 = n, the Hoeffding radius)
+                const double b = stochastic ? VARA_HOEFFDING_K * (double)n_pad * ldexp(1.0, e + 1 - 8 * c) : ldexp(nn, e + 1 - 8 * c);
+                if (b <= target) { S = c; break; }
+            }
         }
         if (mx == 0.0) S = 1;
         hdr->S = S;
+        hdr->pad = stochastic;
         hdr->sumdiag = red[0];
-        hdr->bound = mx > 0.0 ? ldexp(nn, e + 1 - 8 * S) : 0.0;
+        hdr->bound = mx > 0.0 ? ldexp(nn, e + 1 - 8 * S) * (stochastic ? 2.0 : 1.0) : 0.0;  // what can never be exceeded
     }
 }
 
@@ -365,7 +381,25 @@ __global__ __launch_bounds__(256) void k_slice_w(const double* __restrict__ Wu, 
         // output element (k = bk + r, j = bj + tx):  Q = round(Wu * 2^(8S - e - 2)) is an exact integer below 2^(8S-2)
         // (llrint of a double of that size is exact); its balanced base-256 digits, least significant first,
         // d = ((Q + 128) mod 256) - 128 in [-128,127], Q <- (Q - d)/256; the leading digit ends in [-65,65].
-        long long Q = (bk + r == bj + tx) ? 0 : llrint(ldexp(tile[tx][r], 8 * nslices - (e + 2)));
+        long long Q = 0;
+        if (bk + r != bj + tx) {
+            const double yv = ldexp(tile[tx][r], 8 * nslices - (e + 2));
+            if (hdr->pad) {  // unbiased random rounding, keyed by the entry's position (see VARA_HOEFFDING_K above)
+                const double fl = floor(yv);
+                unsigned long long z = (unsigned long long)((bj + tx) * np + bk + r) + 0x9E3779B97F4A7C15ULL;  // splitmix64
+                z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+                z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+                z ^= z >> 31;
+                z += 0x9E3779B97F4A7C15ULL;                                                                      // second round
+                z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+                z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+                z ^= z >> 31;
+                const double u = (double)(z >> 11) * 0x1p-53;  // uniform on multiples of 2^-53 in [0, 1)
+                Q = (long long)fl + (u < yv - fl ? 1 : 0);
+            } else {
+                Q = llrint(yv);
+            }
+        }
         for (int s = nslices - 1; s >= 0; s--) {
             long long d = ((Q + 128) & 255) - 128;
             Q = (Q - d) >> 8;
@@ -411,8 +445,12 @@ __global__ __launch_bounds__(256) void k_marker_shift(const int8_t* __restrict__
     else if (pos > zer && pos > neg) c = 1;
     if (lane == 0) {
         cshift[row] = (int8_t)c;
-        // sum_j |m'_ij| of the re-centred marker: the per-marker digit error bound is l1^2 / 2 * 2^(e+1-8S) (k_cert_*)
-        if (l1norm) l1norm[row] = c == 0 ? neg + pos : (c < 0 ? zer + 2 * pos : zer + 2 * neg);
+        // {sum_j |m'_ij|, sum_j m'_ij^2} of the re-centred marker: the per-marker digit error bound is l1^2 / 2 * 2^(e+1-8S)
+        // (round to nearest) or 8.355 q2 2^(e+1-8S) (stochastic rounding); k_cert_*
+        if (l1norm) {
+            l1norm[2 * row] = c == 0 ? neg + pos : (c < 0 ? zer + 2 * pos : zer + 2 * neg);
+            l1norm[2 * row + 1] = c == 0 ? neg + pos : (c < 0 ? zer + 4 * pos : zer + 4 * neg);
+        }
     }
     int8_t* dst = Mt8s + row * ld;
     for (int j = lane * 16; j < (int)ld; j += 64 * 16) {
@@ -783,7 +821,7 @@ __global__ __launch_bounds__(256) void k_vara_i8_finish(const long long* __restr
 #define CERT_CAP 2048
 struct CertHdr { unsigned long long lb_bits; int count; int overflow; int flagged; int pad; };  // = eagle_cert_info of the public header
 
-struct CertCtx { double delta, absR, sumdiag; };
+struct CertCtx { double delta, absR, sumdiag; int stochastic; };
 __device__ __forceinline__ CertCtx cert_ctx(const VaraHdr* hdr) {
     CertCtx c;
     int e = 0;
@@ -792,11 +830,14 @@ __device__ __forceinline__ CertCtx cert_ctx(const VaraHdr* hdr) {
     c.delta = mx > 0.0 ? ldexp(1.0, e + 1 - 8 * hdr->S) : 0.0;
     c.absR = fabs(hdr->R);
     c.sumdiag = hdr->sumdiag;
+    c.stochastic = hdr->pad;
     return c;
 }
-__device__ __forceinline__ double cert_bound(const CertCtx& cc, int l1, int c, double vdiag, double mrho, double vara) {
-    const double l = (double)l1;
-    double b = 0.5 * l * l * cc.delta;
+__device__ __forceinline__ double cert_bound(const CertCtx& cc, const int32_t* l1q2, long i, int c, double vdiag, double mrho, double vara) {
+    const double l = (double)l1q2[2 * i];
+    // round to nearest: guaranteed; stochastic rounding: exceeded with probability below 1e-30 per marker (and never above
+    // the guaranteed l1^2 * delta of an interval of twice the width)
+    double b = cc.stochastic ? fmin(VARA_HOEFFDING_K * (double)l1q2[2 * i + 1] * cc.delta, l * l * cc.delta) : 0.5 * l * l * cc.delta;
     double mag = fabs(vdiag) + fabs(vara - vdiag);
     if (c != 0) mag += 2.0 * (fabs(mrho) + cc.absR);
     return b + 0x1p-48 * mag + 0x1p-50 * cc.sumdiag;
@@ -810,7 +851,7 @@ __global__ __launch_bounds__(256) void k_cert_lb(const double* __restrict__ a, c
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L; i += (long)gridDim.x * 256) {
         const double x = a[i], v = vara[i];
         if (!(isfinite(x) && isfinite(v))) continue;
-        const double up = v + cert_bound(cc, l1[i], cshift[i], vdiag[i], mrho[i], v);
+        const double up = v + cert_bound(cc, l1, i, cshift[i], vdiag[i], mrho[i], v);
         if (!(up > 0.0)) continue;
         const double lb = (x * x) / up;
         best = lb > best ? lb : best;
@@ -832,7 +873,7 @@ __global__ __launch_bounds__(256) void k_cert_select(const double* __restrict__ 
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L; i += (long)gridDim.x * 256) {
         const double x = a[i], v = vara[i];
         if (!(isfinite(x) && isfinite(v))) continue;  // NaN / Inf operands: the fp64 kernel gives the same
-        const double b = cert_bound(cc, l1[i], cshift[i], vdiag[i], mrho[i], v);
+        const double b = cert_bound(cc, l1, i, cshift[i], vdiag[i], mrho[i], v);
         const bool flagged = b > 1e-7 * fabs(v);
         const double den = v - b;
         const bool cand = !(den > 0.0) || (x * x) / den >= thr;
@@ -945,7 +986,7 @@ __global__ void k_vara_i8_bound(const VaraHdr* __restrict__ hdr, double* __restr
 // workspace: [ VaraHdr (padded to 256) | q: Smax*L_pad int64 | dW: n_pad f64 | vdiag: L_pad f64 | mrho: L_pad f64 | rho: n_pad f64 |
 //              column partials of rho: (n_pad/256 + 1) * n_pad f64 | Bs: Smax*n_pad*n_pad int8 ]
 #define VARA_SMAX_AUTO 7
-static int ws_smax(int nslices) { return nslices > 0 ? nslices : VARA_SMAX_AUTO; }
+static int ws_smax(int nslices) { return (nslices & 0xff) > 0 ? (nslices & 0xff) : VARA_SMAX_AUTO; }  // bit 8: EAGLE_SLICES_STOCHASTIC
 static size_t ws_q_off() { return 256; }
 static size_t ws_dw_off(long L_pad, int smax) { return 256 + (size_t)smax * L_pad * 8; }
 static size_t ws_vd_off(long n_pad, long L_pad, int smax) { return ws_dw_off(L_pad, smax) + (size_t)n_pad * 8; }
@@ -962,7 +1003,7 @@ extern "C" int64_t eagle_vara_i8_workspace_bytes(long n_pad, long L_pad, int nsl
 }
 
 static int vara_i8_check(eagle_ctx* ctx, long L_pad, long n_pad, long ld, int nslices) {
-    if (L_pad % T8 || n_pad % T8 || ld % 128 || n_pad > ld || nslices < 0 || nslices > 8 || (double)ld * T8 >= 2147483648.0)
+    if (L_pad % T8 || n_pad % T8 || ld % 128 || n_pad > ld || nslices < 0 || (nslices & ~EAGLE_SLICES_STOCHASTIC) > 8 || (double)ld * T8 >= 2147483648.0)
         return eagle_fail(ctx, EAGLE_ERR_ARG, "vara_i8: layout contract violated (L_pad % 256, n_pad % 256, 0 <= nslices <= 8)");
     // int32 tile row-sum: 64 columns per wave x |T*m'| <= 2*2*128*n_pad each, |m'| <= 2 (accumulation across tiles is int64)
     if (64.0 * 512.0 * (double)n_pad >= 2147483648.0)

@@ -108,6 +108,13 @@ def set_scan_slices(nslices, device=0):
     _check(ctx, _lib.load().eagle_set_scan_slices(ctx, int(nslices)))
 
 
+def set_scan_rounding(stochastic, device=0):
+    """0 (default) = digits of W rounded to nearest (guaranteed bound); 1 = stochastic rounding (probabilistic certificate,
+    failure probability < 1e-30 per marker, one digit fewer)."""
+    ctx = context(device)
+    _check(ctx, _lib.load().eagle_set_scan_rounding(ctx, int(stochastic)))
+
+
 def drop_cache(device=0):
     _lib.load().eagle_drop_cache(context(device))
 

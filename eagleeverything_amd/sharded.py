@@ -145,6 +145,7 @@ class DeviceShard:
         self.share_w = True  # multi-rank runs split the n^3 part of the scan operands (scan_operands)
         self.mode = 0
         self.nslices = 0  # 0 = chosen by the library from its error bound
+        self.stochastic = False  # digits of W rounded at random (eagle_set_scan_rounding): probabilistic certificate, one digit fewer
 
     # ---- plumbing -------------------------------------------------------------------------------
     def _stream(self):
@@ -273,6 +274,10 @@ class DeviceShard:
         self._check(self.L.eagle_dev_gemv_i8(self.ctx, self.Mt8.data_ptr(), self.Lp, self.np_, self.np_, self.v.data_ptr(),
                                              1.0, self.a.data_ptr(), self._stream()))
 
+    def _ns(self):
+        """The `nslices` argument of the digit-slice entry points: count | EAGLE_SLICES_STOCHASTIC."""
+        return int(self.nslices) | (0x100 if (self.stochastic and self.mode == 1) else 0)
+
     def _ws(self):
         if self.ws is None or self._ws_mode != self.mode:
             fn = self.L.eagle_vara_f6_workspace_bytes if self.mode == 2 else self.L.eagle_vara_i8_workspace_bytes
@@ -287,7 +292,7 @@ class DeviceShard:
         if self.Mt8s is None:
             self.Mt8s = self.torch.empty_like(self.Mt8)
             self.cshift = self.torch.empty(self.Lp, dtype=self.torch.int8, device=self.dev)
-            self.l1 = self.torch.empty(self.Lp, dtype=self.torch.int32, device=self.dev)
+            self.l1 = self.torch.empty((self.Lp, 2), dtype=self.torch.int32, device=self.dev)  # {sum |m'|, sum m'^2} per marker
             self._check(self.L.eagle_dev_marker_shift(self.ctx, self.Mt8.data_ptr(), self.Lp, self.n, self.np_, self.np_,
                                                       self.Mt8s.data_ptr(), self.cshift.data_ptr(), self.l1.data_ptr(), self._stream()))
         return self.Mt8s, self.cshift
@@ -305,7 +310,7 @@ class DeviceShard:
         ws = self._ws()
         prep = self.L.eagle_dev_vara_f6_prepare if self.mode == 2 else self.L.eagle_dev_vara_i8_prepare
         self._check(prep(self.ctx, self.Mt8.data_ptr(), self.Lp, self.np_, self.np_,
-                    self.Wu.data_ptr(), self.nslices, ws.data_ptr(), self.v.data_ptr() if with_a else None,
+                    self.Wu.data_ptr(), self._ns(), ws.data_ptr(), self.v.data_ptr() if with_a else None,
                     self.a.data_ptr() if with_a else None, self._stream()))
 
     def vara_kernel(self):
@@ -320,7 +325,7 @@ class DeviceShard:
         else:
             Ms, cs = self.shifted_image()
             self._check(self.L.eagle_dev_vara_i8_mfma_shifted(self.ctx, Ms.data_ptr(), cs.data_ptr(), self.Lp, self.np_, self.np_,
-                                                              self.nslices, self._ws().data_ptr(), self.vara.data_ptr(), None,
+                                                              self._ns(), self._ws().data_ptr(), self.vara.data_ptr(), None,
                                                               self._stream()))
 
     def certify(self):
@@ -333,7 +338,7 @@ class DeviceShard:
             nb = int(self.L.eagle_scan_certify_workspace_bytes(self.np_))
             self.cert_ws = self.torch.empty(nb, dtype=self.torch.uint8, device=self.dev)
         self._check(self.L.eagle_dev_scan_certify(self.ctx, self.Mt8.data_ptr(), self.Lloc, self.Lp, self.np_, self.np_,
-                                                  self.cshift.data_ptr(), self.l1.data_ptr(), self.nslices, self._ws().data_ptr(),
+                                                  self.cshift.data_ptr(), self.l1.data_ptr(), self._ns(), self._ws().data_ptr(),
                                                   self.Wu.data_ptr(), self.a.data_ptr(), self.vara.data_ptr(), self.cert_ws.data_ptr(),
                                                   self._stream()))
 

@@ -79,6 +79,17 @@ int eagle_device_info(eagle_ctx* ctx, char* arch_out, int arch_len, int* cu_coun
  * (sum_j |m_ij|)^2 * 2^(e+1-8S), max_{j!=k} |W_jk + W_kj| < 2^e, plus fp64 rounding of an n-term and an S-term sum. */
 int eagle_set_scan_mode(eagle_ctx* ctx, int mode);
 int eagle_set_scan_slices(eagle_ctx* ctx, int nslices);
+/* How the digits of W are rounded (digit-slice mode).  0 (default): to nearest -- every vara_i is GUARANTEED within
+ * l1_i^2 / 2 * 2^(e+1-8S) of the exact quadratic form (l1_i = sum_j |m'_ij| of the re-centred marker).  1: stochastic
+ * rounding -- each entry rounded down or up at random with the probabilities that make it unbiased, from a counter-based
+ * generator keyed by the entry's position (independent of the data, reproducible).  The truncation errors are then
+ * independent and zero-mean, Hoeffding's inequality bounds marker i's error by 8.355 q2_i 2^(e+1-8S), q2_i = sum_j m'_ij^2,
+ * with failure probability below 1e-30 per marker (1e-22 over every marker of every scan of an AM() run), and the automatic
+ * digit count drops by one (C2 / C3: S = 3 instead of 4, a quarter less matrix work).  The certificate is then a
+ * probabilistic one; flagging, fp64 re-evaluation and the selected marker work exactly as in mode 0.  In the
+ * device-resident entry points the same switch is bit 8 of the `nslices` argument (EAGLE_SLICES_STOCHASTIC). */
+#define EAGLE_SLICES_STOCHASTIC 0x100
+int eagle_set_scan_rounding(eagle_ctx* ctx, int stochastic);
 
 /* ---------------------------------------------------------------------------------------------
  * 1. Reference-shaped entry points (host pointers, files on disk)
@@ -290,7 +301,8 @@ int eagle_dev_vara_i8_mfma(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n
  * the MFMA kernel on Mt8s (rare-variant markers become sparse rows, so their truncation error bound
  * (sum_j |m'_ij|)^2 / 2 * 2^(e+1-8S) shrinks with their own diagonal term) and adds c_i m_i^T rho - c_i^2 R in fp64;
  * prepare (always on the ORIGINAL image) has left rho, R and m^T rho in the workspace.
- * l1norm (may be NULL): l1norm[i] = sum_j |Mt8s[i][j]|, which eagle_dev_scan_certify turns into marker i's error bound. */
+ * l1norm (may be NULL; 2 * L_pad int32): l1norm[2i] = sum_j |Mt8s[i][j]|, l1norm[2i+1] = sum_j Mt8s[i][j]^2, which
+ * eagle_dev_scan_certify turns into marker i's error bound. */
 int eagle_dev_marker_shift(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n, long n_pad, long ld, int8_t* Mt8s,
                            int8_t* cshift, int32_t* l1norm, void* stream);
 int eagle_dev_vara_i8_mfma_shifted(eagle_ctx* ctx, const int8_t* Mt8s, const int8_t* cshift, long L_pad, long n_pad, long ld,
@@ -298,7 +310,8 @@ int eagle_dev_vara_i8_mfma_shifted(eagle_ctx* ctx, const int8_t* Mt8s, const int
 int eagle_dev_vara_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu,
                       int nslices, void* ws, double* vara_out, double* err_bound_dev, void* stream);
 /* Certification of a digit-slice scan (after eagle_dev_vara_i8_mfma_shifted, before the arg-max), all on the device:
- * every vara_i carries the a-posteriori bound b_i = l1norm[i]^2 / 2 * 2^(e+1-8S) + fp64 rounding terms; markers with
+ * every vara_i carries the a-posteriori bound b_i = l1_i^2 / 2 * 2^(e+1-8S) (stochastic rounding: 8.355 q2_i 2^(e+1-8S)) + fp64
+ * rounding terms; markers with
  * b_i > 1e-7 |vara_i|, and every marker that the bounds cannot exclude from being the arg-max of tsq = a^2 / vara
  * (a_i^2 / (vara_i - b_i) >= max_j a_j^2 / (vara_j + b_j)), are re-evaluated by the fp64 MFMA kernel on the ORIGINAL image
  * Mt8 -- bitwise the value eagle_dev_vara_f64 gives that marker -- and written back into vara.  The arg-max of tsq over the

@@ -50,12 +50,18 @@ def test_contexts_sharing_one_card_reproduce_the_single_device_results(devices, 
     n, L = 700, 6001
     rng = np.random.default_rng(3)
     Mt8 = synth.genotypes_marker_major(n, L, seed=21)
-    Mt8[5000] = Mt8[40]                       # an exact tie across two shards: the smaller global index must win
-    geno = synth.write_geno_pair(str(tmp_path), Mt8)
     A = rng.standard_normal((n, 40)) / 6.0
     S = np.eye(n) + A @ A.T
     V = 0.7 * np.eye(n) - 0.03 * (A[:, :3] @ A[:, :3].T)
     ahat = rng.standard_normal(n)
+    # the strongest marker twice, in the first and in the last shard: an exact tie across devices, the smaller global index wins
+    a0, v0 = oracle.scan_from_i8(Mt8, S, V, ahat)
+    t = int(np.argmax(a0 ** 2 / v0))
+    top = Mt8[t].copy()
+    Mt8[t] = 0
+    Mt8[40] = top
+    Mt8[5000] = top
+    geno = synth.write_geno_pair(str(tmp_path), Mt8)
     P = 0.3 * np.eye(n) + 0.01 * (A @ A.T)
     y = rng.standard_normal((n, 1))
     sel = np.array([7.0, 3000.0, 5999.0])     # masked markers in different shards
@@ -76,7 +82,7 @@ def test_contexts_sharing_one_card_reproduce_the_single_device_results(devices, 
     # and both agree with the oracle
     ref = oracle.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat)
     np.testing.assert_allclose(many["vara1"].ravel(), ref["vara"].ravel(), rtol=1e-7)
-    assert many["best1"][0] == oracle.tsq_argmax(ref["a"], ref["vara"])[1]
+    assert many["best1"][0] == oracle.tsq_argmax(ref["a"], ref["vara"])[1] == 41
     # certification counters are summed over the devices
     nre, nfl, fell = C.c_long(), C.c_long(), C.c_int()
     api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat, device=devices)
