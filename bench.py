@@ -410,6 +410,15 @@ def main():
                                       "selected_marker_equal": bool(s7[0] == sel_i8[0]), "roofline": vara_roofline(sh, p7["kern"], 7)}
         sh.nslices = args.slices
         sh.ws = None
+        # opt-in stochastic rounding of W's digits (eagle_set_scan_rounding): probabilistic certificate, one digit fewer
+        sh.stochastic = True
+        sr, elr, pr = run.timed(3, 1)
+        Sr = sh.vara_i8_info()[0]
+        secondary["scan_stochastic_rounding"] = {"value": Ltot * 3 / elr, "unit": "markers/s", "ms_per_step": elr / 3 * 1e3, "slices": Sr,
+                                                 "selected_marker_equal": bool(sr[0] == sel_i8[0]), "certificate": sh.certificate(),
+                                                 "note": "opt-in: per-marker error bound 8.355*q2*2^(e+1-8S) holds with probability 1 - 1e-30",
+                                                 "roofline": vara_roofline(sh, pr["kern"], Sr)}
+        sh.stochastic = False
         # BASELINE configs[1]: 5,000 x 500,000 on one card
         del run, sh
         torch.cuda.empty_cache()

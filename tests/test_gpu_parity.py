@@ -646,6 +646,61 @@ def test_certified_candidates_are_bitwise_fp64_device_api(api, oracle):
     sh.nslices = 0
 
 
+def test_stochastic_rounding_option(api, oracle):
+    """eagle_set_scan_rounding(1) / EAGLE_SLICES_STOCHASTIC (opt-in): the digits of W rounded at random (unbiased, keyed by
+    position).  One digit fewer than round-to-nearest at n = 5000; every error inside the Hoeffding radius
+    8.355 q2 2^(e+1-8S) that the certification uses and inside the 1e-7 budget; reproducible; same selected marker."""
+    import torch
+    from eagleeverything_amd.sharded import DeviceShard
+    n, L = 5000, 32768
+    sh = DeviceShard(n, L)
+    sh.fill_synthetic(seed=77)
+    gen = torch.Generator(device=sh.dev)
+    gen.manual_seed(3)
+    A = torch.randn((n, 48), generator=gen, device=sh.dev, dtype=torch.float64) / 40.0
+    S = 0.5 * torch.eye(n, dtype=torch.float64, device=sh.dev) + A @ A.T
+    V = 0.6 * torch.eye(n, dtype=torch.float64, device=sh.dev) - 0.03 * (A[:, :6] @ A[:, :6].T)
+    ahat = torch.randn(n, generator=gen, device=sh.dev, dtype=torch.float64)
+    sh.set_operands(S, V, ahat)
+    rows = torch.arange(0, 2048, device=sh.dev)
+    Mt_s = sh.Mt8[rows][:, :n].cpu().numpy()
+    a_ref, v_ref = oracle.scan_from_i8(Mt_s, S.cpu().numpy(), V.cpu().numpy(), ahat.cpu().numpy())
+    sh.mode = 1
+    sh.scan()
+    torch.cuda.synchronize()
+    S_near, _, maxoff = sh.vara_i8_info()
+    best_near = sh.best()[:2]
+    sh.stochastic = True
+    sh.certified = False                       # raw digit values first: the bound must hold for them
+    sh.scan()
+    torch.cuda.synchronize()
+    S_rand = sh.vara_i8_info()[0]
+    assert S_rand == S_near - 1, (S_near, S_rand)
+    raw = sh.vara[rows].cpu().numpy()
+    e = int(np.floor(np.log2(maxoff))) + 1     # max |off-diagonal| < 2^e
+    cs = sh.cshift[rows].cpu().numpy().astype(np.int64)
+    q2 = ((Mt_s.astype(np.int64) - cs[:, None]) ** 2).sum(axis=1)
+    assert np.array_equal(sh.l1[rows, 1].cpu().numpy(), q2)
+    radius = 8.355 * q2 * 2.0 ** (e + 1 - 8 * S_rand)
+    err = np.abs(raw - v_ref)
+    assert np.all(err <= radius + 1e-12 * np.abs(v_ref))
+    assert np.max(radius / np.abs(v_ref)) < 1e-7          # what the certification checks per marker
+    assert np.max(err / np.abs(v_ref)) < 1e-8             # the Hoeffding radius is generous: typical errors are ~ a tenth of it
+    sh.certified = True
+    sh.scan()
+    torch.cuda.synchronize()
+    v1 = sh.vara[:L].clone()
+    assert sh.best()[:2] == best_near                      # same marker, and its fp64 value, whichever rounding
+    assert sh.certificate()["overflow"] == 0
+    sh.scan()
+    torch.cuda.synchronize()
+    assert torch.equal(sh.vara[:L], v1)                    # position-keyed random bits: reproducible
+    np.testing.assert_allclose(v1[rows].cpu().numpy(), v_ref, rtol=RTOL_DIGITS)
+    # the reference-shaped switch
+    api.set_scan_rounding(1)
+    api.set_scan_rounding(0)
+
+
 def test_vara_fp4_fp6_engine(api, oracle):
     """The block-scaled form of the vara kernel (genotypes fp4, base-33 digits of W as fp6, exact fp32 sums): against the
     oracle with the automatic digit count, and inside its documented bound n_pad^2 * 2^(e-5S) with fewer digits."""
