@@ -243,7 +243,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=10000, help="individuals")
+    ap.add_argument("--individuals", "--n", dest="n", type=int, default=10000,
+                    help="individuals (spell it --individuals under torch.distributed.run, whose own parser takes --n for one of its options)")
     ap.add_argument("--markers", type=int, default=1000000, help="markers in TOTAL (split over the GPUs: strong scaling)")
     ap.add_argument("--mode", choices=["f64", "i8"], default=os.environ.get("EAGLE_SCAN_MODE", "i8"))
     ap.add_argument("--slices", type=int, default=0, help="int8 digit slices of W in i8 mode (0 = chosen from the error bound)")

@@ -7,7 +7,7 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
-OURS = ("k_vara_i8", "k_syrk_f4", "k_pack_fp4", "k_marker_shift", "k_rho_rows", "k_rho_cols", "k_rho_final", "k_syrk_i8", "k_gemm_f64", "k_gemv_mfma", "k_slice_vec", "k_sym_check", "k_vara_prep", "k_absmax_offdiag", "k_slice_w", "k_fold_upper", "k_colgemv", "k_tsq", "k_absmax",
+OURS = ("k_vara_i8w", "k_vara_i8", "k_vara_f64", "k_cert_lb", "k_cert_select", "k_cert_gather", "k_tiles_pack", "k_syrk_f4", "k_pack_fp4", "k_marker_shift", "k_rho_rows", "k_rho_cols", "k_rho_final", "k_syrk_i8", "k_gemm_f64", "k_gemv_mfma", "k_slice_vec", "k_sym_check", "k_vara_prep", "k_absmax_offdiag", "k_slice_w", "k_fold_upper", "k_colgemv", "k_tsq", "k_absmax",
         "k_transpose_i8", "k_mmt_finish", "k_mmt_normalise", "k_decode_ascii", "k_vara_i8_finish")
 
 
@@ -25,8 +25,12 @@ def short(name):
                 return "k_gemm_f64_tail"
             if "k_gemm_f64" in name:
                 return "k_gemm_f64<i8A,rowdot>" if "Li1ELi1E" in name or "<1, 1>" in name else "k_gemm_f64<f64A,store>"
-            if k == "k_vara_i8" and "finish" in name:
+            if "k_vara_i8_finish" in name:
                 return "k_vara_i8_finish"
+            if "k_vara_f64_sum" in name:
+                return "k_vara_f64_sum"
+            if "k_vara_f64" in name:
+                return "k_vara_f64<split>" if ("Lb1E" in name or "<true>" in name) else "k_vara_f64"
             return k
     return None
 
