@@ -131,7 +131,9 @@ class Run:
         gen = torch.Generator(device=self.dev)
         gen.manual_seed(7)
         if self.rank == 0:
-            qtl = torch.linspace(0, sh.Lloc - 1, 12, device=self.dev).long()[1:-1]
+            # 10 QTL spread over the first eighth of the markers: inside rank 0's shard for every N <= 8, so that the trait, the
+            # operands and therefore the selected marker are the same whatever the number of GPUs
+            qtl = torch.linspace(0, max(1, self.Ltot // 8) - 1, 12, device=self.dev).long()[1:-1].clamp(max=sh.Lloc - 1)
             y = 0.5 * sh.Mt8[qtl, :n].double().sum(0) + torch.randn(n, generator=gen, device=self.dev, dtype=torch.float64)
             X = torch.ones((n, 1), dtype=torch.float64, device=self.dev)
             if args.load_operands:

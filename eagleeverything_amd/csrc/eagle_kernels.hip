@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_mmt_normalise(double* __restrict__ A, l
 #define GF_T 128
 #define GF_BK 16
 #define GF_LDB (GF_T + 4)   /* doubles per B row in LDS: 4*stride*8 mod 256 == 128 -> the 4 k-groups hit distinct banks */
-#define GF_LDA (GF_BK + 2)  /* doubles per A row in LDS */
+#define GF_LDA (GF_BK + 4)  /* doubles per A row in LDS (pitch 20: 51.2 -> 50.3 ms for W at n = 10,000 against pitch 18; 24 is 10 % slower) */
 
 template <int AMODE>
 struct GfStage {
@@ -191,7 +191,7 @@ __device__ __forceinline__ void gf_load(GfStage<AMODE>& s, const void* __restric
         if (t < 128) s.a8 = *(const i32x4*)(A + (long)t * lda + k0);
     }
 }
-template <int AMODE>
+template <int AMODE, int LDA = GF_LDA>
 __device__ __forceinline__ void gf_store(const GfStage<AMODE>& s, double* ldsA, double* ldsB, int t) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -204,7 +204,7 @@ __device__ __forceinline__ void gf_store(const GfStage<AMODE>& s, double* ldsA, 
         for (int i = 0; i < 4; i++) {
             int c = t + 256 * i;
             int row = c >> 3, cc = c & 7;
-            *(f64x2*)(ldsA + row * GF_LDA + cc * 2) = s.a[i];
+            *(f64x2*)(ldsA + row * LDA + cc * 2) = s.a[i];
         }
     } else {
         if (t < 128) *(i32x4*)((int8_t*)ldsA + t * 16) = s.a8;
@@ -212,7 +212,7 @@ __device__ __forceinline__ void gf_store(const GfStage<AMODE>& s, double* ldsA, 
 }
 // mlim: only the first mlim 16-row tiles of the wave's four are computed (the SPLIT vara kernel re-evaluates a handful of
 // rows; the MFMA sequence of a computed element is the same whatever mlim is)
-template <int AMODE>
+template <int AMODE, int LDA = GF_LDA>
 __device__ __forceinline__ void gf_compute(f64x4 (&acc)[4][4], const double* ldsA, const double* ldsB, int wr, int wc,
                                            int lane, int mlim = 4) {
     const int i16 = lane & 15, g = lane >> 4;
@@ -226,7 +226,7 @@ __device__ __forceinline__ void gf_compute(f64x4 (&acc)[4][4], const double* lds
         double a[4], b[4];
 #pragma unroll
         for (int m = 0; m < 4; m++) {
-            if (AMODE == 0) a[m] = ldsA[(wr * 64 + m * 16 + i16) * GF_LDA + 4 * g + s];
+            if (AMODE == 0) a[m] = ldsA[(wr * 64 + m * 16 + i16) * LDA + 4 * g + s];
             else a[m] = (double)((w4[m] << (24 - 8 * s)) >> 24);  // sign-extended byte s
         }
 #pragma unroll
@@ -240,7 +240,7 @@ __device__ __forceinline__ void gf_compute(f64x4 (&acc)[4][4], const double* lds
     }
 }
 
-// LDS bytes: A: 128*18*8 = 18432 (f64) ; B: 16*132*8 = 16896 ; x2 buffers
+// LDS bytes: A: 128*20*8 = 20480 (f64) ; B: 16*132*8 = 16896 ; x2 buffers (two workgroups per CU: 149.5 KiB)
 #define GF_LDSA_DOUBLES (GF_T * GF_LDA)
 #define GF_LDSB_DOUBLES (GF_BK * GF_LDB)
 
@@ -670,12 +670,16 @@ extern "C" int eagle_dev_add_i32(eagle_ctx* ctx, int32_t* dst, const int32_t* sr
 // skip_if / skip_val: the whole launch is dropped on the device when *skip_if == skip_val (the lower-triangle launch of
 // a product the symmetry check found symmetric).
 // ------------------------------------------------------------------------------------------------
+template <int LDA, int XCDMAP>
 __global__ __launch_bounds__(256, 2) void k_gemm_f64_list(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
                                                           double* __restrict__ C, long ldc, long K, const int* __restrict__ tiles, int n_main,
                                                           int split, double* __restrict__ scratch, const int* __restrict__ skip_if, int skip_val) {
-    __shared__ __attribute__((aligned(16))) double lds[2][GF_LDSA_DOUBLES + GF_LDSB_DOUBLES];
+    constexpr int LDSA = GF_T * LDA;
+    __shared__ __attribute__((aligned(16))) double lds[2][LDSA + GF_LDSB_DOUBLES];
     if (skip_if && *skip_if == skip_val) return;
-    const int b = blockIdx.x;
+    int b = blockIdx.x;
+    // XCDMAP: workgroup b runs on XCD b % 8 (observed dealing); give each XCD a contiguous range of the whole tiles of the list
+    if (XCDMAP && b < n_main) b = (b & 7) * (n_main >> 3) + (b >> 3);
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
     const int i16 = lane & 15, g = lane >> 4;
     const long nkb_all = K / GF_BK;
@@ -704,14 +708,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64_list(const double* __restri
         for (int n = 0; n < 4; n++) acc[m][n] = (f64x4){0.0, 0.0, 0.0, 0.0};
     GfStage<0> st;
     gf_load<0>(st, Ablk, lda, Bblk, ldb, kb0 * GF_BK, t);
-    gf_store<0>(st, lds[0], lds[0] + GF_LDSA_DOUBLES, t);
+    gf_store<0, LDA>(st, lds[0], lds[0] + LDSA, t);
     __syncthreads();
     int cur = 0;
     for (long kb = kb0; kb < kb1; kb++) {
         const bool more = kb + 1 < kb1;
         if (more) gf_load<0>(st, Ablk, lda, Bblk, ldb, (kb + 1) * GF_BK, t);
-        gf_compute<0>(acc, lds[cur], lds[cur] + GF_LDSA_DOUBLES, wr, wc, lane);
-        if (more) gf_store<0>(st, lds[cur ^ 1], lds[cur ^ 1] + GF_LDSA_DOUBLES, t);
+        gf_compute<0, LDA>(acc, lds[cur], lds[cur] + LDSA, wr, wc, lane);
+        if (more) gf_store<0, LDA>(st, lds[cur ^ 1], lds[cur ^ 1] + LDSA, t);
         __syncthreads();
         cur ^= 1;
     }
@@ -752,9 +756,17 @@ static int gemm_tile_list(eagle_ctx* ctx, int nt, int kind, int rt0, int rt1, co
     auto it = g_gemm_lists.find(key);
     if (it != g_gemm_lists.end()) { *out = it->second.first; *count = it->second.second; return EAGLE_OK; }
     std::vector<int> h;
+    const int base_kind = kind & 15;
+    if (kind & 16) {  // 8 x 8 super-tiles (experiment, tune 23 / 24): 64 consecutive entries share 8 row and 8 column panels
+        for (int si = rt0; si < rt1; si += 8)
+            for (int sj = 0; sj < nt; sj += 8)
+                for (int i = si; i < si + 8 && i < rt1; i++)
+                    for (int j = sj; j < sj + 8 && j < nt; j++)
+                        if (base_kind == 0 || (base_kind == 1 && i <= j) || (base_kind == 2 && i > j)) h.push_back((i << 16) | j);
+    } else
     for (int i = rt0; i < rt1; i++)   // row tile outer: consecutive workgroups share an A row panel (measured 4 % faster than column-major)
         for (int j = 0; j < nt; j++)
-            if (kind == 0 || (kind == 1 && i <= j) || (kind == 2 && i > j)) h.push_back((i << 16) | j);
+            if (base_kind == 0 || (base_kind == 1 && i <= j) || (base_kind == 2 && i > j)) h.push_back((i << 16) | j);
     int* d = nullptr;
     if (!h.empty()) {
         hipError_t e = hipMalloc((void**)&d, h.size() * sizeof(int));
@@ -774,7 +786,9 @@ static int gemm_f64_tiles(eagle_ctx* ctx, const double* A, const double* B, doub
     const int* tiles = nullptr;
     long count = 0;
     if (rt1 < 0) rt1 = (int)(np / GF_T);
-    int rc = gemm_tile_list(ctx, (int)(np / GF_T), kind, rt0, rt1, &tiles, &count);
+    const int tune = ctx->tune;
+    const bool super_tiles = tune == 23 || tune == 24;
+    int rc = gemm_tile_list(ctx, (int)(np / GF_T), kind | (super_tiles ? 16 : 0), rt0, rt1, &tiles, &count);
     if (rc || count == 0) return rc;
     const long slots = 2L * (ctx->cu_count > 0 ? ctx->cu_count : 256);  // resident workgroups (2 per CU)
     const long n_main = count / slots * slots, tail = count - n_main;
@@ -800,8 +814,16 @@ static int gemm_f64_tiles(eagle_ctx* ctx, const double* A, const double* B, doub
         scratch = (double*)ctx->gemm_scratch;
     }
     const long blocks = split > 1 ? n_main + tail * split : count;
-    hipLaunchKernelGGL(k_gemm_f64_list, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, A, np, B, np, C, np, np, tiles,
-                       (int)(split > 1 ? n_main : count), split, scratch, skip_if, skip_val);
+#define GEMM_LAUNCH(LDA_, X_) hipLaunchKernelGGL((k_gemm_f64_list<LDA_, X_>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, A, np, B, np, C, np, np, tiles, \
+                       (int)(split > 1 ? n_main : count), split, scratch, skip_if, skip_val)
+    switch (tune) {  // 21..24: schedule experiments of tools/bench_gemm.py (profiles/r02_gemm_ab.txt); anything else: the shipped form
+        case 21: GEMM_LAUNCH(18, 0); break;      // round 1's A pitch
+        case 22: GEMM_LAUNCH(24, 0); break;
+        case 23: GEMM_LAUNCH(GF_LDA, 1); break;  // XCD-contiguous 8 x 8 super-tile order: neutral
+        case 24: GEMM_LAUNCH(18, 1); break;
+        default: GEMM_LAUNCH(GF_LDA, 0);
+    }
+#undef GEMM_LAUNCH
     if (split > 1)
         hipLaunchKernelGGL(k_gemm_f64_tail, dim3((unsigned)(tail * 16)), dim3(256), 0, (hipStream_t)stream, scratch, tiles + n_main, split, C, np, skip_if,
                            skip_val);

@@ -158,17 +158,20 @@ class DeviceShard:
 
     # ---- genotype shard -------------------------------------------------------------------------
     def fill_synthetic(self, seed=20240601, chunk=8192):
-        """HWE genotypes generated on the device: p_j ~ U(0.05,0.5), g_ij ~ Bin(2,p_j)."""
+        """HWE genotypes generated on the device: p_j ~ U(0.05,0.5), g_ij ~ Bin(2,p_j).
+        The stream is keyed by the GLOBAL chunk of 8192 markers a marker belongs to, so a shard holds exactly the markers the
+        whole problem holds at those positions: the same data, MM^T and selected marker at every number of GPUs."""
         torch = self.torch
         gen = torch.Generator(device=self.dev)
-        for m0 in range(0, self.Lloc, chunk):
-            m1 = min(self.Lloc, m0 + chunk)
-            gen.manual_seed(int(seed) * 1000003 + (self.first + m0))
-            p = torch.rand((m1 - m0, 1), generator=gen, device=self.dev) * 0.45 + 0.05
-            u1 = torch.rand((m1 - m0, self.n), generator=gen, device=self.dev)
-            u2 = torch.rand((m1 - m0, self.n), generator=gen, device=self.dev)
+        g0 = (self.first // chunk) * chunk
+        for c0 in range(g0, self.first + self.Lloc, chunk):
+            gen.manual_seed(int(seed) * 1000003 + c0)
+            p = torch.rand((chunk, 1), generator=gen, device=self.dev) * 0.45 + 0.05
+            u1 = torch.rand((chunk, self.n), generator=gen, device=self.dev)
+            u2 = torch.rand((chunk, self.n), generator=gen, device=self.dev)
             g = (u1 < p).to(torch.int8) + (u2 < p).to(torch.int8) - 1
-            self.Mt8[m0:m1, : self.n] = g
+            lo, hi = max(c0, self.first), min(c0 + chunk, self.first + self.Lloc)
+            self.Mt8[lo - self.first:hi - self.first, : self.n] = g[lo - c0:hi - c0]
         self.M8 = None
 
     def load_Mt_ascii(self, path, max_mem_gb=8.0, threads=8):
