@@ -919,7 +919,7 @@ static size_t cert_idx_off() { return 256; }
 static size_t cert_rows_off() { return cert_idx_off() + (size_t)CERT_CAP * sizeof(long); }
 static size_t cert_part_off(long n_pad) { return (cert_rows_off() + (size_t)CERT_CAP * n_pad + 255) / 256 * 256; }
 extern "C" int64_t eagle_scan_certify_workspace_bytes(long n_pad) {
-    return (int64_t)(cert_part_off(n_pad) + (size_t)(CERT_CAP / 128) * (size_t)(n_pad / 128) * 256 * sizeof(double));
+    return (int64_t)(cert_part_off(n_pad) + (size_t)eagle_vara_f64_split_partial_doubles(CERT_CAP, n_pad) * sizeof(double));
 }
 // Phase 1: lower bound of the block's maximum tsq into the head of cert_ws (eagle_cert_info.lower_bound).
 extern "C" int eagle_dev_scan_certify_lb(eagle_ctx* ctx, long L, long L_pad, long n_pad, const int8_t* cshift, const int32_t* l1norm,

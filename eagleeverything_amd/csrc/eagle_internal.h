@@ -24,6 +24,7 @@ int eagle_dev_gemv3_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad
                        const double* x, double scale, double* out_a, double* out_d, double* out_x, void* stream);
 int eagle_dev_vara_f64_gated(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu, double* vara_out,
                              const int* run_if, void* stream);
+long eagle_vara_f64_split_partial_doubles(long rows_cap, long n_pad);
 int eagle_dev_vara_f64_split(eagle_ctx* ctx, const int8_t* rows8, long rows_cap, long n_pad, long ld, const double* Wu,
                              const int* count_dev, const long* dst_dev, double* partial, double* out, void* stream);
 long eagle_upper_tiles_count(long n_pad);  // int32 elements of the packed upper 256-tiles of an n_pad x n_pad matrix

@@ -247,16 +247,19 @@ __device__ __forceinline__ void gf_compute(f64x4 (&acc)[4][4], const double* lds
 // The fp64 vara kernel (calculate_a_and_vara_rcpp.cpp:103-112): vara_i = sum_k m_ik sum_{j<=k} m_ij Wu[j][k] for the 128 markers
 // of a row block, A = int8 genotypes converted in registers, B = Wu (upper triangular fold of W, so column tile ct only
 // needs k < (ct+1)*128).  The summation order is FIXED and is the definition of this library's fp64 result:
-//   s_ct(i, wc) = the row-dot of tile ct restricted to the 64 columns of wave column wc: per lane a 4-term chain over the
-//                 lane's columns, then a butterfly over the 16 lanes of the row;
-//   P_wc(i)     = ((s_0 + s_1) + s_2) + ... in ascending ct;        vara_i = P_0(i) + P_1(i).
-// SPLIT = false: one workgroup walks every column tile of its row block and keeps P in registers.
-// SPLIT = true : grid.y = column tile; the workgroup writes s_ct to partial[rb][ct][wc][128] and k_vara_f64_sum forms the same
-//                chain -- bitwise the same vara for a row, whichever form computed it and whatever rows share its block.
-//                That is what lets the digit-slice scan re-evaluate a handful of markers in fp64 on the whole chip
-//                (k_cert_*, eagle_i8mfma.hip) and promise the fp64-mode result for them.
+//   s_{ct,c}(i, wc) = the row-dot of column tile ct, restricted to the 64 columns of wave column wc, of the partial product over
+//                     the K chunk c = [2048 c, 2048 (c+1)): the MFMA chain over the chunk, then per lane a 4-term chain over
+//                     the lane's columns, then a butterfly over the 16 lanes of the row;
+//   P_wc(i)         = the s_{ct,c} added one by one, ct ascending, c ascending inside a tile;   vara_i = P_0(i) + P_1(i).
+// SPLIT = false: one workgroup walks every (column tile, chunk) of its row block and keeps P in registers.
+// SPLIT = true : grid.y = column tile, grid.z = chunk; the workgroup writes s_{ct,c} to partial[rb][ct][c][wc][128] and
+//                k_vara_f64_sum forms the same chain -- bitwise the same vara for a row, whichever form computed it and
+//                whatever rows share its block.  That is what lets the digit-slice scan re-evaluate a handful of markers in
+//                fp64 on the whole chip (k_cert_*, eagle_i8mfma.hip: the longest workgroup is one 2048-deep chunk, 0.3 ms,
+//                instead of a 10240-deep tile) and promise the fp64-mode result for them.
 // gate (may be NULL): SPLIT = false -> the launch is dropped unless *gate != 0; SPLIT = true -> row blocks at or beyond
 // *gate rows are dropped.
+#define GF_KC 2048  /* K chunk of the canonical summation order */
 template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void k_vara_f64(const int8_t* __restrict__ A8, long lda, const double* __restrict__ B, long ldb,
                                                      double* __restrict__ out, int n_coltiles, long K, const int* __restrict__ gate,
@@ -277,6 +280,7 @@ __global__ __launch_bounds__(256, 2) void k_vara_f64(const int8_t* __restrict__ 
         mlim = left <= 0 ? 0 : (left >= 64 ? 4 : (int)((left + 15) >> 4));
         mlim = __builtin_amdgcn_readfirstlane(mlim);
     }
+    const int nchunk_max = (int)((K + GF_KC - 1) / GF_KC);
     double P[4][4];
 #pragma unroll
     for (int m = 0; m < 4; m++)
@@ -287,47 +291,54 @@ __global__ __launch_bounds__(256, 2) void k_vara_f64(const int8_t* __restrict__ 
     for (int ct = ct0; ct < ct1; ct++) {
         const double* Bblk = B + (long)ct * GF_T;
         const long kend = (long)(ct + 1) * GF_T < K ? (long)(ct + 1) * GF_T : K;
-        const long nkb = kend / GF_BK;
-        f64x4 acc[4][4];
+        const int c0 = SPLIT ? (int)blockIdx.z : 0;
+        const int c1 = SPLIT ? (int)blockIdx.z + 1 : nchunk_max;
+        for (int c = c0; c < c1; c++) {
+            const long kc0 = (long)c * GF_KC;
+            if (kc0 >= kend) break;
+            const long kc1 = kc0 + GF_KC < kend ? kc0 + GF_KC : kend;
+            const long nkb = (kc1 - kc0) / GF_BK;
+            f64x4 acc[4][4];
 #pragma unroll
-        for (int m = 0; m < 4; m++)
+            for (int m = 0; m < 4; m++)
 #pragma unroll
-            for (int n = 0; n < 4; n++) acc[m][n] = (f64x4){0.0, 0.0, 0.0, 0.0};
-        GfStage<1> st;
-        gf_load<1>(st, Ablk, lda, Bblk, ldb, 0, t);
-        __syncthreads();  // previous column tile's readers are done with buffer 0
-        gf_store<1>(st, lds[0], lds[0] + GF_LDSA_DOUBLES, t);
-        __syncthreads();
-        int cur = 0;
-        for (long kb = 0; kb < nkb; kb++) {
-            const bool more = kb + 1 < nkb;
-            if (more) gf_load<1>(st, Ablk, lda, Bblk, ldb, (kb + 1) * GF_BK, t);
-            gf_compute<1>(acc, lds[cur], lds[cur] + GF_LDSA_DOUBLES, wr, wc, lane, mlim);
-            if (more) gf_store<1>(st, lds[cur ^ 1], lds[cur ^ 1] + GF_LDSA_DOUBLES, t);
+                for (int n = 0; n < 4; n++) acc[m][n] = (f64x4){0.0, 0.0, 0.0, 0.0};
+            GfStage<1> st;
+            gf_load<1>(st, Ablk, lda, Bblk, ldb, kc0, t);
+            __syncthreads();  // the previous chunk's readers are done with buffer 0
+            gf_store<1>(st, lds[0], lds[0] + GF_LDSA_DOUBLES, t);
             __syncthreads();
-            cur ^= 1;
-        }
-        // C/D map of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
-#pragma unroll
-        for (int m = 0; m < 4; m++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const long r = row0 + wr * 64 + m * 16 + g + 4 * q;
-                const int8_t* mr = A8 + r * lda + (long)ct * GF_T + wc * 64 + i16;
-                double s = 0.0;
-#pragma unroll
-                for (int n = 0; n < 4; n++) s += acc[m][n][q] * (double)mr[n * 16];
-                s += __shfl_xor(s, 1);
-                s += __shfl_xor(s, 2);
-                s += __shfl_xor(s, 4);
-                s += __shfl_xor(s, 8);
-                if (SPLIT) {
-                    if (i16 == 0)
-                        partial[(((long)blockIdx.x * n_coltiles + ct) * 2 + wc) * GF_T + wr * 64 + m * 16 + g + 4 * q] = s;
-                } else {
-                    P[m][q] += s;
-                }
+            int cur = 0;
+            for (long kb = 0; kb < nkb; kb++) {
+                const bool more = kb + 1 < nkb;
+                if (more) gf_load<1>(st, Ablk, lda, Bblk, ldb, kc0 + (kb + 1) * GF_BK, t);
+                gf_compute<1>(acc, lds[cur], lds[cur] + GF_LDSA_DOUBLES, wr, wc, lane, mlim);
+                if (more) gf_store<1>(st, lds[cur ^ 1], lds[cur ^ 1] + GF_LDSA_DOUBLES, t);
+                __syncthreads();
+                cur ^= 1;
             }
+            // C/D map of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const long r = row0 + wr * 64 + m * 16 + g + 4 * q;
+                    const int8_t* mr = A8 + r * lda + (long)ct * GF_T + wc * 64 + i16;
+                    double s = 0.0;
+#pragma unroll
+                    for (int n = 0; n < 4; n++) s += acc[m][n][q] * (double)mr[n * 16];
+                    s += __shfl_xor(s, 1);
+                    s += __shfl_xor(s, 2);
+                    s += __shfl_xor(s, 4);
+                    s += __shfl_xor(s, 8);
+                    if (SPLIT) {
+                        if (i16 == 0)
+                            partial[((((long)blockIdx.x * n_coltiles + ct) * nchunk_max + c) * 2 + wc) * GF_T + wr * 64 + m * 16 + g + 4 * q] = s;
+                    } else {
+                        P[m][q] += s;
+                    }
+                }
+        }
     }
     if (!SPLIT) {
         __syncthreads();
@@ -342,16 +353,20 @@ __global__ __launch_bounds__(256, 2) void k_vara_f64(const int8_t* __restrict__ 
         if (t < 128) out[row0 + t] = red[t] + red[128 + t];
     }
 }
-// vara of the rows of the SPLIT form: out[dst ? dst[r] : r] = P_0 + P_1, P_wc the ascending-ct chain of the partial sums.
-__global__ __launch_bounds__(128) void k_vara_f64_sum(const double* __restrict__ partial, int n_coltiles, const int* __restrict__ count,
+// vara of the rows of the SPLIT form: out[dst ? dst[r] : r] = P_0 + P_1, P_wc the chain of the partial sums in the order above.
+__global__ __launch_bounds__(128) void k_vara_f64_sum(const double* __restrict__ partial, int n_coltiles, long K, const int* __restrict__ count,
                                                       const long* __restrict__ dst, double* __restrict__ out) {
     const long r = (long)blockIdx.x * GF_T + threadIdx.x;
     if (count && r >= (long)*count) return;
-    const double* p = partial + (long)blockIdx.x * n_coltiles * 2 * GF_T + threadIdx.x;
+    const int nchunk_max = (int)((K + GF_KC - 1) / GF_KC);
+    const double* p = partial + (long)blockIdx.x * n_coltiles * nchunk_max * 2 * GF_T + threadIdx.x;
     double P0 = 0.0, P1 = 0.0;
     for (int ct = 0; ct < n_coltiles; ct++) {
-        P0 += p[((long)ct * 2 + 0) * GF_T];
-        P1 += p[((long)ct * 2 + 1) * GF_T];
+        const long kend = (long)(ct + 1) * GF_T < K ? (long)(ct + 1) * GF_T : K;
+        for (int c = 0; c < nchunk_max && (long)c * GF_KC < kend; c++) {
+            P0 += p[(((long)ct * nchunk_max + c) * 2 + 0) * GF_T];
+            P1 += p[(((long)ct * nchunk_max + c) * 2 + 1) * GF_T];
+        }
     }
     out[dst ? dst[r] : r] = P0 + P1;
 }
@@ -1111,18 +1126,21 @@ extern "C" int eagle_dev_vara_f64_gated(eagle_ctx* ctx, const int8_t* Mt8, long 
     return EAGLE_OK;
 }
 // The same values for the first *count_dev rows (count <= rows_cap, a multiple of 128) of a compact row buffer, with the
-// column tiles spread over the chip (a few rows would otherwise sit on one CU): partial needs
-// rows_cap/128 * n_pad/128 * 256 doubles.  Results go to out[dst_dev[r]] (dst_dev == NULL: out[r]).
+// (column tile, K chunk) pairs spread over the chip (a few rows would otherwise sit on one CU): partial needs
+// eagle_vara_f64_split_partial_doubles(rows_cap, n_pad) doubles.  Results go to out[dst_dev[r]] (dst_dev == NULL: out[r]).
+extern "C" long eagle_vara_f64_split_partial_doubles(long rows_cap, long n_pad) {
+    return (rows_cap / GF_T) * (n_pad / GF_T) * ((n_pad + GF_KC - 1) / GF_KC) * 2 * GF_T;
+}
 extern "C" int eagle_dev_vara_f64_split(eagle_ctx* ctx, const int8_t* rows8, long rows_cap, long n_pad, long ld, const double* Wu,
                                         const int* count_dev, const long* dst_dev, double* partial, double* out, void* stream) {
     if (rows_cap % GF_T || n_pad % GF_T || ld % 16 || n_pad > ld || n_pad / GF_T > 65535)
         return eagle_fail(ctx, EAGLE_ERR_ARG, "vara_f64_split: layout contract violated");
     if (rows_cap == 0) return EAGLE_OK;
     const int nct = (int)(n_pad / GF_T);
-    dim3 grid((unsigned)(rows_cap / GF_T), (unsigned)nct);
+    dim3 grid((unsigned)(rows_cap / GF_T), (unsigned)nct, (unsigned)((n_pad + GF_KC - 1) / GF_KC));
     hipLaunchKernelGGL((k_vara_f64<true>), grid, dim3(256), 0, (hipStream_t)stream, rows8, ld, Wu, n_pad, (double*)nullptr, nct, n_pad, count_dev,
                        partial);
-    hipLaunchKernelGGL(k_vara_f64_sum, dim3((unsigned)(rows_cap / GF_T)), dim3(GF_T), 0, (hipStream_t)stream, partial, nct, count_dev, dst_dev, out);
+    hipLaunchKernelGGL(k_vara_f64_sum, dim3((unsigned)(rows_cap / GF_T)), dim3(GF_T), 0, (hipStream_t)stream, partial, nct, n_pad, count_dev, dst_dev, out);
     LAUNCH_CHECK(ctx);
     return EAGLE_OK;
 }

@@ -50,7 +50,8 @@ class Collectives:
         """In-place sum of the int32 partial MM^T tensors of all ranks (exact).  Only the 256 x 256 tiles on or above the
         diagonal are live (the kernels never write the others), so only those travel: half the bytes of the matrix.
         dst = None: all-reduce (every rank holds the sum); dst = r: reduce to rank r only -- MM^T goes back to ONE host
-        process (calculateMMt_rcpp returns it to R), so the other ranks need not receive it: half the link traffic."""
+        process (calculateMMt_rcpp returns it to R), so the other ranks need not receive it: half the link traffic; their
+        tensors are unspecified afterwards."""
         if self.world > 1:
             np_ = c32.shape[0]
             if dst is None:

@@ -63,6 +63,22 @@ def _worker(rank, world, port, case, out_dir):
         got = big.numpy().astype(np.int64)
         assert np.array_equal(got[:256, :], exp[:256, :]) and np.array_equal(got[256:, 256:], exp[256:, 256:])
         assert np.all(got[256:, :256] == -7 - rank)
+        # reduce to ONE rank (what bench.py does: only the process that hands MM^T to the host algebra needs the sum): rank 0
+        # holds the sum (what the other ranks' buffers hold afterwards is unspecified, as with any reduce)
+        for shape in ("plain", "tiled"):
+            if shape == "plain":
+                t = torch.from_numpy(part.copy())
+                mine = part.astype(np.int64)
+                want = g["MMt"]
+            else:
+                t = torch.zeros((512, 512), dtype=torch.int32)
+                t[:n, :n] = torch.from_numpy(part.copy())
+                mine = t.numpy().astype(np.int64).copy()
+                want = exp
+            coll.sum_partial_mmt(t, dst=0)
+            got = t.numpy().astype(np.int64)
+            if rank == 0:
+                assert np.array_equal(got[:256, :], want[:256, :]) if shape == "tiled" else np.array_equal(got, want)
         # shared W: every rank computes its row block of S V S, one all-gather completes the image
         W = g["S"] @ (g["V"] @ g["S"])
         rows = 64
