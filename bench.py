@@ -63,7 +63,7 @@ def host_operands_torch(torch, MMt_norm, X, y, varE, varG):
     D1 = torch.cholesky_inverse(torch.linalg.cholesky(r1 * (sq.T @ sq) + g1 * I))  # D is SPD
     D1C = D1 @ B.T
     V = varG * I - (D1 + D1C @ torch.linalg.solve(A - B @ D1C, B @ D1))
-    return S, V, ahat
+    return S, V, ahat, P
 
 
 class Run:
@@ -84,6 +84,7 @@ class Run:
         torch.cuda.synchronize(self.dev)
         self.t_gen = time.time() - t0
         self.S = self.V = self.ahat = None
+        self.W_direct = self.v_direct = None
 
     # ---- collectives-aware helpers ----------------------------------------------------------------
     def barrier(self):
@@ -144,7 +145,8 @@ class Run:
                 V = 0.5 * torch.eye(n, dtype=torch.float64, device=self.dev) - 0.01 * (A[:, :8] @ A[:, :8].T)
                 ahat = torch.randn(n, generator=gen, device=self.dev, dtype=torch.float64)
             else:
-                S, V, ahat = host_operands_torch(torch, MMt, X, y, 1.0, 0.5)
+                S, V, ahat, P = host_operands_torch(torch, MMt, X, y, 1.0, 0.5)
+                self.W_direct, self.v_direct = 0.25 * P, 0.5 * (P @ y)  # varG^2 P and varG P y: what eagle_scan_with_W takes
         else:
             S = torch.empty((n, n), dtype=torch.float64, device=self.dev)
             V = torch.empty((n, n), dtype=torch.float64, device=self.dev)
@@ -422,6 +424,15 @@ def main():
                                                  "note": "opt-in: per-marker error bound 8.355*q2*2^(e+1-8S) holds with probability 1 - 1e-30",
                                                  "roofline": vara_roofline(sh, pr["kern"], Sr)}
         sh.stochastic = False
+        # optional R-side shortcut eagle_scan_with_W: W = varG^2 P and v = varG P y handed over, no S (V S) products
+        if run.W_direct is not None:
+            sh.set_W(run.W_direct, run.v_direct)
+            sw, elw, pw = run.timed(3, 1)
+            secondary["scan_with_W_handed_over"] = {"value": Ltot * 3 / elw, "unit": "markers/s", "ms_per_step": elw / 3 * 1e3,
+                                                    "selected_marker_equal": bool(sw[0] == sel_i8[0]),
+                                                    "note": "eagle_scan_with_W: inside AM() W = S V S equals varG^2 P, which find_qtl.R already holds; "
+                                                            "not a .Call of the reference (INTEGRATION.md)"}
+            sh.W0 = sh.v0 = None
         # BASELINE configs[1]: 5,000 x 500,000 on one card
         del run, sh
         torch.cuda.empty_cache()

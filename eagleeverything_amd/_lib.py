@@ -41,6 +41,7 @@ SIGNATURES = {
     "eagle_calculateMMt": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double, C.c_int, c_dp, C.c_long, c_lp, C.c_int, c_dp]),
     "eagle_calculate_a_and_vara": (C.c_int, [C.c_void_p, C.c_char_p, c_dp, C.c_long, c_dp, c_dp, C.c_double, c_lp, c_dp,
                                              C.c_int, c_dp, c_dp]),
+    "eagle_scan_with_W": (C.c_int, [C.c_void_p, C.c_char_p, c_dp, C.c_long, c_dp, c_dp, C.c_double, c_lp, C.c_int, c_dp, c_dp]),
     "eagle_calculate_reduced_a": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double, c_dp, c_dp, C.c_double, c_lp, c_dp,
                                             C.c_long, C.c_int, c_dp]),
     "eagle_extract_geno": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double, C.c_long, c_lp, C.POINTER(C.c_int)]),

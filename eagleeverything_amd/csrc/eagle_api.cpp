@@ -965,13 +965,14 @@ static int ensure_scan_out(eagle_ctx* ctx, long L_pad) {
 // (NULL for one device).  Every device passes the same rendezvous in the same order, failed or not.
 static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, long m0, long m1, const std::vector<long>& sel,
                       const double* inv_MMt_sqrt, const double* dim_reduced_vara, const double* a, double max_memory_in_Gbytes, int quiet,
-                      double* a_out, double* vara_out, int k, int nd, Rendezvous* rv, RcclState* rccl) {
+                      double* a_out, double* vara_out, int k, int nd, Rendezvous* rv, RcclState* rccl, bool w_direct = false) {
+    // w_direct (eagle_scan_with_W): inv_MMt_sqrt is not S but W itself, `a` is v = S a_hat; dim_reduced_vara is unused
     const long Lr = m1 - m0;
     const long np = eagle_pad(n), Lp = eagle_pad(Lr > 0 ? Lr : 1);
     const size_t sq = sizeof(double) * (size_t)np * np;
     const bool use_i8 = ctx->scan_mode == 1 && 64.0 * 512.0 * (double)np < 2147483648.0;
     const int nslices = ctx->scan_slices | (ctx->scan_stochastic ? EAGLE_SLICES_STOCHASTIC : 0);
-    const bool share_w = nd > 1 && rccl && (np / 128) % nd == 0;  // the same answer on every device
+    const bool share_w = !w_direct && nd > 1 && rccl && (np / 128) % nd == 0;  // the same answer on every device
     int rc = EAGLE_OK;
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) rc = eagle_fail_hip(ctx, e, "hipSetDevice");
@@ -1028,9 +1029,14 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
                 l1s[b] = arena_take<int32_t>(ctx, 2 * sizeof(int32_t) * (size_t)Lc);
             }
         }
-        if ((r = upload_square(ctx, inv_MMt_sqrt, n, np, Sa))) return r;
-        if ((r = upload_square(ctx, dim_reduced_vara, n, np, Va))) return r;
-        if ((r = upload_vec(ctx, a, n, np, ah))) return r;
+        if (w_direct) {  // W and v arrive ready: no n^3 work, W goes straight into the buffer the fold works on
+            if ((r = upload_square(ctx, inv_MMt_sqrt, n, np, Wu))) return r;
+            if ((r = upload_vec(ctx, a, n, np, v))) return r;
+        } else {
+            if ((r = upload_square(ctx, inv_MMt_sqrt, n, np, Sa))) return r;
+            if ((r = upload_square(ctx, dim_reduced_vara, n, np, Va))) return r;
+            if ((r = upload_vec(ctx, a, n, np, ah))) return r;
+        }
         if ((r = ensure_scan_out(ctx, Lp))) return r;
         HIPCHK(ctx, hipMemsetAsync(cert_totals, 0, 3 * sizeof(long), ctx->stream));
         return EAGLE_OK;
@@ -1049,7 +1055,7 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
         if (nr != ncclSuccess) rc = failf(ctx, EAGLE_ERR_HIP, "ncclAllGather: %s", rccl->GetErrorString(nr));
         if (!rc) rc = eagle_dev_fold_upper(ctx, Wu, np, ctx->stream);
     } else if (!rc) {
-        rc = eagle_dev_scan_operands(ctx, Sa, Va, ah, n, np, v, Wu, tmp, ctx->stream);
+        rc = w_direct ? eagle_dev_fold_upper(ctx, Wu, np, ctx->stream) : eagle_dev_scan_operands(ctx, Sa, Va, ah, n, np, v, Wu, tmp, ctx->stream);
     }
     if (!rc && streamed && !quiet) say(ctx, " Mt.ascii streamed through HBM in blocks of %ld markers", Lc);
     // one pass per marker block: the whole shard when it is resident, else chunks read back from the file
@@ -1192,6 +1198,36 @@ extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_asc
     rc = run_on_devices(ctx, [&](int k, eagle_ctx* c) -> int {
         return scan_range(c, f_name_ascii, L, n, edge[k], edge[k + 1], sel, inv_MMt_sqrt, dim_reduced_vara, a, max_memory_in_Gbytes, quiet,
                           a_out, vara_out, k, nd, nd > 1 ? &rv : nullptr, rccl);
+    });
+    if (rc) return rc;
+    for (eagle_ctx* p : ctx->peers) {
+        ctx->cert_reevaluated += p->cert_reevaluated; ctx->cert_flagged += p->cert_flagged; ctx->cert_fell_back |= p->cert_fell_back;
+    }
+    return EAGLE_OK;
+}
+
+// Optional shortcut for the R side (not one of the reference's .Call symbols): the same scan with W = S V S and v = S a_hat
+// handed over ready-made.  Inside AM() they need no n^3 product at all: dim_reduced_vara is Henderson's varG I - C22 =
+// varG^2 Ze P Ze with Ze = MMt^1/2 (E/R/calculate_reduced_vara.R:21-35) and inv_MMt_sqrt = Ze^-1, so W = varG^2 P and
+// v = S (varG Ze P y) = varG P y (E/R/calculate_reduced_a.R:31) -- and .find_qtl holds P (find_qtl.R:9).  The reference-shaped
+// entry point cannot know that (it receives opaque matrices) and spends 24 % of a scan at n = 10,000 on S (V S).
+extern "C" int eagle_scan_with_W(eagle_ctx* ctx, const char* f_name_ascii, const double* selected_loci, long n_selected, const double* W,
+                                 const double* v, double max_memory_in_Gbytes, const long dims[2], int quiet, double* a_out, double* vara_out) {
+    if (!ctx) return EAGLE_ERR_ARG;
+    const long L = dims[0], n = dims[1];
+    if (n <= 0 || L <= 0 || !W || !v) return eagle_fail(ctx, EAGLE_ERR_ARG, "bad dims / null operand");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<long> sel;
+    int rc = parse_selected(ctx, selected_loci, n_selected, L, sel);
+    if (rc) return rc;
+    const int nd = ndev_of(ctx);
+    std::vector<long> edge;
+    split_markers(L, nd, edge);
+    Rendezvous rv;
+    rv.n = nd;
+    rc = run_on_devices(ctx, [&](int k, eagle_ctx* c) -> int {
+        return scan_range(c, f_name_ascii, L, n, edge[k], edge[k + 1], sel, W, nullptr, v, max_memory_in_Gbytes, quiet, a_out, vara_out, k, nd,
+                          nd > 1 ? &rv : nullptr, nullptr, true);
     });
     if (rc) return rc;
     for (eagle_ctx* p : ctx->peers) {

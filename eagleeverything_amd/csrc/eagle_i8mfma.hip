@@ -685,14 +685,25 @@ __device__ __forceinline__ void tw_stage(__amdgpu_buffer_rsrc_t rs, const T8Lane
     }
 }
 __global__ __launch_bounds__(512, 2) void k_vara_i8w(const int8_t* __restrict__ Mt8, long ld, int ntm, const int8_t* __restrict__ Bs,
-                                                     long np, const VaraHdr* __restrict__ hdr, long long* __restrict__ q, long Lp) {
+                                                     long np, const VaraHdr* __restrict__ hdr, long long* __restrict__ q, long Lp, int cut_last_round) {
     extern __shared__ __attribute__((aligned(1024))) int8_t ldsv[];  // [2][A 48 KiB | B 32 KiB]
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
     const int nslices = hdr->S;
-    const int mt = (slot / nslices) * 8 + xcd, sl = slot % nslices;
-    if (mt >= ntm) return;
     const int nct = (int)(np / T8), npair = (nct + 1) / 2;
+    // Work per XCD: its marker tiles (mt = 8 g + xcd) x the S slices = `wx` workers on 32 CUs.  The workers of the last, partly
+    // filled round are cut into `psplit` pieces along their column-tile pairs when that round is less than half full, so that
+    // it costs 1/psplit of a worker instead of a whole one (a 125,000-marker shard -- the headline problem on 8 GPUs -- is
+    // 5.1 rounds: 6 worker-times without the cut, 5.2 with it).  Integer atomics into q: the result does not change.
+    const int groups = (ntm + 7) >> 3, wx = groups * nslices, full = (wx >> 5) << 5, tail = wx - full;
+    int psplit = 1;
+    if (cut_last_round && tail > 0 && tail <= 16) { psplit = 32 / tail; if (psplit > npair) psplit = npair; }
+    int worker = slot, piece = 0;
+    if (slot >= full) { const int u = slot - full; worker = full + u / psplit; piece = u - (u / psplit) * psplit; }
+    if (worker >= wx) return;
+    const int mt = (worker / nslices) * 8 + xcd, sl = worker - (worker / nslices) * nslices;
+    if (mt >= ntm) return;
+    const int pair0 = npair * piece / psplit, pair1 = npair * (piece + 1) / psplit;
     const int8_t* Bsl = Bs + (long)sl * np * np;
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -704,7 +715,7 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8w(const int8_t* __restrict__ 
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(Mt8 + row0 * ld), 0, (int)(rows_here * ld), 0x00020000);
 
     VaraIt cur, nxt;
-    cur.p = 0; cur.half = 0; vit_set_tile(cur, nct, npair);
+    cur.p = pair0; cur.half = 0; vit_set_tile(cur, nct, pair1);
     if (!cur.valid) return;
     nxt = cur;
     i32x16 acc[3][4];
@@ -726,7 +737,7 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8w(const int8_t* __restrict__ 
 
     tw_stage<6>(rsA, lnA, ldi, nxt.kt * BK8, ldsv, w);
     tw_stage<4>(t8_rsrc(Bsl + (long)nxt.ct * T8 * np, npi), lnB, npi, nxt.kt * BK8, ldsv + TW_ABYTES, w);
-    vit_advance(nxt, nct, npair);
+    vit_advance(nxt, nct, pair1);
     __syncthreads();
     int buf = 0;
     while (cur.valid) {
@@ -735,7 +746,7 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8w(const int8_t* __restrict__ 
             int8_t* nx = ldsv + (buf ^ 1) * (TW_ABYTES + TILE_BYTES);
             tw_stage<6>(rsA, lnA, ldi, nxt.kt * BK8, nx, w);
             tw_stage<4>(t8_rsrc(Bsl + (long)nxt.ct * T8 * np, npi), lnB, npi, nxt.kt * BK8, nx + TW_ABYTES, w);
-            vit_advance(nxt, nct, npair);
+            vit_advance(nxt, nct, pair1);
         }
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) tw_kstep(acc, st + offA, st + offB, ch[ks]);
@@ -768,7 +779,7 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8w(const int8_t* __restrict__ 
                 keep[m] += v1;
                 __builtin_amdgcn_sched_barrier(0);
             }
-            vit_advance(cur, nct, npair);
+            vit_advance(cur, nct, pair1);
         } else {
             cur.kt++;
         }
@@ -1077,7 +1088,9 @@ extern "C" int eagle_dev_vara_i8_mfma_shifted(eagle_ctx* ctx, const int8_t* Mt8s
             ctx->attr_vara_i8w = true;
         }
         const int ntw = (int)((L_pad + TW_M - 1) / TW_M), gw = (ntw + 7) / 8;
-        hipLaunchKernelGGL(k_vara_i8w, dim3((unsigned)(gw * 8 * smax)), dim3(512), 2 * (TW_ABYTES + TILE_BYTES), s, Mt8s, ld, ntw, Bs, n_pad, hdr, q, L_pad);
+        // per XCD at most gw * smax workers, plus at most 32 more blocks when the last round is cut into pieces
+        hipLaunchKernelGGL(k_vara_i8w, dim3((unsigned)(8 * (gw * smax + 32))), dim3(512), 2 * (TW_ABYTES + TILE_BYTES), s, Mt8s, ld, ntw, Bs, n_pad, hdr, q, L_pad,
+                           ctx->tune == 7 ? 0 : 1);  // tune 7: A/B switch of tools/bench_vara.py (whole workers in the last round)
     } else
     hipLaunchKernelGGL(k_vara_i8, dim3((unsigned)(groups * 8 * smax)), dim3(512), 5 * TILE_BYTES, s, Mt8s, ld, ntm, Bs, n_pad, hdr, q, L_pad);
     hipLaunchKernelGGL(k_vara_i8_finish, dim3((unsigned)((L_pad + 255) / 256)), dim3(256), 0, s, q, L_pad, hdr, vdiag, cshift, mrho, vara_out);

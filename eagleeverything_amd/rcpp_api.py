@@ -163,6 +163,25 @@ def calculate_a_and_vara_rcpp(f_name_ascii, selected_loci, inv_MMt_sqrt, dim_red
     return {"a": a_out.reshape(Lm, 1), "vara": v_out.reshape(Lm, 1)}
 
 
+def scan_with_W(f_name_ascii, selected_loci, W, v, max_memory_in_Gbytes, dims, quiet=True, message=None, device=0):
+    """eagle_scan_with_W: the scan of calculate_a_and_vara_rcpp with W = S V S and v = S a_hat ready-made (inside AM():
+    W = varG^2 P, v = varG P y; no n^3 product).  Not a symbol of the reference; an R-side shortcut."""
+    L = _lib.load()
+    ctx = context(device)
+    _set_message(ctx, message)
+    Lm, n = int(dims[0]), int(dims[1])
+    Wm = _f64F(W)
+    vv = _f64F(np.ravel(v))
+    if Wm.shape != (n, n) or vv.size != n:
+        raise ValueError("W must be n x n and v of length n")
+    s, sp, ns = _sel(selected_loci)
+    a_out = np.zeros(Lm)
+    v_out = np.zeros(Lm)
+    _check(ctx, L.eagle_scan_with_W(ctx, os.fsencode(f_name_ascii), sp, ns, _dp(Wm), _dp(vv), float(max_memory_in_Gbytes), _dims(dims),
+                                    int(bool(quiet)), _dp(a_out), _dp(v_out)))
+    return {"a": a_out.reshape(Lm, 1), "vara": v_out.reshape(Lm, 1)}
+
+
 def calculate_reduced_a_rcpp(f_name_ascii, varG, P, y, max_memory_in_Gbytes, dims, selected_loci, quiet=True,
                              message=None, device=0):
     L = _lib.load()

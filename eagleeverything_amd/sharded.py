@@ -137,6 +137,7 @@ class DeviceShard:
         self._scratch = torch.zeros(3 * 1024, dtype=torch.float64, device=self.dev)
         self._best = torch.zeros(3, dtype=torch.int64, device=self.dev)  # eagle_best: {f64, i64, i64}
         self.Sa = self.Va = self.ahat = self.v = self.Wu = self.tmp = None
+        self.W0 = self.v0 = None
         self.ws = None
         self._ws_mode = None
         self.Mt4 = None
@@ -248,9 +249,23 @@ class DeviceShard:
             self.Wu = torch.zeros((np_, np_), dtype=torch.float64, device=self.dev)
             self.tmp = torch.zeros((np_, np_), dtype=torch.float64, device=self.dev)
 
+    def set_W(self, W, v):
+        """eagle_scan_with_W's operands: W = S V S (n x n, any layout, as a MATRIX) and v = S a_hat handed over ready-made
+        (inside AM(): varG^2 P and varG P y); scan_operands() then only folds W instead of forming two n^3 products."""
+        torch = self.torch
+        n, np_ = self.n, self.np_
+        self.W0 = torch.zeros((np_, np_), dtype=torch.float64, device=self.dev)
+        self.W0[:n, :n] = torch.as_tensor(W, dtype=torch.float64, device=self.dev).t()
+        if self.v is None:
+            self.v = torch.zeros(np_, dtype=torch.float64, device=self.dev)
+            self.Wu = torch.zeros((np_, np_), dtype=torch.float64, device=self.dev)
+        self.v.zero_()
+        self.v[:n] = torch.as_tensor(v, dtype=torch.float64, device=self.dev).reshape(-1)
+        self.v0 = self.v.clone()
+
     def release_operands(self):
         """Drop the n x n operand images and the vara workspace (a and vara of the last scan stay)."""
-        self.Sa = self.Va = self.ahat = self.v = self.Wu = self.tmp = None
+        self.Sa = self.Va = self.ahat = self.v = self.Wu = self.tmp = self.W0 = self.v0 = None
         self.ws = None
         self.torch.cuda.empty_cache()
 
@@ -258,6 +273,11 @@ class DeviceShard:
         """v = S a_hat and Wu = fold(S V S).  With a Collectives of world > 1 whose size divides the 128-row tiles of W, the
         n^3 work is shared: every rank computes its row block of the W^T image, one all-gather completes it (the
         replicated computation is the fallback)."""
+        if getattr(self, "W0", None) is not None:  # W and v were handed over (set_W): copy + fold, no product
+            self.Wu.copy_(self.W0)
+            self.v.copy_(self.v0)
+            self._check(self.L.eagle_dev_fold_upper(self.ctx, self.Wu.data_ptr(), self.np_, self._stream()))
+            return
         world = coll.world if coll is not None else 1
         nt = self.np_ // 128
         if world > 1 and nt % world == 0 and self.share_w:

@@ -204,6 +204,14 @@ int eagle_matmul(eagle_ctx* ctx, const double* A, const double* B, long m, long 
  * compares with nrow(MMt) (:35-46; may be NULL). */
 int eagle_mmt_sqrt_and_sqrtinv(eagle_ctx* ctx, const double* MMt, long n, double* sqrt_out, double* invsqrt_out, double* trace_out);
 
+/* Optional shortcut (NOT one of the reference's .Call symbols; a maintainer who edits find_qtl.R may use it): the scan of
+ * eagle_calculate_a_and_vara with W = S V S (n x n) and v = S a_hat (n) handed over ready-made.  Inside AM() neither needs an
+ * n^3 product: dim_reduced_vara = varG I - C22 = varG^2 Ze P Ze with Ze = MMt^1/2 (E/R/calculate_reduced_vara.R:21-35),
+ * inv_MMt_sqrt = Ze^-1, hence W = varG^2 P and v = varG P y, and .find_qtl holds P (E/R/find_qtl.R:9, calculateP.R:27-28).
+ * Same outputs, sentinel-free (no availmemGb branch rules: those belong to the reference-shaped call). */
+int eagle_scan_with_W(eagle_ctx* ctx, const char* f_name_ascii, const double* selected_loci, long n_selected, const double* W,
+                      const double* v, double max_memory_in_Gbytes, const long dims[2], int quiet, double* a_out, double* vara_out);
+
 /* Replaces the R tail of .find_qtl:  tsq <- a^2/vara ; which(tsq == max(tsq, na.rm=TRUE))[1]
  *                                                E/R/find_qtl.R:71-83
  * Evaluated on the device on the a / vara of the LAST eagle_calculate_a_and_vara call of this ctx (still in

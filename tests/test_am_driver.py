@@ -92,6 +92,50 @@ def test_emma_pieces_are_consistent():
     assert abs(root - 2.0 ** (1 / 3)) < 2e-4
 
 
+def test_W_is_varG2_P_inside_AM(golden):
+    """What eagle_scan_with_W rests on: with the operands .find_qtl builds (E/R/find_qtl.R:5-49), dim_reduced_vara =
+    varG I - C22 = varG^2 Ze P Ze (Henderson; calculate_reduced_vara.R:21-35) and inv_MMt_sqrt = Ze^-1, so the W = S V S the
+    reference forms with two n^3 products per call is varG^2 P, and v = S a_hat is varG P y."""
+    g = golden("genoDemo_150x4998")
+    n = 150
+    MMtn = g["MMt"] / g["MMt"].max() + 0.95 * np.eye(n)
+    for varE, varG, X in ((1.0, 0.5, g["X"]), (0.3, 2.0, np.column_stack([g["X"], g["M8"][:, [17, 900]].astype(float)]))):
+        ops = host_model.scan_operands(MMtn, X, g["y"], varE, varG)
+        W = ops["S"] @ (ops["V"] @ ops["S"])
+        np.testing.assert_allclose(W, varG ** 2 * ops["P"], rtol=0, atol=1e-10 * np.abs(W).max())
+        np.testing.assert_allclose(ops["S"] @ ops["ahat"], varG * (ops["P"] @ np.ravel(g["y"])), rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_scan_with_W_shortcut_matches_the_reference_shaped_scan(golden, tmp_path):
+    from eagleeverything_amd import rcpp_api
+    g = golden("genoDemo_150x4998")
+    n, L = g["M8"].shape
+    geno = synth.write_geno_pair(str(tmp_path), np.ascontiguousarray(g["M8"].T))
+    MMtn = g["MMt"] / g["MMt"].max() + 0.95 * np.eye(n)
+    varE, varG = 1.0, 0.5
+    ops = host_model.scan_operands(MMtn, g["X"], g["y"], varE, varG)
+    ref = rcpp_api.calculate_a_and_vara_rcpp(geno["asciifileMt"], np.nan, ops["S"], ops["V"], 8.0, (L, n), ops["ahat"])
+    idx_ref = rcpp_api.last_scan_argmax()[0]
+    res = rcpp_api.scan_with_W(geno["asciifileMt"], np.nan, varG ** 2 * ops["P"], varG * (ops["P"] @ np.ravel(g["y"])), 8.0, (L, n))
+    assert rcpp_api.last_scan_argmax()[0] == idx_ref
+    np.testing.assert_allclose(res["a"], ref["a"], rtol=1e-8, atol=1e-10 * np.abs(ref["a"]).max())
+    vs = np.abs(ref["vara"]).max()
+    np.testing.assert_allclose(res["vara"], ref["vara"], rtol=1e-7, atol=1e-10 * vs)
+    # masking and a non-symmetric W work as in the reference-shaped call
+    W = np.random.default_rng(0).standard_normal((n, n)) * 0.01 + np.eye(n)
+    v = np.random.default_rng(1).standard_normal(n)
+    sel = np.array([3.0, 77.0])
+    res2 = rcpp_api.scan_with_W(geno["asciifileMt"], sel, W, v, 8.0, (L, n))
+    Mt = g["M8"].T.astype(np.float64)
+    a_ref = Mt @ v
+    v_ref = np.einsum("ij,jk,ik->i", Mt, W, Mt)
+    a_ref[[3, 77]] = 0.0; v_ref[[3, 77]] = 0.0
+    np.testing.assert_allclose(res2["a"].ravel(), a_ref, rtol=1e-9, atol=1e-11 * np.abs(a_ref).max())
+    np.testing.assert_allclose(res2["vara"].ravel(), v_ref, rtol=1e-7, atol=1e-9 * np.abs(v_ref).max())
+    rcpp_api.drop_cache()
+
+
 @pytest.mark.gpu
 def test_am_hip_selects_same_markers_as_oracle(oracle, golden, tmp_path):
     g = golden("genoDemo_150x4998")
