@@ -700,6 +700,7 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8w(const int8_t* __restrict__ 
     if (cut_last_round && tail > 0 && tail <= 16) { psplit = 32 / tail; if (psplit > npair) psplit = npair; }
     int worker = slot, piece = 0;
     if (slot >= full) { const int u = slot - full; worker = full + u / psplit; piece = u - (u / psplit) * psplit; }
+    else psplit = 1;  // only the workers of the last round are cut
     if (worker >= wx) return;
     const int mt = (worker / nslices) * 8 + xcd, sl = worker - (worker / nslices) * nslices;
     if (mt >= ntm) return;
