@@ -9,7 +9,7 @@ from eagleeverything_amd import _lib
 from eagleeverything_amd.sharded import DeviceShard
 
 n = int(os.environ.get("N", 10000))
-variants = [int(v) for v in os.environ.get("VARIANTS", "0,21,22,23,24").split(",")]
+variants = [int(v) for v in os.environ.get("VARIANTS", "0,26,21,22,23").split(",")]
 lib = _lib.load()
 sh = DeviceShard(n, 256)
 gen = torch.Generator(device=sh.dev); gen.manual_seed(1)
