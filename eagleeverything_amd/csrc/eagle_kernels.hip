@@ -745,6 +745,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f64_list(const double* __restri
 // The same tile with EIGHT waves (4 x 2, wave tile 32 x 64 = 2 x 4 MFMA tiles, 64 accumulator registers): under 128 VGPRs, so two
 // workgroups = 16 waves = 4 per SIMD are resident and the matrix pipe has four waves to choose from around every barrier
 // instead of two (the 4-wave form keeps the fp64 pipe 83 % busy).  Same K order per element: bitwise the same C.
+// Sixteen waves (wave tile 16 x 64, 64 VGPRs with spills) were measured too: 54.8 ms against 48.4 ms at n = 10,000, not kept.
 template <int LDA>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_gemm_f64_list8(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
                                                            double* __restrict__ C, long ldc, long K, const int* __restrict__ tiles, int n_main,
@@ -828,90 +829,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int n = 0; n < 4; n++)
 #pragma unroll
             for (int q = 0; q < 4; q++) dst[(long)(wr * 32 + m * 16 + g + 4 * q) * ldo + wc * 64 + n * 16 + i16] = acc[m][n][q];
-}
-template <int LDA>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_gemm_f64_list16(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
-                                                           double* __restrict__ C, long ldc, long K, const int* __restrict__ tiles, int n_main,
-                                                           int split, double* __restrict__ scratch, const int* __restrict__ skip_if, int skip_val) {
-    constexpr int LDSA = GF_T * LDA;
-    __shared__ __attribute__((aligned(16))) double lds[2][LDSA + GF_LDSB_DOUBLES];
-    if (skip_if && *skip_if == skip_val) return;
-    const int b = blockIdx.x;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wr = w >> 1, wc = w & 1;
-    const int i16 = lane & 15, g = lane >> 4;
-    const long nkb_all = K / GF_BK;
-    int tile;
-    long kb0 = 0, kb1 = nkb_all;
-    double* out;
-    long ldo;
-    if (b < n_main) {
-        tile = tiles[b];
-        out = nullptr; ldo = ldc;
-    } else {
-        const int u = b - n_main, tt = u / split, ks = u - tt * split;
-        tile = tiles[n_main + tt];
-        kb0 = nkb_all * ks / split;
-        kb1 = nkb_all * (ks + 1) / split;
-        out = scratch + (long)u * (GF_T * GF_T);
-        ldo = GF_T;
-    }
-    const long row0 = (long)(tile >> 16) * GF_T, col0 = (long)(tile & 0xffff) * GF_T;
-    const double* Ablk = A + row0 * lda;
-    const double* Bblk = B + col0;
-    f64x4 acc[1][4];
-#pragma unroll
-    for (int m = 0; m < 1; m++)
-#pragma unroll
-        for (int n = 0; n < 4; n++) acc[m][n] = (f64x4){0.0, 0.0, 0.0, 0.0};
-    f64x2 sa[1], sb[1];
-    auto load = [&](long k0) {
-#pragma unroll
-        for (int i = 0; i < 1; i++) {
-            const int c = t;
-            sb[i] = *(const f64x2*)(Bblk + (k0 + (c >> 6)) * ldb + (c & 63) * 2);
-            sa[i] = *(const f64x2*)(Ablk + (long)(c >> 3) * lda + k0 + (c & 7) * 2);
-        }
-    };
-    auto store = [&](double* ldsA, double* ldsB) {
-#pragma unroll
-        for (int i = 0; i < 1; i++) {
-            const int c = t;
-            *(f64x2*)(ldsB + (c >> 6) * GF_LDB + (c & 63) * 2) = sb[i];
-            *(f64x2*)(ldsA + (c >> 3) * LDA + (c & 7) * 2) = sa[i];
-        }
-    };
-    load(kb0 * GF_BK);
-    store(lds[0], lds[0] + LDSA);
-    __syncthreads();
-    int cur = 0;
-    for (long kb = kb0; kb < kb1; kb++) {
-        const bool more = kb + 1 < kb1;
-        if (more) load((kb + 1) * GF_BK);
-        const double* ldsA = lds[cur];
-        const double* ldsB = lds[cur] + LDSA;
-#pragma unroll
-        for (int s4 = 0; s4 < 4; s4++) {
-            double a[1], bb[4];
-#pragma unroll
-            for (int m = 0; m < 1; m++) a[m] = ldsA[(wr * 16 + m * 16 + i16) * LDA + 4 * g + s4];
-#pragma unroll
-            for (int n = 0; n < 4; n++) bb[n] = ldsB[(4 * g + s4) * GF_LDB + wc * 64 + n * 16 + i16];
-#pragma unroll
-            for (int m = 0; m < 1; m++)
-#pragma unroll
-                for (int n = 0; n < 4; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], bb[n], acc[m][n], 0, 0, 0);
-        }
-        if (more) store(lds[cur ^ 1], lds[cur ^ 1] + LDSA);
-        __syncthreads();
-        cur ^= 1;
-    }
-    double* dst = out ? out : C + row0 * ldc + col0;
-#pragma unroll
-    for (int m = 0; m < 1; m++)
-#pragma unroll
-        for (int n = 0; n < 4; n++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) dst[(long)(wr * 16 + m * 16 + g + 4 * q) * ldo + wc * 64 + n * 16 + i16] = acc[m][n][q];
 }
 __global__ __launch_bounds__(256) void k_gemm_f64_tail(const double* __restrict__ scratch, const int* __restrict__ tail_tiles, int split,
                                                        double* __restrict__ C, long ldc, const int* __restrict__ skip_if, int skip_val) {
@@ -1008,10 +925,6 @@ static int gemm_f64_tiles(eagle_ctx* ctx, const double* A, const double* B, doub
         case 23: GEMM_LAUNCH(GF_LDA, 1); break;  // XCD-contiguous 8 x 8 super-tile order: neutral
         case 24: GEMM_LAUNCH(18, 1); break;
         case 26: GEMM_LAUNCH(GF_LDA, 0); break;  // four waves per tile, pitch 20 (shipped until the eight-wave form)
-        case 27:  // sixteen waves per tile
-            hipLaunchKernelGGL((k_gemm_f64_list16<GF_LDA>), dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, A, np, B, np, C, np, np, tiles,
-                               (int)(split > 1 ? n_main : count), split, scratch, skip_if, skip_val);
-            break;
         default:  // eight waves per tile: 50.4 -> 48.4 ms for W at n = 10,000 (66.6 TF incl. v, symmetry check, fold), same bits
             hipLaunchKernelGGL((k_gemm_f64_list8<GF_LDA>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, A, np, B, np, C, np, np, tiles,
                                (int)(split > 1 ? n_main : count), split, scratch, skip_if, skip_val);
