@@ -53,6 +53,7 @@ def host_operands_torch(torch, MMt_norm, X, y, varE, varG):
     HX = Hinv @ X
     P = Hinv - HX @ torch.linalg.solve(X.T @ HX, HX.T)
     ev, U = torch.linalg.eigh(MMt_norm)
+    host_operands_torch.eig = (ev, U)  # kept for the spectral-scan secondary entry (section 1d of the header)
     sq = (U * ev.sqrt()) @ U.T
     sq = 0.5 * (sq + sq.T)
     S = torch.cholesky_inverse(torch.linalg.cholesky(sq))
@@ -85,6 +86,7 @@ class Run:
         self.t_gen = time.time() - t0
         self.S = self.V = self.ahat = None
         self.W_direct = self.v_direct = None
+        self.eig = self.Xy = None
 
     # ---- collectives-aware helpers ----------------------------------------------------------------
     def barrier(self):
@@ -147,6 +149,7 @@ class Run:
             else:
                 S, V, ahat, P = host_operands_torch(torch, MMt, X, y, 1.0, 0.5)
                 self.W_direct, self.v_direct = 0.25 * P, 0.5 * (P @ y)  # varG^2 P and varG P y: what eagle_scan_with_W takes
+                self.eig, self.Xy = host_operands_torch.eig, (X, y)
         else:
             S = torch.empty((n, n), dtype=torch.float64, device=self.dev)
             V = torch.empty((n, n), dtype=torch.float64, device=self.dev)
@@ -433,6 +436,56 @@ def main():
                                                     "note": "eagle_scan_with_W: inside AM() W = S V S equals varG^2 P, which find_qtl.R already holds; "
                                                             "not a .Call of the reference (INTEGRATION.md)"}
             sh.W0 = sh.v0 = None
+        # the scan in the eigenbasis of MM^T (opt-in entry points of section 1d): Z = Mt U once, then one HBM-bound pass per scan
+        if run.eig is not None:
+            import ctypes as C
+            lib, ctx = sh.L, sh.ctx
+            ev, U = run.eig
+            Xm, yv = run.Xy
+            stream = lambda: C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            Ur = torch.zeros((sh.np_, sh.np_), dtype=torch.float64, device=dev)
+            Ur[:n, :n] = U
+            Z = torch.empty((sh.Lp, sh.np_), dtype=torch.float64, device=dev)
+            torch.cuda.synchronize(dev)
+            tz = time.perf_counter()
+            sh._check(lib.eagle_dev_spectral_zbuild(ctx, sh.Mt8.data_ptr(), sh.Lp, sh.np_, sh.np_, Ur.data_ptr(), Z.data_ptr(), stream()))
+            torch.cuda.synchronize(dev)
+            zbuild_s = time.perf_counter() - tz
+            del Ur
+            UtX, Uty = U.T @ Xm, U.T @ yv
+            p = UtX.shape[1]
+            lin = torch.empty((sh.Lp, 16), dtype=torch.float64, device=dev)
+            quad = torch.empty(sh.Lp, dtype=torch.float64, device=dev)
+            a_s, v_s = torch.zeros(sh.Lp, dtype=torch.float64, device=dev), torch.zeros(sh.Lp, dtype=torch.float64, device=dev)
+
+            def spectral_step(varE=1.0, varG=0.5):
+                d = torch.zeros(sh.np_, dtype=torch.float64, device=dev)
+                d[:n] = 1.0 / (varE + varG * ev)
+                G = torch.zeros((sh.np_, 16), dtype=torch.float64, device=dev)
+                G[:n, 0] = d[:n] * Uty
+                G[:n, 1:1 + p] = d[:n, None] * UtX
+                Cm = torch.linalg.inv(UtX.T @ (d[:n, None] * UtX)).contiguous()
+                c1 = (Cm @ (UtX.T @ (d[:n] * Uty))).contiguous()
+                sh._check(lib.eagle_dev_spectral_pass(ctx, Z.data_ptr(), sh.Lp, sh.np_, G.data_ptr(), 16, d.data_ptr(), lin.data_ptr(), quad.data_ptr(), stream()))
+                sh._check(lib.eagle_dev_spectral_finish(ctx, lin.data_ptr(), 16, quad.data_ptr(), Ltot, p, Cm.data_ptr(), c1.data_ptr(), varG,
+                                                        a_s.data_ptr(), v_s.data_ptr(), stream()))
+                sh._check(lib.eagle_dev_tsq_argmax(ctx, a_s.data_ptr(), v_s.data_ptr(), Ltot, None, sh._best.data_ptr(), sh._scratch.data_ptr(), stream()))
+                return sh.best()
+
+            spectral_step()
+            torch.cuda.synchronize(dev)
+            ts = time.perf_counter()
+            for _ in range(5):
+                bsp = spectral_step()
+            torch.cuda.synchronize(dev)
+            sp_s = (time.perf_counter() - ts) / 5
+            secondary["scan_spectral"] = {"value": Ltot / sp_s, "unit": "markers/s", "ms_per_step": sp_s * 1e3, "one_time_Z_build_s": zbuild_s,
+                                          "Z_bytes": float(sh.Lp) * sh.np_ * 8, "selected_marker_equal": bool(bsp[1] + 1 == sel_i8[0]),
+                                          "hbm": {"bound": "hbm", "achieved": float(sh.Lp) * sh.np_ * 8 / sp_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                  "frac": float(sh.Lp) * sh.np_ * 8 / sp_s / 1e9 / HBM_PEAK_GBS},
+                                          "note": "opt-in entry points (include/eagle_hip.h 1d): needs U, lambda of the normalised MM^T and an R-side "
+                                                  "change; K is fixed during an AM() run, so Z = Mt U is built once and each scan is one pass over Z"}
+            del Z, lin, quad
         # BASELINE configs[1]: 5,000 x 500,000 on one card
         del run, sh
         torch.cuda.empty_cache()

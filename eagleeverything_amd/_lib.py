@@ -41,6 +41,8 @@ SIGNATURES = {
     "eagle_calculateMMt": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double, C.c_int, c_dp, C.c_long, c_lp, C.c_int, c_dp]),
     "eagle_calculate_a_and_vara": (C.c_int, [C.c_void_p, C.c_char_p, c_dp, C.c_long, c_dp, c_dp, C.c_double, c_lp, c_dp,
                                              C.c_int, c_dp, c_dp]),
+    "eagle_spectral_prepare": (C.c_int, [C.c_void_p, C.c_char_p, c_lp, c_dp, C.c_double]),
+    "eagle_spectral_scan": (C.c_int, [C.c_void_p, c_dp, c_dp, c_dp, C.c_long, C.c_double, C.c_double, c_dp, C.c_long, c_dp, c_dp]),
     "eagle_scan_with_W": (C.c_int, [C.c_void_p, C.c_char_p, c_dp, C.c_long, c_dp, c_dp, C.c_double, c_lp, C.c_int, c_dp, c_dp]),
     "eagle_calculate_reduced_a": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double, c_dp, c_dp, C.c_double, c_lp, c_dp,
                                             C.c_long, C.c_int, c_dp]),
@@ -102,6 +104,11 @@ SIGNATURES = {
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "eagle_dev_vara_i8_mfma": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_int, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eagle_dev_spectral_zbuild": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eagle_dev_spectral_pass": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p]),
+    "eagle_dev_spectral_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_void_p, C.c_double,
+                                            C.c_void_p, C.c_void_p, C.c_void_p]),
     "eagle_dev_zero_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_long,
                                       C.c_void_p]),
     "eagle_dev_tsq_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p,

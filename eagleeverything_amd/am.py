@@ -207,6 +207,32 @@ class HipBackend:
                                        device=self.device).astype(np.int64)
 
 
+class SpectralBackend(HipBackend):
+    """The same loop with the scan in the eigenbasis of MM^T (include/eagle_hip.h section 1d; OPT-IN, needs the R-side change
+    INTEGRATION.md describes): K = MM^T/max + 0.95 I is fixed for the whole run, so Z = Mt U is made once after calcMMt and
+    every find_qtl is one HBM-bound pass over Z instead of an n x n quadratic form per marker.  Selects the markers the
+    reference-shaped path selects (tests/test_am_driver.py)."""
+
+    def __init__(self, device=0):
+        super().__init__(device)
+        self.lam = self.U = None
+        self.L = None
+
+    def calcMMt(self, geno, availmemGb, ncpu, selected_loci, quiet):
+        MMt = super().calcMMt(geno, availmemGb, ncpu, selected_loci, quiet)
+        self.lam, self.U = np.linalg.eigh(MMt)                       # the decomposition emma.REMLE needs anyway
+        n, self.L = geno["dim_of_ascii_M"]
+        self.rcpp_api.spectral_prepare(geno["asciifileMt"], (self.L, n), self.U, availmemGb, device=self.device)
+        return MMt
+
+    def find_qtl(self, geno, availmemGb, selected_loci, MMt, invMMt, best_ve, best_vg, currentX, ncpu, quiet, trait):
+        res = self.rcpp_api.spectral_scan(self.lam, self.U.T @ currentX, self.U.T @ np.ravel(trait), best_ve, best_vg, self.L,
+                                          selected_loci, device=self.device)
+        with np.errstate(all="ignore"):
+            tsq = res["a"].ravel() ** 2 / res["vara"].ravel()
+        return int(np.flatnonzero(tsq == np.nanmax(tsq))[0]) + 1         # find_qtl.R:71-83
+
+
 def AM(trait, X, geno, availmemGb=8, ncpu=1, maxit=20, quiet=True, backend=None, message=None, algebra=None):
     """E/R/AM.R:400-475 for a complete-data trait vector and a ready design matrix X (n x q, intercept included).
 

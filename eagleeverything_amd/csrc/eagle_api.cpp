@@ -251,6 +251,7 @@ extern "C" void eagle_close(eagle_ctx* ctx) {
     ctx->peers.clear();
     (void)hipSetDevice(ctx->device);
     eagle_linalg_release(ctx);
+    eagle_spectral_release(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     eagle_drop_cache(ctx);
     if (ctx->d_mmt) (void)hipFree(ctx->d_mmt);

@@ -61,6 +61,7 @@ struct eagle_ctx {
     // multi-device: the ctx eagle_open_devices returns is the LEAD (first device); it owns one sub-context per further device.
     std::vector<eagle_ctx*> peers;
     eagle_ctx* lead = nullptr;           // set in sub-contexts
+    double* d_Z = nullptr; long z_L = 0, z_n = 0;  // Z = Mt U of the opt-in spectral scan (eagle_spectral.hip), L_pad x n_pad fp64
     void* blas_handle = nullptr;         // rocblas_handle of the opt-in device model algebra (eagle_linalg.cpp)
     void* rccl = nullptr;                // RcclState* of the lead (communicators, one per device), or NULL: host-staged sums
     long scan_first = 0;                 // global index of the first marker of this device's last scan

@@ -37,6 +37,7 @@ int eagle_dev_scale_rows_pow(eagle_ctx* ctx, double* R, long n, long ld, const d
 int eagle_dev_transpose_f64(eagle_ctx* ctx, const double* in, double* out, long N, void* stream);
 int eagle_dev_dot_matrices(eagle_ctx* ctx, const double* A, long lda, const double* B, long ldb, long n, double* out, void* stream);
 void eagle_linalg_release(eagle_ctx* ctx);
+void eagle_spectral_release(eagle_ctx* ctx);
 int eagle_dev_extract_col(eagle_ctx* ctx, const int8_t* M8, long n, long ld, long col, int* out, void* stream);
 #ifdef __cplusplus
 }

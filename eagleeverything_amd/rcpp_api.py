@@ -182,6 +182,32 @@ def scan_with_W(f_name_ascii, selected_loci, W, v, max_memory_in_Gbytes, dims, q
     return {"a": a_out.reshape(Lm, 1), "vara": v_out.reshape(Lm, 1)}
 
 
+def spectral_prepare(f_name_ascii, dims, U, max_memory_in_Gbytes=8.0, device=0):
+    """eagle_spectral_prepare: Z = Mt U once per AM() run (dims = (L, n) of Mt.ascii, U = eigenvectors of the normalised MM^T)."""
+    L = _lib.load()
+    ctx = context(device)
+    Um = _f64F(U)
+    n = int(dims[1])
+    if Um.shape != (n, n):
+        raise ValueError("U must be n x n")
+    _check(ctx, L.eagle_spectral_prepare(ctx, os.fsencode(f_name_ascii), _dims(dims), _dp(Um), float(max_memory_in_Gbytes)))
+
+
+def spectral_scan(lam, UtX, Uty, varE, varG, n_markers, selected_loci=np.nan, device=0):
+    """eagle_spectral_scan: a and vara of every marker from one pass over Z (see include/eagle_hip.h section 1d)."""
+    L = _lib.load()
+    ctx = context(device)
+    lam = _f64F(np.ravel(lam))
+    UtX = _f64F(np.atleast_2d(UtX).reshape(lam.size, -1))
+    Uty = _f64F(np.ravel(Uty))
+    p = UtX.shape[1]
+    s, sp, ns = _sel(selected_loci)
+    a_out = np.zeros(int(n_markers))
+    v_out = np.zeros(int(n_markers))
+    _check(ctx, L.eagle_spectral_scan(ctx, _dp(lam), _dp(UtX), _dp(Uty), p, float(varE), float(varG), sp, ns, _dp(a_out), _dp(v_out)))
+    return {"a": a_out.reshape(-1, 1), "vara": v_out.reshape(-1, 1)}
+
+
 def calculate_reduced_a_rcpp(f_name_ascii, varG, P, y, max_memory_in_Gbytes, dims, selected_loci, quiet=True,
                              message=None, device=0):
     L = _lib.load()

@@ -212,6 +212,25 @@ int eagle_mmt_sqrt_and_sqrtinv(eagle_ctx* ctx, const double* MMt, long n, double
 int eagle_scan_with_W(eagle_ctx* ctx, const char* f_name_ascii, const double* selected_loci, long n_selected, const double* W,
                       const double* v, double max_memory_in_Gbytes, const long dims[2], int quiet, double* a_out, double* vara_out);
 
+/* ---------------------------------------------------------------------------------------------
+ * 1d. The scan in the eigenbasis of MM^T (OPT-IN; not symbols of the reference -- a maintainer who edits find_qtl.R may use
+ *     them; the reference-shaped eagle_calculate_a_and_vara above stays the drop-in).
+ *     Per iteration the reference evaluates a_i = varG m_i^T P y and vara_i = varG^2 m_i^T P m_i (W = S V S = varG^2 P, see
+ *     eagle_scan_with_W) with P = H^-1 - H^-1 X (X^T H^-1 X)^-1 X^T H^-1, H = varE I + varG K, K = the normalised MM^T of
+ *     calcMMt.R:13 -- an n x n quadratic form per marker.  K does not change during an AM() run (only varE, varG, X do), so with
+ *     K = U diag(lambda) U^T (emma.REMLE computes it anyway, E/R/emma_eigen_R_wo_Z.R:17) and Z = Mt U made ONCE,
+ *     every scan is one streaming pass over Z: 8 n bytes and (p + 2) n multiply-adds per marker, HBM-bound.
+ * ------------------------------------------------------------------------------------------- */
+/* Once per AM() run: Z = Mt U (L x n fp64, 8 bytes per genotype, kept in HBM by the ctx) from the resident int8 image of
+ * Mt.ascii (dims = (L, n)) and the eigenvectors U of K (n x n column-major, any order, the same order as lambda below). */
+int eagle_spectral_prepare(eagle_ctx* ctx, const char* f_name_ascii, const long dims[2], const double* U, double max_memory_in_Gbytes);
+/* Per iteration: lambda (n eigenvalues of K), UtX = U^T X (n x p column-major, p = columns of the fixed-effects design,
+ * 1 <= p <= 31), Uty = U^T y (n), the variance components.  a_out, vara_out: L doubles, the values
+ * eagle_calculate_a_and_vara returns for the S, V, a_hat that find_qtl.R:5-49 builds from the same K, X, y, varE, varG.
+ * selected_loci: the reference's masking rule (element 0 NA: none). */
+int eagle_spectral_scan(eagle_ctx* ctx, const double* lambda, const double* UtX, const double* Uty, long p, double varE, double varG,
+                        const double* selected_loci, long n_selected, double* a_out, double* vara_out);
+
 /* Replaces the R tail of .find_qtl:  tsq <- a^2/vara ; which(tsq == max(tsq, na.rm=TRUE))[1]
  *                                                E/R/find_qtl.R:71-83
  * Evaluated on the device on the a / vara of the LAST eagle_calculate_a_and_vara call of this ctx (still in
@@ -356,6 +375,15 @@ int eagle_dev_vara_f6_prepare(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, lon
                               int nslices, void* ws, const double* v, double* a_out, void* stream);
 int eagle_dev_vara_f6_mfma(eagle_ctx* ctx, const int8_t* Mt8, const void* Mt4, long L_pad, long n_pad, long ld, int nslices,
                            void* ws, double* vara_out, double* err_bound_dev, void* stream);
+/* The spectral scan (section 1d) on device-resident data: Z[L_pad][n_pad] = Mt8 * Ur with Ur = U row-major [n_pad][n_pad]
+ * (Ur[j][k] = U[j][k], zero padded); one pass over Z: lin[L_pad][NC] = Z G and quad[i] = sum_k Z_ik^2 d_k with G [n_pad][NC]
+ * row-major, NC = 16 or 32 (column 0 = d o U^T y, columns 1..p = d o U^T X, the rest zero); the finish:
+ * a_i = varG (lin_i0 - q_i . c1), vara_i = varG^2 (quad_i - q_i^T C q_i), q_i = lin_i[1..p], C p x p row-major, c1 p. */
+int eagle_dev_spectral_zbuild(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Ur, double* Z, void* stream);
+int eagle_dev_spectral_pass(eagle_ctx* ctx, const double* Z, long L_pad, long n_pad, const double* G, int NC, const double* d, double* lin,
+                            double* quad, void* stream);
+int eagle_dev_spectral_finish(eagle_ctx* ctx, const double* lin, int NC, const double* quad, long L, long p, const double* Cm, const double* c1,
+                              double varG, double* a, double* vara, void* stream);
 /* zero a[i], vara[i] at the listed rows (row masking of calculate_a_and_vara_rcpp.cpp:79-84: a zeroed
  * marker row yields exactly a = 0, vara = 0). rows_dev: device array of long, entries outside [0,L) ignored. */
 int eagle_dev_zero_rows(eagle_ctx* ctx, double* a, double* vara, long L, const long* rows_dev, long nrows,

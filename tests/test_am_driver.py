@@ -137,6 +137,48 @@ def test_scan_with_W_shortcut_matches_the_reference_shaped_scan(golden, tmp_path
 
 
 @pytest.mark.gpu
+def test_spectral_scan_matches_the_reference_shaped_scan(golden, tmp_path):
+    """include/eagle_hip.h section 1d: Z = Mt U once, then a and vara of every marker from one pass over Z -- against the
+    reference-shaped scan fed with the S, V, a_hat that find_qtl.R builds from the same K, X, y, varE, varG."""
+    from eagleeverything_amd import rcpp_api
+    g = golden("genoDemo_150x4998")
+    n, L = g["M8"].shape
+    geno = synth.write_geno_pair(str(tmp_path), np.ascontiguousarray(g["M8"].T))
+    K = g["MMt"] / g["MMt"].max() + 0.95 * np.eye(n)
+    lam, U = np.linalg.eigh(K)
+    rcpp_api.spectral_prepare(geno["asciifileMt"], (L, n), U, 8.0)
+    y = np.ravel(g["y"])
+    rng = np.random.default_rng(3)
+    cases = [(1.0, 0.5, g["X"]),
+             (0.3, 2.0, np.column_stack([g["X"], g["M8"][:, [17, 900, 4000]].astype(float)])),
+             (0.7, 0.9, np.column_stack([g["X"], rng.standard_normal((n, 19))]))]        # p = 20: the 32-column form of the kernel
+    for varE, varG, X in cases:
+        ops = host_model.scan_operands(K, X, y, varE, varG)
+        ref = rcpp_api.calculate_a_and_vara_rcpp(geno["asciifileMt"], np.nan, ops["S"], ops["V"], 8.0, (L, n), ops["ahat"])
+        idx_ref = rcpp_api.last_scan_argmax()[0]
+        res = rcpp_api.spectral_scan(lam, U.T @ X, U.T @ y, varE, varG, L)
+        np.testing.assert_allclose(res["a"], ref["a"], rtol=1e-8, atol=1e-10 * np.abs(ref["a"]).max())
+        np.testing.assert_allclose(res["vara"], ref["vara"], rtol=1e-7, atol=1e-10 * np.abs(ref["vara"]).max())
+        with np.errstate(all="ignore"):
+            tsq = res["a"].ravel() ** 2 / res["vara"].ravel()
+        assert int(np.nanargmax(tsq)) + 1 == idx_ref
+    # masking rule of the reference
+    res_m = rcpp_api.spectral_scan(lam, U.T @ g["X"], U.T @ y, 1.0, 0.5, L, selected_loci=np.array([5.0, 4000.0]))
+    assert res_m["a"][5, 0] == 0.0 and res_m["vara"][4000, 0] == 0.0 and res_m["a"][6, 0] != 0.0
+    rcpp_api.drop_cache()
+
+
+@pytest.mark.gpu
+def test_am_spectral_backend_selects_the_same_markers(golden, tmp_path):
+    g = golden("genoDemo_150x4998")
+    geno = synth.write_geno_pair(str(tmp_path), np.ascontiguousarray(g["M8"].T))
+    ref = am.AM(g["y"], g["X"], geno, maxit=5)
+    spec = am.AM(g["y"], g["X"], geno, maxit=5, backend=am.SpectralBackend())
+    assert spec["all_picks"] == ref["all_picks"] and spec["selected_loci"] == ref["selected_loci"]
+    np.testing.assert_allclose(spec["extBIC_trace"], ref["extBIC_trace"], rtol=1e-12)
+
+
+@pytest.mark.gpu
 def test_am_hip_selects_same_markers_as_oracle(oracle, golden, tmp_path):
     g = golden("genoDemo_150x4998")
     geno = synth.write_geno_pair(str(tmp_path), np.ascontiguousarray(g["M8"].T))
