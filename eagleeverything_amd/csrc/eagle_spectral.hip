@@ -179,8 +179,13 @@ __global__ __launch_bounds__(256) void k_spectral_finish(const double* __restric
         for (int l = 0; l < p; l++) r += Cm[j * p + l] * li[1 + l];
         qCq += qj * r;
     }
-    a[i] = varG * (li[0] - qc1);
-    vara[i] = varG * varG * (quad[i] - qCq);
+    // A marker that is (numerically) in the column space of X -- one that is already in the model -- has a = vara = 0 in exact
+    // arithmetic and rounding noise here (the reference's selected_loci masking, which never fires from AM(), was meant for
+    // exactly these): give it the masked values a = vara = 0 (tsq NaN, skipped by na.rm) instead of noise / noise.
+    const double r = quad[i] - qCq;
+    const bool in_model = !(r > 1e-12 * quad[i]);
+    a[i] = in_model ? 0.0 : varG * (li[0] - qc1);
+    vara[i] = in_model ? 0.0 : varG * varG * r;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
