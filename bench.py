@@ -450,8 +450,16 @@ def main():
             tz = time.perf_counter()
             sh._check(lib.eagle_dev_spectral_zbuild(ctx, sh.Mt8.data_ptr(), sh.Lp, sh.np_, sh.np_, Ur.data_ptr(), Z.data_ptr(), stream()))
             torch.cuda.synchronize(dev)
-            zbuild_s = time.perf_counter() - tz
-            del Ur
+            zbuild_f64_s = time.perf_counter() - tz
+            zcheck = Z[:4096, :n].clone()
+            wsz = torch.empty(int(lib.eagle_spectral_zbuild_i8_workspace_bytes(sh.np_, 6)), dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize(dev)
+            tz = time.perf_counter()
+            sh._check(lib.eagle_dev_spectral_zbuild_i8(ctx, sh.Mt8.data_ptr(), sh.Lp, sh.np_, sh.np_, Ur.data_ptr(), Z.data_ptr(), wsz.data_ptr(), 6, stream()))
+            torch.cuda.synchronize(dev)
+            zbuild_s = time.perf_counter() - tz   # the default of eagle_spectral_prepare: six exact int8 digit slices of U
+            z_diff = float((Z[:4096, :n] - zcheck).abs().max())
+            del Ur, wsz, zcheck
             UtX, Uty = U.T @ Xm, U.T @ yv
             p = UtX.shape[1]
             lin = torch.empty((sh.Lp, 16), dtype=torch.float64, device=dev)
@@ -479,7 +487,8 @@ def main():
                 bsp = spectral_step()
             torch.cuda.synchronize(dev)
             sp_s = (time.perf_counter() - ts) / 5
-            secondary["scan_spectral"] = {"value": Ltot / sp_s, "unit": "markers/s", "ms_per_step": sp_s * 1e3, "one_time_Z_build_s": zbuild_s,
+            secondary["scan_spectral"] = {"value": Ltot / sp_s, "unit": "markers/s", "ms_per_step": sp_s * 1e3, "one_time_Z_build_s": zbuild_s, "Z_build_fp64_mfma_s": zbuild_f64_s,
+                                          "Z_int8_vs_fp64_max_abs_diff": z_diff,
                                           "Z_bytes": float(sh.Lp) * sh.np_ * 8, "selected_marker_equal": bool(bsp[1] + 1 == sel_i8[0]),
                                           "hbm": {"bound": "hbm", "achieved": float(sh.Lp) * sh.np_ * 8 / sp_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                   "frac": float(sh.Lp) * sh.np_ * 8 / sp_s / 1e9 / HBM_PEAK_GBS},

@@ -105,6 +105,9 @@ SIGNATURES = {
     "eagle_dev_vara_i8_mfma": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_int, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "eagle_dev_spectral_zbuild": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "eagle_spectral_zbuild_i8_workspace_bytes": (C.c_int64, [C.c_long, C.c_int]),
+    "eagle_dev_spectral_zbuild_i8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                               C.c_void_p]),
     "eagle_dev_spectral_pass": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
     "eagle_dev_spectral_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_void_p, C.c_double,

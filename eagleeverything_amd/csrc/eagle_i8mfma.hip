@@ -23,6 +23,7 @@
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 #define T8 256          /* block tile (rows of A, rows of B) */
 #define BK8 128         /* K bytes per stage */
@@ -792,6 +793,151 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8w(const int8_t* __restrict__ 
 #pragma unroll
     for (int m = 0; m < 3; m++)
         if ((lane & 16) == 0 && keep[m] && qrow + m * 32 < Lp) atomicAdd((unsigned long long*)&qs[m * 32], (unsigned long long)keep[m]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_zbuild_i8: Z = Mt8 * U for the spectral scan (eagle_spectral.hip) from exact int8 digit slices of U, on the tile engine of
+// k_vara_i8w (384 x 256 tile, 8 waves 4 x 2, 3 x 4 MFMA tiles per wave) with a dense K loop and a store epilogue:
+//   U = 2^(e+2) sum_{s<S} D_s 256^-(s+1) + R,  max|U| < 2^e,  |R_jk| <= 2^(e+1-8S);   Us[s][k][j] = D_s[j][k]  (k = output column)
+//   T_s[i][k] = sum_j Mt8[i][j] D_s[j][k]  exactly (int32: |T| <= 128 n_pad);   Z[i][k] = 2^(e+2) sum_s 256^-(s+1) T_s[i][k],
+// the slices walked least significant first inside one workgroup, each added into its tile of Z (owned by that workgroup alone).
+// |Z_ik - (Mt U)_ik| <= (sum_j |m_ij|) 2^(e+1-8S) + S-term fp64 rounding.  Against the fp64 MFMA form (k_zbuild) this is S int8
+// products instead of one fp64 product: 64x the matrix rate per product.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_absmax_all(const double* __restrict__ x, long count, unsigned long long* __restrict__ bits) {
+    double m = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) {
+        const double v = fabs(x[i]);
+        m = v > m ? v : m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { double y = __shfl_down(m, o); m = y > m ? y : m; }
+    if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(bits, (unsigned long long)__double_as_longlong(m));
+}
+// Us[s][k][j] = digit s of Ur[j][k]; 32 x 32 tiles through LDS so that both sides are coalesced
+__global__ __launch_bounds__(256) void k_slice_u(const double* __restrict__ Ur, long np, const unsigned long long* __restrict__ maxbits, int nslices,
+                                                 int8_t* __restrict__ Us) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long bj = (long)blockIdx.y * 32, bk = (long)blockIdx.x * 32;
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = Ur[(bj + r) * np + bk + tx];  // tile[jj][kk]
+    __syncthreads();
+    int e = 0;
+    const double mx = __longlong_as_double((long long)*maxbits);
+    if (mx > 0.0) (void)frexp(mx, &e);
+    for (int r = ty; r < 32; r += 8) {
+        long long Q = llrint(ldexp(tile[tx][r], 8 * nslices - (e + 2)));   // element (k = bk + r, j = bj + tx)
+        for (int s = nslices - 1; s >= 0; s--) {
+            const long long d = ((Q + 128) & 255) - 128;
+            Q = (Q - d) >> 8;
+            Us[(long)s * np * np + (bk + r) * np + bj + tx] = (int8_t)d;
+        }
+    }
+}
+__global__ __launch_bounds__(512, 2) void k_zbuild_i8(const int8_t* __restrict__ Mt8, long ld, int ntm, const int8_t* __restrict__ Us, long np,
+                                                      int nslices, const unsigned long long* __restrict__ maxbits, double* __restrict__ Z, long Lp) {
+    extern __shared__ __attribute__((aligned(1024))) int8_t ldsv[];  // [2][A 48 KiB | B 32 KiB]
+    // XCD-aware placement (speed only): an XCD's 32 CUs work on 4 marker tiles x 8 column tiles in lock-step along K, so a
+    // stage of either operand is fetched into that L2 once and read 8 / 4 times from there
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    const int nct = (int)(np / T8), ncg = (nct + 7) >> 3;
+    const int within = slot & 31, grp = slot >> 5;
+    const int mt = (((grp / ncg) * 4 + (within >> 3)) << 3) + xcd, ct = (grp % ncg) * 8 + (within & 7);
+    if (mt >= ntm || ct >= nct) return;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = w >> 1, wc = w & 1;
+    const int ldi = (int)ld, npi = (int)np;
+    const T8Lane lnA = t8_lane(lane, ldi), lnB = t8_lane(lane, npi);
+    const long row0 = (long)mt * TW_M;
+    const long rows_here = Lp - row0 < TW_M ? Lp - row0 : TW_M;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(Mt8 + row0 * ld), 0, (int)(rows_here * ld), 0x00020000);
+    int e = 0;
+    const double mx = __longlong_as_double((long long)*maxbits);
+    if (mx > 0.0) (void)frexp(mx, &e);
+    i32x16 acc[3][4];
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+#pragma unroll
+        for (int n = 0; n < 4; n++)
+#pragma unroll
+            for (int x = 0; x < 16; x++) acc[m][n][x] = 0;
+    const int r = lane & 31, h = lane >> 5, swz = (r >> 1) & 7;
+    const int offA = wr * (96 * BK8) + r * BK8, offB = TW_ABYTES + wc * (128 * BK8) + r * BK8;
+    int ch[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) ch[ks] = ((2 * ks + h) ^ swz) << 4;
+    // the workgroup's tile of Z: rows row0 .. row0 + rows_here, columns ct*256 .. +256 (byte offsets fit 32 bits: 384 rows x 8 np)
+    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc((void*)(Z + row0 * np + (long)ct * T8), 0,
+                                                                         (int)(((rows_here - 1) * np + T8) * 8), 0x00020000);
+    const int zvoff = ((wr * 96 + 4 * h) * npi + wc * 128 + r) * 8;
+    const int nk = (int)(np / BK8), total = nslices * nk;  // flattened (slice, K stage) sequence, least significant slice first
+    auto stage = [&](int qi, int8_t* dst) {
+        const int s = nslices - 1 - qi / nk, kt = qi - (qi / nk) * nk;
+        tw_stage<6>(rsA, lnA, ldi, kt * BK8, dst, w);
+        tw_stage<4>(t8_rsrc(Us + (long)s * np * np + (long)ct * T8 * np, npi), lnB, npi, kt * BK8, dst + TW_ABYTES, w);
+    };
+    stage(0, ldsv);
+    __syncthreads();
+    int buf = 0;
+    for (int qi = 0; qi < total; qi++) {
+        const int8_t* st = ldsv + buf * (TW_ABYTES + TILE_BYTES);
+        if (qi + 1 < total) stage(qi + 1, ldsv + (buf ^ 1) * (TW_ABYTES + TILE_BYTES));
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) tw_kstep(acc, st + offA, st + offB, ch[ks]);
+        const int kt = qi - (qi / nk) * nk;
+        if (kt == nk - 1) {  // slice done: Z tile (+)= 2^(e+2-8(s+1)) T_s, through the tile's buffer descriptor (rows beyond L_pad dropped)
+            const int s = nslices - 1 - qi / nk;
+            const double scale = ldexp(1.0, e + 2 - 8 * (s + 1));
+            const bool first = s == nslices - 1;
+#pragma unroll
+            for (int m = 0; m < 3; m++)
+#pragma unroll
+                for (int x = 0; x < 16; x++) {
+                    const int so = ((m * 32 + (x & 3) + 8 * (x >> 2)) * npi) * 8;
+#pragma unroll
+                    for (int n = 0; n < 4; n++) {
+                        double v = scale * (double)acc[m][n][x];
+                        if (!first) v += __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsZ, zvoff, so + n * 256, 0));
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rsZ, zvoff, so + n * 256, 0);
+                        acc[m][n][x] = 0;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // one accumulator row at a time: bounds the live registers
+                }
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+}
+// Us: nslices * n_pad * n_pad bytes + 16.  nslices = 0: chosen so that n_pad * 2^(e+1-8S) <= 1e-10 (Z entries are O(1)).
+extern "C" int64_t eagle_spectral_zbuild_i8_workspace_bytes(long n_pad, int nslices) {
+    return (int64_t)((size_t)(nslices > 0 ? nslices : 7) * n_pad * n_pad + 256);
+}
+extern "C" int eagle_dev_spectral_zbuild_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Ur, double* Z, void* ws,
+                                            int nslices, void* stream) {
+    if (L_pad % T8 || n_pad % T8 || ld % 128 || n_pad > ld || nslices < 1 || nslices > 7 || (double)ld * TW_M >= 2147483648.0 ||
+        128.0 * (double)n_pad >= 2147483648.0)
+        return eagle_fail(ctx, EAGLE_ERR_ARG, "spectral_zbuild_i8: layout contract violated (L_pad % 256, n_pad % 256, 1 <= nslices <= 7)");
+    if (L_pad == 0) return EAGLE_OK;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long* maxbits = (unsigned long long*)ws;
+    int8_t* Us = (int8_t*)ws + 256;
+    hipError_t er = hipMemsetAsync(ws, 0, 256, s);
+    if (er != hipSuccess) return eagle_fail_hip(ctx, er, "zbuild_i8 memset");
+    hipLaunchKernelGGL(k_absmax_all, dim3(1024), dim3(256), 0, s, Ur, n_pad * n_pad, maxbits);
+    hipLaunchKernelGGL(k_slice_u, dim3((unsigned)(n_pad / 32), (unsigned)(n_pad / 32)), dim3(256), 0, s, Ur, n_pad, maxbits, nslices, Us);
+    if (!ctx->attr_zbuild_i8) {
+        hipError_t ea = hipFuncSetAttribute((const void*)k_zbuild_i8, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TW_ABYTES + TILE_BYTES));
+        if (ea != hipSuccess) return eagle_fail_hip(ctx, ea, "hipFuncSetAttribute(k_zbuild_i8)");
+        ctx->attr_zbuild_i8 = true;
+    }
+    const int ntm = (int)((L_pad + TW_M - 1) / TW_M), nct = (int)(n_pad / T8), ncg = (nct + 7) / 8;
+    const int mg = ((ntm + 7) / 8 + 3) / 4;  // groups of 4 marker tiles per XCD
+    hipLaunchKernelGGL(k_zbuild_i8, dim3((unsigned)(8 * mg * ncg * 32)), dim3(512), 2 * (TW_ABYTES + TILE_BYTES), s, Mt8, ld, ntm, Us, n_pad, nslices, maxbits, Z,
+                       L_pad);
+    hipError_t e2 = hipGetLastError();
+    if (e2 != hipSuccess) return eagle_fail_hip(ctx, e2, "k_zbuild_i8");
+    return EAGLE_OK;
 }
 
 __global__ __launch_bounds__(256) void k_vara_i8_finish(const long long* __restrict__ q, long Lp, const VaraHdr* __restrict__ hdr,

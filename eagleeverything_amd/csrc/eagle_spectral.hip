@@ -258,7 +258,15 @@ extern "C" int eagle_spectral_prepare(eagle_ctx* ctx, const char* f_name_ascii, 
     HIPCHK(ctx, hipMemsetAsync(Ut.p, 0, ubytes, ctx->stream));
     HIPCHK(ctx, hipMemcpy2DAsync(Ut.p, sizeof(double) * np, U, sizeof(double) * n, sizeof(double) * n, n, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = eagle_dev_transpose_f64(ctx, Ut.as<double>(), Ur.as<double>(), np, ctx->stream))) return rc;
-    if ((rc = eagle_dev_spectral_zbuild(ctx, g->dev, Lp, np, g->ld, Ur.as<double>(), ctx->d_Z, ctx->stream))) return rc;
+    if (ctx->scan_mode == 1 && 128.0 * (double)np < 2147483648.0) {
+        // default: six exact int8 digit slices of U on the int8 MFMA; |Z - Mt U| <= n 2^(e+1-48) <= n 2^-47 (|U| <= 1)
+        DevBuf ws;
+        HIPCHK(ctx, ws.alloc((size_t)eagle_spectral_zbuild_i8_workspace_bytes(np, 6)));
+        if ((rc = eagle_dev_spectral_zbuild_i8(ctx, g->dev, Lp, np, g->ld, Ur.as<double>(), ctx->d_Z, ws.p, 6, ctx->stream))) return rc;
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    } else if ((rc = eagle_dev_spectral_zbuild(ctx, g->dev, Lp, np, g->ld, Ur.as<double>(), ctx->d_Z, ctx->stream))) {  // eagle_set_scan_mode(0): fp64 MFMA
+        return rc;
+    }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->z_L = L; ctx->z_n = n;
     return EAGLE_OK;

@@ -380,6 +380,12 @@ int eagle_dev_vara_f6_mfma(eagle_ctx* ctx, const int8_t* Mt8, const void* Mt4, l
  * row-major, NC = 16 or 32 (column 0 = d o U^T y, columns 1..p = d o U^T X, the rest zero); the finish:
  * a_i = varG (lin_i0 - q_i . c1), vara_i = varG^2 (quad_i - q_i^T C q_i), q_i = lin_i[1..p], C p x p row-major, c1 p. */
 int eagle_dev_spectral_zbuild(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Ur, double* Z, void* stream);
+/* The same Z from S exact int8 digit slices of U on the int8 MFMA (the tile engine of the digit-slice scan, dense K loop, store
+ * epilogue): |Z_ik - (Mt U)_ik| <= (sum_j |m_ij|) 2^(e+1-8S), max|U| < 2^e <= 1.  ws: eagle_spectral_zbuild_i8_workspace_bytes bytes.
+ * eagle_spectral_prepare uses S = 6 (error <= n 2^-47) unless eagle_set_scan_mode(ctx, 0) asks for the fp64 form. */
+int64_t eagle_spectral_zbuild_i8_workspace_bytes(long n_pad, int nslices);
+int eagle_dev_spectral_zbuild_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Ur, double* Z, void* ws,
+                                 int nslices, void* stream);
 int eagle_dev_spectral_pass(eagle_ctx* ctx, const double* Z, long L_pad, long n_pad, const double* G, int NC, const double* d, double* lin,
                             double* quad, void* stream);
 int eagle_dev_spectral_finish(eagle_ctx* ctx, const double* lin, int NC, const double* quad, long L, long p, const double* Cm, const double* c1,

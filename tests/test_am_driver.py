@@ -169,6 +169,36 @@ def test_spectral_scan_matches_the_reference_shaped_scan(golden, tmp_path):
 
 
 @pytest.mark.gpu
+def test_spectral_zbuild_int8_slices_against_fp64():
+    """Z = Mt U from six exact int8 digit slices of U (default) against the fp64 MFMA form and against numpy, within the
+    documented bound (sum_j |m_ij|) 2^(e+1-48); ragged marker count (last 384-marker tile short), n not a multiple of 256."""
+    import ctypes as C
+    import torch
+    from eagleeverything_amd.sharded import DeviceShard
+    n, L = 1003, 5000
+    sh = DeviceShard(n, L)
+    sh.fill_synthetic(seed=9)
+    rng = np.random.default_rng(4)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    Ur = torch.zeros((sh.np_, sh.np_), dtype=torch.float64, device=sh.dev)
+    Ur[:n, :n] = torch.from_numpy(Q).to(sh.dev)
+    Z64 = torch.empty((sh.Lp, sh.np_), dtype=torch.float64, device=sh.dev)
+    Z8 = torch.full((sh.Lp, sh.np_), float("nan"), dtype=torch.float64, device=sh.dev)
+    lib, ctx = sh.L, sh.ctx
+    st = C.c_void_p(torch.cuda.current_stream(sh.dev).cuda_stream)
+    sh._check(lib.eagle_dev_spectral_zbuild(ctx, sh.Mt8.data_ptr(), sh.Lp, sh.np_, sh.np_, Ur.data_ptr(), Z64.data_ptr(), st))
+    ws = torch.empty(int(lib.eagle_spectral_zbuild_i8_workspace_bytes(sh.np_, 6)), dtype=torch.uint8, device=sh.dev)
+    sh._check(lib.eagle_dev_spectral_zbuild_i8(ctx, sh.Mt8.data_ptr(), sh.Lp, sh.np_, sh.np_, Ur.data_ptr(), Z8.data_ptr(), ws.data_ptr(), 6, st))
+    torch.cuda.synchronize()
+    ref = sh.Mt8[:L, :n].double() @ Ur[:n, :n]
+    l1 = sh.Mt8[:L, :n].abs().sum(dim=1, dtype=torch.int64).double()
+    assert torch.allclose(Z64[:L, :n], ref, rtol=0, atol=1e-12)
+    bound = l1[:, None] * 2.0 ** (0 + 1 - 48) + 1e-13                # e <= 0 for an orthogonal matrix
+    assert bool(((Z8[:L, :n] - ref).abs() <= bound).all())
+    assert bool((Z8[L:, :] == 0).all()) and bool((Z8[:, n:] == 0).all())  # padding rows / columns come out as exact zeros
+
+
+@pytest.mark.gpu
 def test_am_spectral_backend_selects_the_same_markers(golden, tmp_path):
     g = golden("genoDemo_150x4998")
     geno = synth.write_geno_pair(str(tmp_path), np.ascontiguousarray(g["M8"].T))
