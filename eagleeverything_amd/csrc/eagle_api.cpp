@@ -708,6 +708,13 @@ int eagle_get_resident(eagle_ctx* ctx, const char* path, long rows, long cols, d
     *out = g;
     return rc;
 }
+int eagle_get_resident_window(eagle_ctx* ctx, const char* path, long row0, long rows, long col0, long cols, double max_mem_gb, int threads,
+                              const GenoEntry** out) {
+    GenoEntry* g = nullptr;
+    int rc = get_resident(ctx, path, row0, rows, col0, cols, max_mem_gb, threads, &g);
+    *out = g;
+    return rc;
+}
 size_t eagle_resident_budget() { return resident_budget(); }
 
 // Rows (multiple of 256) of a streamed chunk whose padded row length is `row_bytes`.
@@ -1423,5 +1430,39 @@ extern "C" int eagle_calculate_reduced_a(eagle_ctx* ctx, const char* f_name_asci
     split_markers(L, nd, edge);
     return run_on_devices(ctx, [&](int k, eagle_ctx* c) -> int {
         return reduced_a_range(c, f_name_ascii, n, L, edge[k], edge[k + 1], sel, varG, P, y, max_memory_in_Gbytes, ar_out);
+    });
+}
+
+// ------------------------------------------------------------------------------------------------
+// The scan in the eigenbasis of MM^T (include/eagle_hip.h section 1d; kernels and per-device work in eagle_spectral.hip): the
+// markers -- and with them Z = Mt U -- split over the devices of the context like everywhere else; no exchange step at all.
+// ------------------------------------------------------------------------------------------------
+extern "C" int eagle_spectral_prepare(eagle_ctx* ctx, const char* f_name_ascii, const long dims[2], const double* U, double max_memory_in_Gbytes) {
+    if (!ctx || !f_name_ascii || !U) return EAGLE_ERR_ARG;
+    const long L = dims[0], n = dims[1];
+    if (L <= 0 || n <= 0) return eagle_fail(ctx, EAGLE_ERR_ARG, "bad dims");
+    const int nd = ndev_of(ctx);
+    std::vector<long> edge;
+    split_markers(L, nd, edge);
+    int rc = run_on_devices(ctx, [&](int k, eagle_ctx* c) -> int {
+        return eagle_spectral_prepare_range(c, f_name_ascii, L, n, edge[k], edge[k + 1], U, max_memory_in_Gbytes);
+    });
+    ctx->spectral_L = rc ? 0 : L;
+    return rc;
+}
+extern "C" int eagle_spectral_scan(eagle_ctx* ctx, const double* lambda, const double* UtX, const double* Uty, long p, double varE, double varG,
+                                   const double* selected_loci, long n_selected, double* a_out, double* vara_out) {
+    if (!ctx || !lambda || !UtX || !Uty || !a_out || !vara_out) return EAGLE_ERR_ARG;
+    if (ctx->spectral_L <= 0) return eagle_fail(ctx, EAGLE_ERR_ARG, "spectral_scan: eagle_spectral_prepare has not run");
+    if (p < 1 || p > 31) return eagle_fail(ctx, EAGLE_ERR_ARG, "spectral_scan: 1 <= p <= 31 fixed-effect columns");
+    const long L = ctx->spectral_L, n = ctx->z_n, np = eagle_pad(n);
+    std::vector<long> sel;
+    int rc = parse_selected(ctx, selected_loci, n_selected, L, sel);
+    if (rc) return rc;
+    const int NC = p + 1 <= 16 ? 16 : 32;
+    std::vector<double> d(np), G((size_t)np * NC), Cm((size_t)p * p), c1(p);
+    if ((rc = eagle_spectral_host_operands(ctx, n, lambda, UtX, Uty, p, varE, varG, NC, d.data(), G.data(), Cm.data(), c1.data()))) return rc;
+    return run_on_devices(ctx, [&](int, eagle_ctx* c) -> int {
+        return eagle_spectral_scan_range(c, d.data(), G.data(), NC, Cm.data(), c1.data(), p, varG, sel.data(), (long)sel.size(), a_out, vara_out);
     });
 }

@@ -61,7 +61,7 @@ struct eagle_ctx {
     // multi-device: the ctx eagle_open_devices returns is the LEAD (first device); it owns one sub-context per further device.
     std::vector<eagle_ctx*> peers;
     eagle_ctx* lead = nullptr;           // set in sub-contexts
-    double* d_Z = nullptr; long z_L = 0, z_n = 0;  // Z = Mt U of the opt-in spectral scan (eagle_spectral.hip), L_pad x n_pad fp64
+    double* d_Z = nullptr; long z_L = 0, z_n = 0, z_first = 0; long spectral_L = 0;  // Z = Mt U of the opt-in spectral scan (eagle_spectral.hip), L_pad x n_pad fp64
     void* blas_handle = nullptr;         // rocblas_handle of the opt-in device model algebra (eagle_linalg.cpp)
     void* rccl = nullptr;                // RcclState* of the lead (communicators, one per device), or NULL: host-staged sums
     long scan_first = 0;                 // global index of the first marker of this device's last scan
@@ -161,5 +161,8 @@ extern "C" int eagle_dev_unpack2b(eagle_ctx* ctx, const uint8_t* raw, long rows,
 inline bool eagle_sidecar_enabled() { const char* e = getenv("EAGLE_HIP_SIDECAR"); return !(e && e[0] == '0'); }
 // Whole-file resident copy (loads it if needed); EAGLE_OK, 2 (too large for HBM: stream it) or an error.
 int eagle_get_resident(eagle_ctx* ctx, const char* path, long rows, long cols, double max_mem_gb, int threads, const GenoEntry** out);
+// The same for the window [row0, row0+rows) x [col0, col0+cols) of the file (a marker shard of a multi-device context).
+int eagle_get_resident_window(eagle_ctx* ctx, const char* path, long row0, long rows, long col0, long cols, double max_mem_gb, int threads,
+                              const GenoEntry** out);
 size_t eagle_resident_budget();
 #endif

@@ -38,6 +38,11 @@ int eagle_dev_transpose_f64(eagle_ctx* ctx, const double* in, double* out, long 
 int eagle_dev_dot_matrices(eagle_ctx* ctx, const double* A, long lda, const double* B, long ldb, long n, double* out, void* stream);
 void eagle_linalg_release(eagle_ctx* ctx);
 void eagle_spectral_release(eagle_ctx* ctx);
+int eagle_spectral_prepare_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, long m0, long m1, const double* U, double max_memory_in_Gbytes);
+int eagle_spectral_host_operands(eagle_ctx* ctx, long n, const double* lambda, const double* UtX, const double* Uty, long p, double varE, double varG,
+                                 int NC, double* d, double* G, double* Cm, double* c1);
+int eagle_spectral_scan_range(eagle_ctx* ctx, const double* d, const double* G, int NC, const double* Cm, const double* c1, long p, double varG,
+                              const long* sel, long nsel, double* a_out, double* vara_out);
 int eagle_dev_extract_col(eagle_ctx* ctx, const int8_t* M8, long n, long ld, long col, int* out, void* stream);
 #ifdef __cplusplus
 }

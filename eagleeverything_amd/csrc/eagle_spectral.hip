@@ -235,17 +235,20 @@ extern "C" void eagle_spectral_release(eagle_ctx* ctx) {
     ctx->z_L = ctx->z_n = 0;
 }
 
-extern "C" int eagle_spectral_prepare(eagle_ctx* ctx, const char* f_name_ascii, const long dims[2], const double* U, double max_memory_in_Gbytes) {
-    if (!ctx || !f_name_ascii || !U) return EAGLE_ERR_ARG;
-    const long L = dims[0], n = dims[1];
-    if (L <= 0 || n <= 0) return eagle_fail(ctx, EAGLE_ERR_ARG, "bad dims");
+// Z of the markers [m0, m1) of Mt.ascii on ctx's device (the whole file on one device; a marker range per device of a
+// multi-device context: Z shards by markers exactly like the genotypes).
+extern "C" int eagle_spectral_prepare_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, long m0, long m1, const double* U,
+                                            double max_memory_in_Gbytes) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    const long np = eagle_pad(n), Lp = eagle_pad(L);
-    const GenoEntry* g = nullptr;
-    int rc = eagle_get_resident(ctx, f_name_ascii, L, n, max_memory_in_Gbytes, host_threads(), &g);
-    if (rc < 0) return rc;
-    if (rc != EAGLE_OK || !g) return eagle_fail(ctx, EAGLE_ERR_NOMEM, "spectral_prepare: the genotype file must fit in HBM next to Z (8 bytes per genotype)");
     eagle_spectral_release(ctx);
+    const long Lr = m1 - m0;
+    ctx->z_first = m0;
+    if (Lr <= 0) { ctx->z_L = 0; ctx->z_n = n; return EAGLE_OK; }
+    const long np = eagle_pad(n), Lp = eagle_pad(Lr);
+    const GenoEntry* g = nullptr;
+    int rc = eagle_get_resident_window(ctx, f_name_ascii, m0, Lr, 0, n, max_memory_in_Gbytes, host_threads(), &g);
+    if (rc < 0) return rc;
+    if (rc != EAGLE_OK || !g) return eagle_fail(ctx, EAGLE_ERR_NOMEM, "spectral_prepare: the genotype shard must fit in HBM next to Z (8 bytes per genotype)");
     size_t freeb = 0, totalb = 0;
     HIPCHK(ctx, hipMemGetInfo(&freeb, &totalb));
     const size_t zbytes = sizeof(double) * (size_t)Lp * np, ubytes = sizeof(double) * (size_t)np * np;
@@ -268,7 +271,7 @@ extern "C" int eagle_spectral_prepare(eagle_ctx* ctx, const char* f_name_ascii, 
         return rc;
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->z_L = L; ctx->z_n = n;
+    ctx->z_L = Lr; ctx->z_n = n;
     return EAGLE_OK;
 }
 
@@ -306,25 +309,13 @@ static bool small_spd_inverse(std::vector<long double>& A, int p) {
     return true;
 }
 
-extern "C" int eagle_spectral_scan(eagle_ctx* ctx, const double* lambda, const double* UtX, const double* Uty, long p, double varE, double varG,
-                                   const double* selected_loci, long n_selected, double* a_out, double* vara_out) {
-    if (!ctx || !lambda || !UtX || !Uty || !a_out || !vara_out) return EAGLE_ERR_ARG;
-    if (!ctx->d_Z || ctx->z_L <= 0) return eagle_fail(ctx, EAGLE_ERR_ARG, "spectral_scan: eagle_spectral_prepare has not run");
-    if (p < 1 || p > 31) return eagle_fail(ctx, EAGLE_ERR_ARG, "spectral_scan: 1 <= p <= 31 fixed-effect columns");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    const long L = ctx->z_L, n = ctx->z_n, np = eagle_pad(n), Lp = eagle_pad(L);
-    std::vector<long> sel;
-    if (n_selected > 0 && selected_loci && !isnan(selected_loci[0])) {  // the reference's rule: masking fires iff element 0 is not NA
-        for (long i = 0; i < n_selected; i++) {
-            if (isnan(selected_loci[i])) return eagle_fail(ctx, EAGLE_ERR_ARG, "NA in selected_loci after element 0");
-            const long v = (long)selected_loci[i];
-            if (v < 0 || v >= L) return eagle_fail(ctx, EAGLE_ERR_ARG, "selected_loci index out of range");
-            sel.push_back(v);
-        }
-    }
-    const int NC = p + 1 <= 16 ? 16 : 32;
-    // host: d, G = [d o U^T y | d o U^T X], C = (X^T H^-1 X)^-1 = (UtX^T D UtX)^-1, c1 = C (UtX^T D Uty)
-    std::vector<double> d(np, 0.0), G((size_t)np * NC, 0.0);
+// Host side of a scan, once per call whatever the number of devices: d, G = [d o U^T y | d o U^T X] (n_pad x NC row-major),
+// C = (X^T H^-1 X)^-1 = (UtX^T D UtX)^-1, c1 = C (UtX^T D Uty).
+extern "C" int eagle_spectral_host_operands(eagle_ctx* ctx, long n, const double* lambda, const double* UtX, const double* Uty, long p, double varE,
+                                            double varG, int NC, double* d, double* G, double* Cm, double* c1) {
+    const long np = eagle_pad(n);
+    memset(d, 0, sizeof(double) * np);
+    memset(G, 0, sizeof(double) * (size_t)np * NC);
     for (long k = 0; k < n; k++) {
         const double h = varE + varG * lambda[k];
         if (!(h > 0.0)) return eagle_fail(ctx, EAGLE_ERR_ARG, "spectral_scan: varE + varG * lambda must be positive");
@@ -345,38 +336,49 @@ extern "C" int eagle_spectral_scan(eagle_ctx* ctx, const double* lambda, const d
         bvec[j] = s;
     }
     if (!small_spd_inverse(A, (int)p)) return eagle_fail(ctx, EAGLE_ERR_ARG, "spectral_scan: X^T H^-1 X is not positive definite (collinear fixed effects)");
-    std::vector<double> Cm((size_t)p * p), c1(p);
     for (long j = 0; j < p; j++) {
         long double s = 0.0L;
         for (long l = 0; l < p; l++) { Cm[(size_t)j * p + l] = (double)A[(size_t)j * p + l]; s += A[(size_t)j * p + l] * bvec[l]; }
         c1[j] = (double)s;
     }
+    return EAGLE_OK;
+}
+
+// One device's pass over its shard of Z; results into a_out / vara_out at the shard's global marker positions.
+extern "C" int eagle_spectral_scan_range(eagle_ctx* ctx, const double* d, const double* G, int NC, const double* Cm, const double* c1, long p,
+                                         double varG, const long* sel, long nsel, double* a_out, double* vara_out) {
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const long L = ctx->z_L, n = ctx->z_n, m0 = ctx->z_first;
+    if (L <= 0) return EAGLE_OK;
+    const long np = eagle_pad(n), Lp = eagle_pad(L);
     DevBuf dG, dd, dC, dc1, dlin, dquad, da, dv, dsel;
-    HIPCHK(ctx, dG.alloc(sizeof(double) * G.size()));
+    HIPCHK(ctx, dG.alloc(sizeof(double) * (size_t)np * NC));
     HIPCHK(ctx, dd.alloc(sizeof(double) * np));
-    HIPCHK(ctx, dC.alloc(sizeof(double) * Cm.size()));
+    HIPCHK(ctx, dC.alloc(sizeof(double) * (size_t)p * p));
     HIPCHK(ctx, dc1.alloc(sizeof(double) * p));
     HIPCHK(ctx, dlin.alloc(sizeof(double) * (size_t)Lp * NC));
     HIPCHK(ctx, dquad.alloc(sizeof(double) * Lp));
     HIPCHK(ctx, da.alloc(sizeof(double) * Lp));
     HIPCHK(ctx, dv.alloc(sizeof(double) * Lp));
-    HIPCHK(ctx, hipMemcpyAsync(dG.p, G.data(), sizeof(double) * G.size(), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(dd.p, d.data(), sizeof(double) * np, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(dC.p, Cm.data(), sizeof(double) * Cm.size(), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(dc1.p, c1.data(), sizeof(double) * p, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dG.p, G, sizeof(double) * (size_t)np * NC, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dd.p, d, sizeof(double) * np, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dC.p, Cm, sizeof(double) * (size_t)p * p, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(dc1.p, c1, sizeof(double) * p, hipMemcpyHostToDevice, ctx->stream));
     int rcs = eagle_dev_spectral_pass(ctx, ctx->d_Z, Lp, np, dG.as<double>(), NC, dd.as<double>(), dlin.as<double>(), dquad.as<double>(), ctx->stream);
     if (rcs) return rcs;
     if ((rcs = eagle_dev_spectral_finish(ctx, dlin.as<double>(), NC, dquad.as<double>(), L, p, dC.as<double>(), dc1.as<double>(), varG, da.as<double>(),
                                          dv.as<double>(), ctx->stream)))
         return rcs;
-    if (!sel.empty()) {
-        HIPCHK(ctx, dsel.alloc(sizeof(long) * sel.size()));
-        HIPCHK(ctx, hipMemcpyAsync(dsel.p, sel.data(), sizeof(long) * sel.size(), hipMemcpyHostToDevice, ctx->stream));
-        int rc = eagle_dev_zero_rows(ctx, da.as<double>(), dv.as<double>(), L, dsel.as<long>(), (long)sel.size(), 0, ctx->stream);
+    std::vector<long> in_range;
+    for (long i = 0; i < nsel; i++) if (sel[i] >= m0 && sel[i] < m0 + L) in_range.push_back(sel[i] - m0);
+    if (!in_range.empty()) {
+        HIPCHK(ctx, dsel.alloc(sizeof(long) * in_range.size()));
+        HIPCHK(ctx, hipMemcpyAsync(dsel.p, in_range.data(), sizeof(long) * in_range.size(), hipMemcpyHostToDevice, ctx->stream));
+        int rc = eagle_dev_zero_rows(ctx, da.as<double>(), dv.as<double>(), L, dsel.as<long>(), (long)in_range.size(), 0, ctx->stream);
         if (rc) return rc;
     }
-    HIPCHK(ctx, hipMemcpyAsync(a_out, da.p, sizeof(double) * L, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(vara_out, dv.p, sizeof(double) * L, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(a_out + m0, da.p, sizeof(double) * L, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(vara_out + m0, dv.p, sizeof(double) * L, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return EAGLE_OK;
 }

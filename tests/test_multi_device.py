@@ -91,6 +91,43 @@ def test_contexts_sharing_one_card_reproduce_the_single_device_results(devices, 
     api.drop_cache(device=devices)
 
 
+def test_spectral_scan_over_two_contexts(api, tmp_path):
+    """The opt-in scan in the eigenbasis of MM^T (header section 1d) over a multi-device context: Z shards by markers, no
+    exchange step; a and vara bit for bit as from one device, masking rule included."""
+    n, L = 300, 5000
+    rng = np.random.default_rng(12)
+    Mt8 = synth.genotypes_marker_major(n, L, seed=5)
+    geno = synth.write_geno_pair(str(tmp_path), Mt8)
+    G = Mt8.astype(np.float64)
+    K = G.T @ G
+    K = K / K.max() + 0.95 * np.eye(n)
+    lam, U = np.linalg.eigh(K)
+    X = np.column_stack([np.ones(n), Mt8[[10, 4000]].T.astype(np.float64)])
+    y = rng.standard_normal(n)
+    sel = np.array([3.0, 4500.0])
+    out = {}
+    for dev in (0, (0, 0)):
+        api.spectral_prepare(geno["asciifileMt"], (L, n), U, 8.0, device=dev)
+        out[dev] = (api.spectral_scan(lam, U.T @ X, U.T @ y, 0.8, 0.6, L, device=dev),
+                    api.spectral_scan(lam, U.T @ X, U.T @ y, 0.8, 0.6, L, selected_loci=sel, device=dev))
+        api.drop_cache(device=dev)
+    for a, b in zip(out[0], out[(0, 0)]):
+        np.testing.assert_array_equal(a["a"], b["a"])
+        np.testing.assert_array_equal(a["vara"], b["vara"])
+    masked = out[(0, 0)][1]
+    assert masked["a"][3, 0] == 0.0 and masked["vara"][4500, 0] == 0.0
+    # against the definition: a_i = varG m_i^T P y, vara_i = varG^2 m_i^T P m_i
+    H = 0.8 * np.eye(n) + 0.6 * K
+    Hi = np.linalg.inv(H)
+    P = Hi - Hi @ X @ np.linalg.solve(X.T @ Hi @ X, X.T @ Hi)
+    rows = np.r_[0:50, 2500:2600, L - 50:L]
+    rows = rows[~np.isin(rows, [10, 4000])]            # markers in the model: masked values (a = vara = 0)
+    M = G[rows]
+    np.testing.assert_allclose(out[(0, 0)][0]["a"].ravel()[rows], 0.6 * (M @ (P @ y)), rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(out[(0, 0)][0]["vara"].ravel()[rows], 0.36 * np.einsum("ij,jk,ik->i", M, P, M), rtol=1e-8)
+    assert out[0][0]["a"][10, 0] == 0.0 and out[0][0]["vara"][4000, 0] == 0.0
+
+
 def test_multi_device_streamed_shards(api, oracle, tmp_path, monkeypatch):
     """Shards that may not stay resident are streamed per device; MM^T stays exact, a identical, vara identical except where a
     block's own certification re-evaluated a few more markers in fp64, the selected marker identical."""
