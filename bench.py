@@ -53,7 +53,6 @@ def host_operands_torch(torch, MMt_norm, X, y, varE, varG):
     HX = Hinv @ X
     P = Hinv - HX @ torch.linalg.solve(X.T @ HX, HX.T)
     ev, U = torch.linalg.eigh(MMt_norm)
-    host_operands_torch.eig = (ev, U)  # kept for the spectral-scan secondary entry (section 1d of the header)
     sq = (U * ev.sqrt()) @ U.T
     sq = 0.5 * (sq + sq.T)
     S = torch.cholesky_inverse(torch.linalg.cholesky(sq))
@@ -64,7 +63,7 @@ def host_operands_torch(torch, MMt_norm, X, y, varE, varG):
     D1 = torch.cholesky_inverse(torch.linalg.cholesky(r1 * (sq.T @ sq) + g1 * I))  # D is SPD
     D1C = D1 @ B.T
     V = varG * I - (D1 + D1C @ torch.linalg.solve(A - B @ D1C, B @ D1))
-    return S, V, ahat, P
+    return S, V, ahat, P, (ev, U)  # P and the eigen-decomposition feed the opt-in secondary entries (scan_with_W, spectral scan)
 
 
 class Run:
@@ -147,9 +146,9 @@ class Run:
                 V = 0.5 * torch.eye(n, dtype=torch.float64, device=self.dev) - 0.01 * (A[:, :8] @ A[:, :8].T)
                 ahat = torch.randn(n, generator=gen, device=self.dev, dtype=torch.float64)
             else:
-                S, V, ahat, P = host_operands_torch(torch, MMt, X, y, 1.0, 0.5)
+                S, V, ahat, P, self.eig = host_operands_torch(torch, MMt, X, y, 1.0, 0.5)
                 self.W_direct, self.v_direct = 0.25 * P, 0.5 * (P @ y)  # varG^2 P and varG P y: what eagle_scan_with_W takes
-                self.eig, self.Xy = host_operands_torch.eig, (X, y)
+                self.Xy = (X, y)
         else:
             S = torch.empty((n, n), dtype=torch.float64, device=self.dev)
             V = torch.empty((n, n), dtype=torch.float64, device=self.dev)
