@@ -237,7 +237,7 @@ def vara_roofline(sh, kern_s, S_used):
     else:
         nct8 = np_ // 256
         ops = sum(2.0 * Lp * 256 * min((ct + 1) * 256, np_) for ct in range(nct8)) * S_used
-        roof = {"bound": "mfma", "kernel": "k_vara_i8 (v_mfma_i32_32x32x32_i8, %d digit slices)" % S_used, "dtype": "i8",
+        roof = {"bound": "mfma", "kernel": "k_vara_i8p (v_mfma_i32_32x32x32_i8, %d digit slices)" % S_used, "dtype": "i8",
                 "achieved": ops / kern_s / 1e12, "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s"}
     roof["frac"] = roof["achieved"] / roof["peak"]
     roof["kernel_ms"] = kern_s * 1e3

@@ -675,23 +675,6 @@ __device__ __forceinline__ void tw_kstep(i32x16 (&acc)[3][4], const int8_t* pa, 
 #pragma unroll
         for (int n = 0; n < 4; n++) acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b[n], acc[m][n], 0, 0, 0);
 }
-// the same k-step with a hook after each of its three MFMA rows (DMA loads of the next stage go there)
-template <class F>
-__device__ __forceinline__ void tw_kstep_rows(i32x16 (&acc)[3][4], const int8_t* pa, const int8_t* pb, int ch, F&& after_row) {
-    i32x4 a[3], b[4];
-#pragma unroll
-    for (int m = 0; m < 3; m++) a[m] = *(const i32x4*)(pa + m * (32 * BK8) + ch);
-#pragma unroll
-    for (int n = 0; n < 4; n++) b[n] = *(const i32x4*)(pb + n * (32 * BK8) + ch);
-#pragma unroll
-    for (int m = 0; m < 3; m++) {
-#pragma unroll
-        for (int n = 0; n < 4; n++) acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b[n], acc[m][n], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        after_row(m);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
 // `groups` row groups (8 rows each) of an operand tile per wave: wave w issues groups w*groups .. (groups is even)
 template <int GROUPS>
 __device__ __forceinline__ void tw_stage(__amdgpu_buffer_rsrc_t rs, const T8Lane& ln, int ld, int k0, int8_t* ldsTile, int w) {
@@ -702,16 +685,6 @@ __device__ __forceinline__ void tw_stage(__amdgpu_buffer_rsrc_t rs, const T8Lane
                                                  (i & 1) ? ln.voffO : ln.voffE, grp * 8 * ld + k0, 0, 0);
     }
 }
-template <int G0, int G1, int GPW>
-__device__ __forceinline__ void tw_stage_part(__amdgpu_buffer_rsrc_t rs, const T8Lane& ln, int ld, int k0, int8_t* ldsTile, int w) {
-#pragma unroll
-    for (int i = G0; i < G1; i++) {
-        const int grp = w * GPW + i;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(ldsTile + grp * 1024), 16,
-                                                 (i & 1) ? ln.voffO : ln.voffE, grp * 8 * ld + k0, 0, 0);
-    }
-}
-template <int SPREAD>
 __global__ __launch_bounds__(512, 2) void k_vara_i8w(const int8_t* __restrict__ Mt8, long ld, int ntm, const int8_t* __restrict__ Bs,
                                                      long np, const VaraHdr* __restrict__ hdr, long long* __restrict__ q, long Lp, int cut_last_round) {
     extern __shared__ __attribute__((aligned(1024))) int8_t ldsv[];  // [2][A 48 KiB | B 32 KiB]
@@ -725,7 +698,7 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8w(const int8_t* __restrict__ 
     // 5.1 rounds: 6 worker-times without the cut, 5.2 with it).  Integer atomics into q: the result does not change.
     const int groups = (ntm + 7) >> 3, wx = groups * nslices, full = (wx >> 5) << 5, tail = wx - full;
     int psplit = 1;
-    if ((cut_last_round & 1) && tail > 0 && tail <= 16) { psplit = 32 / tail; if (psplit > npair) psplit = npair; }
+    if (cut_last_round && tail > 0 && tail <= 16) { psplit = 32 / tail; if (psplit > npair) psplit = npair; }
     int worker = slot, piece = 0;
     if (slot >= full) { const int u = slot - full; worker = full + u / psplit; piece = u - (u / psplit) * psplit; }
     else psplit = 1;  // only the workers of the last round are cut
@@ -771,8 +744,6 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8w(const int8_t* __restrict__ 
     int buf = 0;
     while (cur.valid) {
         const int8_t* st = ldsv + buf * (TW_ABYTES + TILE_BYTES);
-        constexpr int spread = SPREAD;  // experiment: the next stage's DMA issued in parts between the k-steps
-        if constexpr (spread == 0) {
         if (nxt.valid) {
             int8_t* nx = ldsv + (buf ^ 1) * (TW_ABYTES + TILE_BYTES);
             tw_stage<6>(rsA, lnA, ldi, nxt.kt * BK8, nx, w);
@@ -781,56 +752,6 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8w(const int8_t* __restrict__ 
         }
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) tw_kstep(acc, st + offA, st + offB, ch[ks]);
-        } else {
-            const bool on = nxt.valid;
-            int8_t* nx = ldsv + (buf ^ 1) * (TW_ABYTES + TILE_BYTES);
-            const int k0 = nxt.kt * BK8;
-            const __amdgpu_buffer_rsrc_t rsB = t8_rsrc(Bsl + (long)nxt.ct * T8 * np, npi);
-            if constexpr (spread >= 4) {
-                // load j of the wave's ten (A 0-5, B 6-9), one at a time
-                auto one = [&](int j) {
-                    if (!on) return;
-                    const bool isA = j < 6;
-                    const int i = isA ? j : j - 6, grp = w * (isA ? 6 : 4) + i;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? rsA : rsB, (__attribute__((address_space(3))) void*)(nx + (isA ? 0 : TW_ABYTES) + grp * 1024), 16,
-                                                             (i & 1) ? (isA ? lnA.voffO : lnB.voffO) : (isA ? lnA.voffE : lnB.voffE),
-                                                             grp * 8 * (isA ? ldi : npi) + k0, 0, 0);
-                };
-                if constexpr (spread == 4) {  // one after every MFMA row of k-steps 0-2, the tenth after the first row of k-step 3
-                    tw_kstep_rows(acc, st + offA, st + offB, ch[0], [&](int m) { one(m); });
-                    tw_kstep_rows(acc, st + offA, st + offB, ch[1], [&](int m) { one(3 + m); });
-                    tw_kstep_rows(acc, st + offA, st + offB, ch[2], [&](int m) { one(6 + m); });
-                    tw_kstep_rows(acc, st + offA, st + offB, ch[3], [&](int m) { if (m == 0) one(9); });
-                } else {  // two after every row of k-step 0, then one after every row of k-step 1 and the tenth in k-step 2
-                    tw_kstep_rows(acc, st + offA, st + offB, ch[0], [&](int m) { one(2 * m); one(2 * m + 1); });
-                    tw_kstep_rows(acc, st + offA, st + offB, ch[1], [&](int m) { one(6 + m); });
-                    tw_kstep_rows(acc, st + offA, st + offB, ch[2], [&](int m) { if (m == 0) one(9); });
-                    tw_kstep(acc, st + offA, st + offB, ch[3]);
-                }
-                if (on) vit_advance(nxt, nct, pair1);
-            } else {
-            if (on) {
-                if (spread == 1) tw_stage<6>(rsA, lnA, ldi, k0, nx, w);
-                else if (spread == 2) tw_stage_part<0, 3, 6>(rsA, lnA, ldi, k0, nx, w);
-                else { tw_stage_part<0, 4, 6>(rsA, lnA, ldi, k0, nx, w); }
-            }
-            tw_kstep(acc, st + offA, st + offB, ch[0]);
-            if (on) {
-                if (spread == 1) tw_stage<4>(rsB, lnB, npi, k0, nx + TW_ABYTES, w);
-                else if (spread == 2) tw_stage_part<3, 6, 6>(rsA, lnA, ldi, k0, nx, w);
-                else { tw_stage_part<4, 6, 6>(rsA, lnA, ldi, k0, nx, w); tw_stage_part<0, 2, 4>(rsB, lnB, npi, k0, nx + TW_ABYTES, w); }
-            }
-            tw_kstep(acc, st + offA, st + offB, ch[1]);
-            if (on) {
-                if (spread == 2) tw_stage_part<0, 2, 4>(rsB, lnB, npi, k0, nx + TW_ABYTES, w);
-                else if (spread == 3) tw_stage_part<2, 4, 4>(rsB, lnB, npi, k0, nx + TW_ABYTES, w);
-            }
-            tw_kstep(acc, st + offA, st + offB, ch[2]);
-            if (on && spread == 2) tw_stage_part<2, 4, 4>(rsB, lnB, npi, k0, nx + TW_ABYTES, w);
-            tw_kstep(acc, st + offA, st + offB, ch[3]);
-            if (on) vit_advance(nxt, nct, pair1);
-            }
-        }
         if (cur.kt == cur.nk - 1) {
             const int ecol = cur.ct * T8;
             const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
@@ -875,52 +796,55 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8w(const int8_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_vara_i8x (experiment, tune 10): the 384 x 256 tile with FOUR waves (2 x 2), one per SIMD, wave tile 192 x 128 = 6 x 4 MFMA
-// tiles = 384 accumulator registers: rows 0-3 (256) in AGPRs, rows 4-5 (128) in VGPRs.  10 fragment reads per 24 MFMAs instead
-// of 7 per 12 (-29 % LDS reads per MAC).  hipcc cannot allocate this (with more than 256 registers per wave it selects the AGPR
-// form for every MFMA and copies the rest through scratch), so a k-step is two inline-asm blocks with the register classes
-// spelled out.  One wave per SIMD has nobody to hide behind, so the fragment reads are software pipelined inside the blocks:
-// every fragment register is re-loaded for the NEXT k-step as soon as its last MFMA of this k-step has issued.  Order in a
-// k-step: rows 0-2 column-major (#1-#12), rows 3-5 column-major (#13-#24); a0-a2 are released at #10-#12, b_n at #15+3n,
-// a3-a5 at #22-#24 -- each re-load is issued >= 10 MFMAs (320 cycles) before its first use.  LDS returns in order, so the
-// waits are counted (issue order of the re-loads: a0 a1 a2 b0 b1 b2 a3 a4 b3 a5).  An MFMA reads its A/B sources as it issues
-// and LDS data returns tens of cycles later, so re-loading a source register right behind the MFMA is safe.
-// The first k-step of a tile uses the inline constant 0 as the C operand: no zeroing pass.
-// The stage's last k-step holds the barrier after MFMA #10 (before its first re-load, which reads the other buffer): the
-// matrix pipe is busy while the four waves meet, and the DMA of the stage after next is issued right behind the barrier.
+// k_vara_i8p: k_vara_i8w (384 x 256 tile, 8 waves 4 x 2, wave tile 96 x 128 = 3 x 4 MFMA tiles) with the k-step written as
+// inline asm so that LDS reads, LDS-DMA loads and MFMAs overlap inside ONE wave.  hipcc's schedule of the k-step is "7 fragment
+// reads, wait, 12 MFMAs"; the two waves of a SIMD advance in step (they alternate on the matrix pipe), so both sit in the
+// read phase together: 56 KiB of fragment reads per k-step = 450 cycles of the LDS pipe against 770 cycles of MFMA, unhidden.
+// Here a k-step issues, between its own MFMAs, the fragment reads of the NEXT k-step:
+//   * MFMA order column-major (column n = W-digit fragment b_n): b_n is re-loaded in place when its column is done, 9 MFMAs
+//     before its next use; the genotype fragments are double-buffered (a / an, +12 VGPRs), loaded 11 MFMAs ahead;
+//   * LDS returns in order, so the waits are counted (issue order per k-step: an0 an1 b0 an2 b1 b2 b3).  An MFMA reads its A/B
+//     sources as it issues and LDS data comes back tens of cycles later, so re-loading a source register right behind the last
+//     MFMA that reads it is safe;
+//   * the next stage's ten LDS-DMA loads per wave go out one at a time behind every second MFMA (3 behind the barrier, 6 in
+//     the next k-step, the last in the one after) instead of as a burst at the top of the stage (the burst alone costs 3-4 %, tune 11-15 experiments);
+//   * the first k-step of a tile uses the inline constant 0 as the C operand: no zeroing pass;
+//   * the stage barrier sits in the middle of the last k-step (after 6 of its 12 MFMAs: all fragment reads of this stage have
+//     returned; the re-loads behind the barrier read the other buffer), so each wave reaches it with matrix work in flight.
 // ------------------------------------------------------------------------------------------------
 #define X_MF(c, a, b) "v_mfma_i32_32x32x32_i8 %[" #c "], %[" #a "], %[" #b "], %[" #c "]\n\t"
 #define X_MZ(c, a, b) "v_mfma_i32_32x32x32_i8 %[" #c "], %[" #a "], %[" #b "], 0\n\t"
 #define X_LD(d, p, off) "ds_read_b128 %[" #d "], %[" #p "] offset:" #off "\n\t"
 #define X_WT(n) "s_waitcnt lgkmcnt(" #n ")\n\t"
-// one LDS-DMA load of the stage being fetched: next row group (LDS +1 KiB, source + 8 rows), even / odd group lane offsets
-#define X_DM(vo) "s_add_u32 m0, m0, 0x400\n\ts_add_u32 %[so], %[so], %[st]\n\tbuffer_load_dwordx4 %[" #vo "], %[rs], %[so] offen lds\n\t"
-#define X_NO(vo)
-#define X_M0_IN "s_mov_b32 m0, %[m0v]\n\t"
-#define X_M0_OUT "s_mov_b32 %[m0v], m0\n\t"
-// rows 0-2, MFMAs #1..#10 (M = X_MF or X_MZ; D = X_DM or X_NO)
-#define X_P1_HEAD(M, D)                                                                                              \
-    X_WT(6) M(c00, a0, b0) M(c10, a1, b0) M(c20, a2, b0) D(vE) X_WT(5) M(c01, a0, b1) M(c11, a1, b1) M(c21, a2, b1) D(vO) \
-    X_WT(4) M(c02, a0, b2) M(c12, a1, b2) M(c22, a2, b2) D(vE) X_WT(1) M(c03, a0, b3)
-// #11, #12 with the re-loads of a0-a2
-#define X_P1_TAIL(M, D) X_LD(a0, pa, 0) M(c13, a1, b3) X_LD(a1, pa, 4096) M(c23, a2, b3) X_LD(a2, pa, 8192) D(vO)
-// rows 3-5, #13..#24 with the re-loads of b0-b3, a3-a5
-#define X_P2(M, D)                                                                                    \
-    M(c30, a3, b0) M(c40, a4, b0) X_WT(3) M(c50, a5, b0) X_LD(b0, pb, 0) D(vE)                        \
-    M(c31, a3, b1) M(c41, a4, b1) M(c51, a5, b1) X_LD(b1, pb, 4096) D(vO)                             \
-    M(c32, a3, b2) M(c42, a4, b2) M(c52, a5, b2) X_LD(b2, pb, 8192) D(vE)                             \
-    M(c33, a3, b3) X_LD(a3, pa, 12288) M(c43, a4, b3) X_LD(a4, pa, 16384) M(c53, a5, b3) X_LD(b3, pb, 12288) X_LD(a5, pa, 20480) D(vO)
-#define X_ROW_A(m) [c##m##0] "+a"(c[m][0]), [c##m##1] "+a"(c[m][1]), [c##m##2] "+a"(c[m][2]), [c##m##3] "+a"(c[m][3])
-#define X_ROW_V(m) [c##m##0] "+v"(c[m][0]), [c##m##1] "+v"(c[m][1]), [c##m##2] "+v"(c[m][2]), [c##m##3] "+v"(c[m][3])
-#define X_ROW_A0(m) [c##m##0] "=&a"(c[m][0]), [c##m##1] "=&a"(c[m][1]), [c##m##2] "=&a"(c[m][2]), [c##m##3] "=&a"(c[m][3])
-#define X_ROW_V0(m) [c##m##0] "=&v"(c[m][0]), [c##m##1] "=&v"(c[m][1]), [c##m##2] "=&v"(c[m][2]), [c##m##3] "=&v"(c[m][3])
-#define X_FR_LO [a0] "+v"(f.a[0]), [a1] "+v"(f.a[1]), [a2] "+v"(f.a[2])
-#define X_FR_HI [a3] "+v"(f.a[3]), [a4] "+v"(f.a[4]), [a5] "+v"(f.a[5])
-#define X_FR_B [b0] "+v"(f.b[0]), [b1] "+v"(f.b[1]), [b2] "+v"(f.b[2]), [b3] "+v"(f.b[3])
-#define X_DMA_OUT [m0v] "+s"(d.m0), [so] "+s"(d.so)
-#define X_DMA_IN [st] "s"(d.st), [rs] "s"(d.rs), [vE] "v"(d.vE), [vO] "v"(d.vO)
-struct TxFrag { i32x4 a[6], b[4]; };
-typedef i32x16 TxAcc[6][4];
+// one LDS-DMA load of the stage being fetched, operand set s (a = genotype rows, b = W-digit rows): next row group
+// (LDS +1 KiB, source + 8 rows), even / odd group lane offsets
+#define X_DM(vo, s) "s_add_u32 %[m0" #s "], %[m0" #s "], 0x400\n\ts_mov_b32 m0, %[m0" #s "]\n\ts_add_u32 %[so" #s "], %[so" #s "], %[st" #s "]\n\t" \
+                    "buffer_load_dwordx4 %[" #vo #s "], %[rs" #s "], %[so" #s "] offen lds\n\t"
+#define X_NO(vo, s)
+// k-steps 0-2 (M = X_MF or X_MZ; D1-D6: DMA slots behind every second MFMA): queue on entry an0 an1 b0 an2 b1 b2 b3
+// (as a0-a2 here), loads x0-x2, b0-b3
+#define X_KSTEP(M, D1, D2, D3, D4, D5, D6)                                                                  \
+    X_WT(4) M(c00, a0, b0) X_LD(x0, pa, 0) M(c10, a1, b0) X_LD(x1, pa, 4096) D1                             \
+    X_WT(5) M(c20, a2, b0) X_LD(b0, pb, 0)                                                                  \
+    X_WT(5) M(c01, a0, b1) X_LD(x2, pa, 8192) D2 M(c11, a1, b1) M(c21, a2, b1) X_LD(b1, pb, 4096) D3        \
+    X_WT(6) M(c02, a0, b2) M(c12, a1, b2) D4 M(c22, a2, b2) X_LD(b2, pb, 8192)                              \
+    X_WT(6) M(c03, a0, b3) D5 M(c13, a1, b3) M(c23, a2, b3) X_LD(b3, pb, 12288) D6
+// the stage's last k-step: no loads before the barrier; behind it the loads of the next stage's first k-step in queue order
+// and the first three DMA loads of the stage after next
+#define X_KLAST                                                                                             \
+    X_WT(4) X_MF(c00, a0, b0) X_MF(c10, a1, b0) X_WT(3) X_MF(c20, a2, b0)                                   \
+    X_WT(2) X_MF(c01, a0, b1) X_MF(c11, a1, b1) X_MF(c21, a2, b1)                                           \
+    "s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier\n\t"                                                        \
+    X_LD(x0, pa, 0) X_LD(x1, pa, 4096) X_LD(b0, pb, 0) X_LD(x2, pa, 8192) X_LD(b1, pb, 4096)                \
+    X_MF(c02, a0, b2) X_MF(c12, a1, b2) X_DM(vE, a) X_MF(c22, a2, b2) X_LD(b2, pb, 8192)                    \
+    X_MF(c03, a0, b3) X_DM(vO, a) X_MF(c13, a1, b3) X_MF(c23, a2, b3) X_LD(b3, pb, 12288) X_DM(vE, a)
+#define X_ACC_RW(m) [c##m##0] "+v"(c[m][0]), [c##m##1] "+v"(c[m][1]), [c##m##2] "+v"(c[m][2]), [c##m##3] "+v"(c[m][3])
+#define X_ACC_W(m) [c##m##0] "=&v"(c[m][0]), [c##m##1] "=&v"(c[m][1]), [c##m##2] "=&v"(c[m][2]), [c##m##3] "=&v"(c[m][3])
+#define X_FRAGS [a0] "+v"(a[0]), [a1] "+v"(a[1]), [a2] "+v"(a[2]), [x0] "=&v"(an[0]), [x1] "=&v"(an[1]), [x2] "=&v"(an[2]), \
+                [b0] "+v"(b[0]), [b1] "+v"(b[1]), [b2] "+v"(b[2]), [b3] "+v"(b[3])
+#define X_DMA_OUT(s, d) [m0##s] "+s"(d.m0), [so##s] "+s"(d.so)
+#define X_DMA_IN(s, d) [st##s] "s"(d.st), [rs##s] "s"(d.rs), [vE##s] "v"(d.vE), [vO##s] "v"(d.vO)
+typedef i32x16 TxAcc[3][4];
 // state of one operand's DMA sequence: LDS address of the last issued row group (m0), its source offset (so), the stride of a
 // row group in the source (st = 8 rows), the buffer descriptor (num_records = 0 when there is nothing left to fetch: the loads
 // then write zeros into a buffer nobody reads again) and the even / odd lane offsets
@@ -934,53 +858,42 @@ __device__ __forceinline__ i32x4 x_rsrc(const void* base, unsigned bytes) {
     r[3] = 0x00020000;
     return r;
 }
-__device__ __forceinline__ void tx_prologue(TxFrag& f, unsigned pa, unsigned pb) {
-    asm volatile(X_LD(a0, pa, 0) X_LD(a1, pa, 4096) X_LD(a2, pa, 8192) X_LD(b0, pb, 0) X_LD(b1, pb, 4096) X_LD(b2, pb, 8192)
-                 X_LD(a3, pa, 12288) X_LD(a4, pa, 16384) X_LD(b3, pb, 12288) X_LD(a5, pa, 20480) X_WT(0)
-                 : [a0] "=&v"(f.a[0]), [a1] "=&v"(f.a[1]), [a2] "=&v"(f.a[2]), [a3] "=&v"(f.a[3]), [a4] "=&v"(f.a[4]), [a5] "=&v"(f.a[5]),
-                   [b0] "=&v"(f.b[0]), [b1] "=&v"(f.b[1]), [b2] "=&v"(f.b[2]), [b3] "=&v"(f.b[3])
+__device__ __forceinline__ void tx_prologue(i32x4 (&an)[3], i32x4 (&b)[4], unsigned pa, unsigned pb) {
+    asm volatile(X_LD(x0, pa, 0) X_LD(x1, pa, 4096) X_LD(b0, pb, 0) X_LD(x2, pa, 8192) X_LD(b1, pb, 4096) X_LD(b2, pb, 8192) X_LD(b3, pb, 12288) X_WT(0)
+                 : [x0] "=&v"(an[0]), [x1] "=&v"(an[1]), [x2] "=&v"(an[2]), [b0] "=&v"(b[0]), [b1] "=&v"(b[1]), [b2] "=&v"(b[2]), [b3] "=&v"(b[3])
                  : [pa] "v"(pa), [pb] "v"(pb) : "memory");
 }
-__device__ __forceinline__ void tx_dma4(XDma& d) {  // four loads on their own (pipeline fill)
-    asm volatile(X_M0_IN X_DM(vE) X_DM(vO) X_DM(vE) X_DM(vO) X_M0_OUT : X_DMA_OUT : X_DMA_IN : "memory", "m0");
+__device__ __forceinline__ void tx_dma3(XDma& da) {  // three loads on their own (pipeline fill)
+    asm volatile(X_DM(vE, a) X_DM(vO, a) X_DM(vE, a) : X_DMA_OUT(a, da) : X_DMA_IN(a, da) : "memory");
 }
-// one k-step with eight DMA loads of operand d between its MFMAs; pa / pb: LDS byte addresses of the NEXT k-step's fragments
-template <bool FIRST>
-__device__ __forceinline__ void tx_kstep_dma(TxAcc& c, TxFrag& f, unsigned pa, unsigned pb, XDma& d) {
-    if (FIRST) {
-        asm volatile(X_M0_IN X_P1_HEAD(X_MZ, X_DM) X_P1_TAIL(X_MZ, X_DM) X_M0_OUT
-                     : X_ROW_A0(0), X_ROW_A0(1), X_ROW_A0(2), X_FR_LO, X_FR_B, X_DMA_OUT : [pa] "v"(pa), X_DMA_IN : "memory", "m0");
-        asm volatile(X_M0_IN X_P2(X_MZ, X_DM) X_M0_OUT
-                     : X_ROW_A0(3), X_ROW_V0(4), X_ROW_V0(5), X_FR_HI, X_FR_B, X_DMA_OUT : [pa] "v"(pa), [pb] "v"(pb), X_DMA_IN : "memory", "m0");
-    } else {
-        asm volatile(X_M0_IN X_P1_HEAD(X_MF, X_DM) X_P1_TAIL(X_MF, X_DM) X_M0_OUT
-                     : X_ROW_A(0), X_ROW_A(1), X_ROW_A(2), X_FR_LO, X_FR_B, X_DMA_OUT : [pa] "v"(pa), X_DMA_IN : "memory", "m0");
-        asm volatile(X_M0_IN X_P2(X_MF, X_DM) X_M0_OUT
-                     : X_ROW_A(3), X_ROW_V(4), X_ROW_V(5), X_FR_HI, X_FR_B, X_DMA_OUT : [pa] "v"(pa), [pb] "v"(pb), X_DMA_IN : "memory", "m0");
-    }
+// k-step on fragments a (genotype rows) / b, loading an / b for the next k-step from LDS byte addresses pa / pb.
+// DMA: 0 = none; 1 = the stage's first k-step: loads 3-5 of the genotype sequence, 0-2 of the W-digit one; 2 = the second: the last
+template <bool FIRST, int DMA>
+__device__ __forceinline__ void tx_kstep(TxAcc& c, i32x4 (&a)[3], i32x4 (&an)[3], i32x4 (&b)[4], unsigned pa, unsigned pb, XDma& da, XDma& db) {
+    if (DMA == 1 && FIRST)
+        asm volatile(X_KSTEP(X_MZ, X_DM(vO, a), X_DM(vE, a), X_DM(vO, a), X_DM(vE, b), X_DM(vO, b), X_DM(vE, b))
+                     : X_ACC_W(0), X_ACC_W(1), X_ACC_W(2), X_FRAGS, X_DMA_OUT(a, da), X_DMA_OUT(b, db) : [pa] "v"(pa), [pb] "v"(pb), X_DMA_IN(a, da), X_DMA_IN(b, db) : "memory");
+    else if (DMA == 1)
+        asm volatile(X_KSTEP(X_MF, X_DM(vO, a), X_DM(vE, a), X_DM(vO, a), X_DM(vE, b), X_DM(vO, b), X_DM(vE, b))
+                     : X_ACC_RW(0), X_ACC_RW(1), X_ACC_RW(2), X_FRAGS, X_DMA_OUT(a, da), X_DMA_OUT(b, db) : [pa] "v"(pa), [pb] "v"(pb), X_DMA_IN(a, da), X_DMA_IN(b, db) : "memory");
+    else if (DMA == 2)
+        asm volatile(X_KSTEP(X_MF, X_DM(vO, b), , , , , )
+                     : X_ACC_RW(0), X_ACC_RW(1), X_ACC_RW(2), X_FRAGS, X_DMA_OUT(b, db) : [pa] "v"(pa), [pb] "v"(pb), X_DMA_IN(b, db) : "memory");
+    else
+        asm volatile(X_KSTEP(X_MF, , , , , , ) : X_ACC_RW(0), X_ACC_RW(1), X_ACC_RW(2), X_FRAGS : [pa] "v"(pa), [pb] "v"(pb) : "memory");
 }
-__device__ __forceinline__ void tx_kstep(TxAcc& c, TxFrag& f, unsigned pa, unsigned pb) {
-    asm volatile(X_P1_HEAD(X_MF, X_NO) X_P1_TAIL(X_MF, X_NO) : X_ROW_A(0), X_ROW_A(1), X_ROW_A(2), X_FR_LO, X_FR_B : [pa] "v"(pa) : "memory");
-    asm volatile(X_P2(X_MF, X_NO) : X_ROW_A(3), X_ROW_V(4), X_ROW_V(5), X_FR_HI, X_FR_B : [pa] "v"(pa), [pb] "v"(pb) : "memory");
+// last k-step of a stage; da: the genotype DMA sequence of the stage after next (armed before the call), three of its loads go out here
+__device__ __forceinline__ void tx_klast(TxAcc& c, i32x4 (&a)[3], i32x4 (&an)[3], i32x4 (&b)[4], unsigned pa, unsigned pb, XDma& da) {
+    asm volatile(X_KLAST : X_ACC_RW(0), X_ACC_RW(1), X_ACC_RW(2), X_FRAGS, X_DMA_OUT(a, da) : [pa] "v"(pa), [pb] "v"(pb), X_DMA_IN(a, da) : "memory");
 }
-// the stage's last k-step, in two parts around the arming of the next DMA sequence: part 1 = #1..#10, then every read of this
-// buffer has returned and this wave's share of the other buffer's DMA has landed -> barrier.
-__device__ __forceinline__ void tx_klast_head(TxAcc& c, TxFrag& f) {
-    asm volatile(X_P1_HEAD(X_MF, X_NO) "s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier\n\t" : X_ROW_A(0), X_ROW_A(1), X_ROW_A(2), X_FR_LO, X_FR_B : : "memory");
-}
-__device__ __forceinline__ void tx_klast_tail(TxAcc& c, TxFrag& f, unsigned pa, unsigned pb, XDma& d) {
-    asm volatile(X_M0_IN X_P1_TAIL(X_MF, X_NO) X_P2(X_MF, X_DM) X_M0_OUT
-                 : [c13] "+a"(c[1][3]), [c23] "+a"(c[2][3]), X_ROW_A(3), X_ROW_V(4), X_ROW_V(5), X_FR_LO, X_FR_HI, X_FR_B, X_DMA_OUT
-                 : [pa] "v"(pa), [pb] "v"(pb), X_DMA_IN : "memory", "m0");
-}
-__global__ __launch_bounds__(256) void k_vara_i8x(const int8_t* __restrict__ Mt8, long ld, int ntm, const int8_t* __restrict__ Bs,
-                                                  long np, const VaraHdr* __restrict__ hdr, long long* __restrict__ q, long Lp, int cut_last_round) {
+__global__ __launch_bounds__(512, 2) void k_vara_i8p(const int8_t* __restrict__ Mt8, long ld, int ntm, const int8_t* __restrict__ Bs,
+                                                     long np, const VaraHdr* __restrict__ hdr, long long* __restrict__ q, long Lp, int cut_last_round) {
     extern __shared__ __attribute__((aligned(1024))) int8_t ldsv[];  // [2][A 48 KiB | B 32 KiB]
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
     const int nslices = hdr->S;
     const int nct = (int)(np / T8), npair = (nct + 1) / 2;
-    const int groups = (ntm + 7) >> 3, wx = groups * nslices, full = (wx >> 5) << 5, tail = wx - full;
+    const int groups = (ntm + 7) >> 3, wx = groups * nslices, full = (wx >> 5) << 5, tail = wx - full;  // see k_vara_i8w
     int psplit = 1;
     if (cut_last_round && tail > 0 && tail <= 16) { psplit = 32 / tail; if (psplit > npair) psplit = npair; }
     int worker = slot, piece = 0;
@@ -993,7 +906,7 @@ __global__ __launch_bounds__(256) void k_vara_i8x(const int8_t* __restrict__ Mt8
     const int8_t* Bsl = Bs + (long)sl * np * np;
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wr = w >> 1, wc = w & 1;   // 2 x 2 waves
+    const int wr = w >> 1, wc = w & 1;   // 4 x 2 waves
     const int ldi = (int)ld, npi = (int)np;
     const T8Lane lnA = t8_lane(lane, ldi), lnB = t8_lane(lane, npi);
     const long row0 = (long)mt * TW_M;
@@ -1004,21 +917,19 @@ __global__ __launch_bounds__(256) void k_vara_i8x(const int8_t* __restrict__ Mt8
     cur.p = pair0; cur.half = 0; vit_set_tile(cur, nct, pair1);
     if (!cur.valid) return;
     nxt = cur;
-    long long keep[6] = {0, 0, 0, 0, 0, 0};
+    long long keep[3] = {0, 0, 0};
     const int r = lane & 31, h = lane >> 5, swz = (r >> 1) & 7;
     constexpr int STG = TW_ABYTES + TILE_BYTES;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) int8_t*)ldsv;
-    const unsigned offA = lds0 + wr * (192 * BK8) + r * BK8, offB = lds0 + TW_ABYTES + wc * (128 * BK8) + r * BK8;
+    const unsigned offA = lds0 + wr * (96 * BK8) + r * BK8, offB = lds0 + TW_ABYTES + wc * (128 * BK8) + r * BK8;
     unsigned ch[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) ch[ks] = ((2 * ks + h) ^ swz) << 4;
     const int xsel = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
-    const int evoff = (wr * 192 + 4 * h) * ldi + wc * 128 + r;
-    // four waves issue the DMA of a stage: A 48 row groups (12 per wave), B 32 (8 per wave).  A burst of 20 loads per wave has
-    // nothing to overlap with when the wave is alone on its SIMD (measured: 50.1 ms as a burst, 45.6 ms in four parts), so the
-    // loads sit between the MFMAs: 4 (A) behind the barrier, 8 (A) in the next stage's first k-step, 8 (B) in its second.
-    tw_stage<12>(rsA, lnA, ldi, nxt.kt * BK8, ldsv, w);
-    tw_stage<8>(t8_rsrc(Bsl + (long)nxt.ct * T8 * np, npi), lnB, npi, nxt.kt * BK8, ldsv + TW_ABYTES, w);
+    const int evoff = (wr * 96 + 4 * h) * ldi + wc * 128 + r;
+    // stage 0 as a burst, then the pipeline: eight waves issue the DMA of a stage, A 48 row groups (6 per wave), B 32 (4 per wave)
+    tw_stage<6>(rsA, lnA, ldi, nxt.kt * BK8, ldsv, w);
+    tw_stage<4>(t8_rsrc(Bsl + (long)nxt.ct * T8 * np, npi), lnB, npi, nxt.kt * BK8, ldsv + TW_ABYTES, w);
     vit_advance(nxt, nct, pair1);
     __syncthreads();
     XDma dA, dB;
@@ -1028,36 +939,35 @@ __global__ __launch_bounds__(256) void k_vara_i8x(const int8_t* __restrict__ Mt8
     auto dma_arm = [&](int into) {  // the sequence of the next stage to fetch, into buffer `into`
         const bool on = nxt.valid;
         const unsigned base = lds0 + into * STG;
-        dA.m0 = base + (w * 12) * 1024 - 1024;
-        dB.m0 = base + TW_ABYTES + (w * 8) * 1024 - 1024;
-        dA.so = (unsigned)((w * 12) * 8 * ldi + nxt.kt * BK8 - 8 * ldi);
-        dB.so = (unsigned)((w * 8) * 8 * npi + nxt.kt * BK8 - 8 * npi);
+        dA.m0 = base + (w * 6) * 1024 - 1024;
+        dB.m0 = base + TW_ABYTES + (w * 4) * 1024 - 1024;
+        dA.so = (unsigned)((w * 6) * 8 * ldi + nxt.kt * BK8 - 8 * ldi);
+        dB.so = (unsigned)((w * 4) * 8 * npi + nxt.kt * BK8 - 8 * npi);
         dA.rs = on ? rsA_raw : rs_none;
         dB.rs = on ? x_rsrc(Bsl + (long)nxt.ct * T8 * np, (unsigned)(T8 * npi)) : rs_none;
         if (on) vit_advance(nxt, nct, pair1);
     };
     dma_arm(1);
-    tx_dma4(dA);
+    tx_dma3(dA);
     int buf = 0;
-    TxFrag f;
+    i32x4 fa[2][3], fb[4];
     TxAcc c;
-    tx_prologue(f, offA + ch[0], offB + ch[0]);
-    // the stage's k-steps 1-3; the last one carries the barrier, and its re-loads read the other buffer
+    tx_prologue(fa[0], fb, offA + ch[0], offB + ch[0]);
+    // the stage's k-steps 1-3; the DMA sequence of the stage after next is armed before the last one, which carries the barrier
     auto stage_rest = [&] {
         const unsigned sa = offA + buf * STG, sb = offB + buf * STG;
-        tx_kstep_dma<false>(c, f, sa + ch[2], sb + ch[2], dB);
-        tx_kstep(c, f, sa + ch[3], sb + ch[3]);
-        tx_klast_head(c, f);
+        tx_kstep<false, 2>(c, fa[1], fa[0], fb, sa + ch[2], sb + ch[2], dA, dB);
+        tx_kstep<false, 0>(c, fa[0], fa[1], fb, sa + ch[3], sb + ch[3], dA, dB);
         dma_arm(buf);
         buf ^= 1;
-        tx_klast_tail(c, f, offA + buf * STG + ch[0], offB + buf * STG + ch[0], dA);
+        tx_klast(c, fa[1], fa[0], fb, offA + buf * STG + ch[0], offB + buf * STG + ch[0], dA);
     };
     while (cur.valid) {
         const int done_ct = cur.ct, nk = cur.nk;  // nk >= 2
-        tx_kstep_dma<true>(c, f, offA + buf * STG + ch[1], offB + buf * STG + ch[1], dA);
+        tx_kstep<true, 1>(c, fa[0], fa[1], fb, offA + buf * STG + ch[1], offB + buf * STG + ch[1], dA, dB);
         stage_rest();
         for (int kt = 1; kt < nk; kt++) {
-            tx_kstep_dma<false>(c, f, offA + buf * STG + ch[1], offB + buf * STG + ch[1], dA);
+            tx_kstep<false, 1>(c, fa[0], fa[1], fb, offA + buf * STG + ch[1], offB + buf * STG + ch[1], dA, dB);
             stage_rest();
         }
         cur.kt = nk - 1;
@@ -1069,7 +979,7 @@ __global__ __launch_bounds__(256) void k_vara_i8x(const int8_t* __restrict__ Mt8
             const int ecol = done_ct * T8;
             const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
 #pragma unroll
-            for (int m = 0; m < 6; m++) {
+            for (int m = 0; m < 3; m++) {
                 int v16[16], v8[8], v4[4], v2[2];
 #pragma unroll
                 for (int x = 0; x < 16; x++) {
@@ -1095,10 +1005,10 @@ __global__ __launch_bounds__(256) void k_vara_i8x(const int8_t* __restrict__ Mt8
             }
         }
     }
-    const long qrow = row0 + wr * 192 + 4 * h + (xsel & 3) + 8 * (xsel >> 2);
+    const long qrow = row0 + wr * 96 + 4 * h + (xsel & 3) + 8 * (xsel >> 2);
     long long* qs = q + (long)sl * Lp + qrow;
 #pragma unroll
-    for (int m = 0; m < 6; m++)
+    for (int m = 0; m < 3; m++)
         if ((lane & 16) == 0 && keep[m] && qrow + m * 32 < Lp) atomicAdd((unsigned long long*)&qs[m * 32], (unsigned long long)keep[m]);
 }
 
@@ -1532,31 +1442,26 @@ extern "C" int eagle_dev_vara_i8_mfma_shifted(eagle_ctx* ctx, const int8_t* Mt8s
         if (ea != hipSuccess) return eagle_fail_hip(ctx, ea, "hipFuncSetAttribute(k_vara_i8)");
         ctx->attr_vara_i8 = true;
     }
-    // The 384 x 256 tile form is the default (C2: 23.05 -> 21.91 ms, C3 shape: 45.2 -> 43.1 ms per 262144 markers, bit-identical
-    // q; profiles/r02_ab_vara_tile.txt); the 256 x 256 form serves n_pad >= 32768 (its int32 butterfly spans 64 columns per wave
-    // instead of 128) and stays reachable for A/B runs with tune = 8.
-    if (ctx->tune == 10 && n_pad < 32768) {  // experiment: four waves, 384 accumulators per wave (AGPR + VGPR)
-        if (!ctx->attr_vara_i8x) {
-            hipError_t ea = hipFuncSetAttribute((const void*)k_vara_i8x, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TW_ABYTES + TILE_BYTES));
-            if (ea != hipSuccess) return eagle_fail_hip(ctx, ea, "hipFuncSetAttribute(k_vara_i8x)");
-            ctx->attr_vara_i8x = true;
-        }
-        const int ntw = (int)((L_pad + TW_M - 1) / TW_M), gw = (ntw + 7) / 8;
-        hipLaunchKernelGGL(k_vara_i8x, dim3((unsigned)(8 * (gw * smax + 32))), dim3(256), 2 * (TW_ABYTES + TILE_BYTES), s, Mt8s, ld, ntw, Bs, n_pad, hdr, q, L_pad, 1);
-    } else
+    // The 384 x 256 tile is the default (C2: 23.05 -> 21.91 ms, C3 shape: 45.2 -> 43.1 ms per 262144 markers; profiles/
+    // r02_ab_vara_tile.txt), since round 2 in its asm-pipelined form k_vara_i8p (another -4 to -5 %, profiles/r02_ab_vara_pipe.txt).
+    // All forms give bit-identical q.  The 256 x 256 form serves n_pad >= 32768 (its int32 butterfly spans 64 columns per wave
+    // instead of 128).  A/B switches of tools/bench_vara.py: tune 8 = the 256 x 256 form, 9 = the compiler-scheduled 384 x 256
+    // form (k_vara_i8w), 7 = whole workers in the last round.
     if (ctx->tune != 8 && n_pad < 32768) {
-        const int spread = ctx->tune >= 11 && ctx->tune <= 15 ? ctx->tune - 10 : 0;  // 11-15: A/B switches of tools/bench_vara.py
-        typedef void (*KW)(const int8_t*, long, int, const int8_t*, long, const VaraHdr*, long long*, long, int);
-        static const KW kws[6] = {k_vara_i8w<0>, k_vara_i8w<1>, k_vara_i8w<2>, k_vara_i8w<3>, k_vara_i8w<4>, k_vara_i8w<5>};
-        if (!(ctx->attr_vara_i8w & (1 << spread))) {
-            hipError_t ea = hipFuncSetAttribute((const void*)kws[spread], hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TW_ABYTES + TILE_BYTES));
-            if (ea != hipSuccess) return eagle_fail_hip(ctx, ea, "hipFuncSetAttribute(k_vara_i8w)");
-            ctx->attr_vara_i8w |= 1 << spread;
+        const bool piped = ctx->tune != 9;
+        const void* kfn = piped ? (const void*)k_vara_i8p : (const void*)k_vara_i8w;
+        bool& attr = piped ? ctx->attr_vara_i8p : ctx->attr_vara_i8w;
+        if (!attr) {
+            hipError_t ea = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TW_ABYTES + TILE_BYTES));
+            if (ea != hipSuccess) return eagle_fail_hip(ctx, ea, "hipFuncSetAttribute(k_vara_i8p/w)");
+            attr = true;
         }
         const int ntw = (int)((L_pad + TW_M - 1) / TW_M), gw = (ntw + 7) / 8;
         // per XCD at most gw * smax workers, plus at most 32 more blocks when the last round is cut into pieces
-        const int cut = ctx->tune == 7 ? 0 : 1;  // tune 7: A/B switch of tools/bench_vara.py (whole workers in the last round)
-        hipLaunchKernelGGL(kws[spread], dim3((unsigned)(8 * (gw * smax + 32))), dim3(512), 2 * (TW_ABYTES + TILE_BYTES), s, Mt8s, ld, ntw, Bs, n_pad, hdr, q, L_pad, cut);
+        const dim3 gridw((unsigned)(8 * (gw * smax + 32)));
+        const int cut = ctx->tune == 7 ? 0 : 1;
+        if (piped) hipLaunchKernelGGL(k_vara_i8p, gridw, dim3(512), 2 * (TW_ABYTES + TILE_BYTES), s, Mt8s, ld, ntw, Bs, n_pad, hdr, q, L_pad, cut);
+        else hipLaunchKernelGGL(k_vara_i8w, gridw, dim3(512), 2 * (TW_ABYTES + TILE_BYTES), s, Mt8s, ld, ntw, Bs, n_pad, hdr, q, L_pad, cut);
     } else
     hipLaunchKernelGGL(k_vara_i8, dim3((unsigned)(groups * 8 * smax)), dim3(512), 5 * TILE_BYTES, s, Mt8s, ld, ntm, Bs, n_pad, hdr, q, L_pad);
     hipLaunchKernelGGL(k_vara_i8_finish, dim3((unsigned)((L_pad + 255) / 256)), dim3(256), 0, s, q, L_pad, hdr, vdiag, cshift, mrho, vara_out);

@@ -5,7 +5,7 @@ import random
 
 
 def vara_i8w_cover(ntm, S, npair, smax=7, cut=True):
-    """k_vara_i8w (csrc/eagle_i8mfma.hip): block b -> (xcd = b & 7, slot = b >> 3) -> worker -> (marker tile, slice) and, for the
+    """k_vara_i8p / k_vara_i8w (csrc/eagle_i8mfma.hip): block b -> (xcd = b & 7, slot = b >> 3) -> worker -> (marker tile, slice) and, for the
     workers of a last round that is less than half full, a piece [pair0, pair1) of the column-tile pairs."""
     groups = (ntm + 7) >> 3
     wx = groups * S

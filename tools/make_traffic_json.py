@@ -47,7 +47,7 @@ def entry(k, algorithmic):
 npad = (n + 255) // 256 * 256
 lpad = (markers + 255) // 256 * 256
 out = {"kernel_sha16": kernel_sha16(),
-       "k_vara_i8": entry("k_vara_i8w", float(lpad) * npad + slices * npad * npad / 2.0),
+       "k_vara_i8": entry("k_vara_i8p", float(lpad) * npad + slices * npad * npad / 2.0),
        "k_gemv_mfma": entry("k_gemv_mfma", float(lpad) * npad),
        "k_syrk_f4": entry("k_syrk_f4", float(lpad) * npad / 2.0),
        "k_gemm_f64_list": entry("k_gemm_f64_list", 3.0 * 8 * npad * npad)}
