@@ -1921,6 +1921,155 @@ __global__ __launch_bounds__(512, 2) void k_syrk_f4(const uint8_t* __restrict__ 
             }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_syrk_f4p: k_syrk_f4 with the k-step in inline asm, software pipelined like k_vara_i8p: both fragment sets double-buffered
+// (24 + 24 VGPRs), the six reads of the next k-step issued behind the first six MFMAs of this one (issue order a0 b0 a1 b1 a2 a3,
+// counted waits), the eight LDS-DMA loads of the next stage one behind each MFMA that follows the stage barrier (6 in the
+// stage's last k-step, whose barrier sits behind its second MFMA, 2 in the next), C = 0 as an inline constant in the very first k-step.
+// Same sums of the same exact integers: bit-identical C.
+// ------------------------------------------------------------------------------------------------
+#define S_MF(c, a, b) "v_mfma_scale_f32_32x32x64_f8f6f4 %[" #c "], %[" #a "], %[" #b "], %[" #c "], %[sc], %[sc] op_sel_hi:[0,0,0] cbsz:4 blgp:4\n\t"
+#define S_MZ(c, a, b) "v_mfma_scale_f32_32x32x64_f8f6f4 %[" #c "], %[" #a "], %[" #b "], 0, %[sc], %[sc] op_sel_hi:[0,0,0] cbsz:4 blgp:4\n\t"
+#define S_KSTEP(M, D1, D2, D3, D4)                                                             \
+    X_WT(4) M(c00, a0, b0) X_LD(x0, pa, 0) D1                                                  \
+    X_WT(3) M(c01, a0, b1) X_LD(y0, pb, 0)                                                     \
+            M(c10, a1, b0) X_LD(x1, pa, 4096) D2                                               \
+            M(c11, a1, b1) X_LD(y1, pb, 4096)                                                  \
+    X_WT(5) M(c20, a2, b0) X_LD(x2, pa, 8192) D3                                               \
+            M(c21, a2, b1) X_LD(x3, pa, 12288)                                                 \
+    X_WT(6) M(c30, a3, b0) D4                                                                  \
+            M(c31, a3, b1)
+#define S_KLAST                                                                                \
+    X_WT(4) S_MF(c00, a0, b0) X_WT(2) S_MF(c01, a0, b1)                                        \
+    "s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier\n\t"                                           \
+    X_LD(x0, pa, 0) X_LD(y0, pb, 0) X_LD(x1, pa, 4096) X_LD(y1, pb, 4096) X_LD(x2, pa, 8192) X_LD(x3, pa, 12288) \
+    S_MF(c10, a1, b0) X_DM(vE, a) S_MF(c11, a1, b1) X_DM(vO, a) S_MF(c20, a2, b0) X_DM(vE, a) S_MF(c21, a2, b1) X_DM(vO, a) \
+    S_MF(c30, a3, b0) X_DM(vE, b) S_MF(c31, a3, b1) X_DM(vO, b)
+#define S_ACC_RW(m) [c##m##0] "+v"(c[m][0]), [c##m##1] "+v"(c[m][1])
+#define S_ACC_W(m) [c##m##0] "=&v"(c[m][0]), [c##m##1] "=&v"(c[m][1])
+#define S_NEXT [x0] "=&v"(g.a[0]), [x1] "=&v"(g.a[1]), [x2] "=&v"(g.a[2]), [x3] "=&v"(g.a[3]), [y0] "=&v"(g.b[0]), [y1] "=&v"(g.b[1])
+#define S_CUR [a0] "v"(f.a[0]), [a1] "v"(f.a[1]), [a2] "v"(f.a[2]), [a3] "v"(f.a[3]), [b0] "v"(f.b[0]), [b1] "v"(f.b[1]), [sc] "v"(sc), [pa] "v"(pa), [pb] "v"(pb)
+struct SxFrag { i32x4 a[4], b[2]; };
+typedef f32x16 SxAcc[4][2];
+// k-step on fragments f, loading g for the next k-step from LDS byte addresses pa / pb.
+// DMA: 0 = none; 1 = the stage's first k-step: the last two loads (2, 3) of the column-tile sequence
+// hipcc's uniformity analysis calls the scalar outputs of these asm blocks divergent in this kernel (not in k_vara_i8p), puts their
+// loop-carried copies into VGPRs and then cannot feed them to the next block's "s" operands: say it explicitly
+__device__ __forceinline__ void sx_uniform(XDma& d) {
+    d.m0 = __builtin_amdgcn_readfirstlane(d.m0);
+    d.so = __builtin_amdgcn_readfirstlane(d.so);
+}
+template <bool FIRST, int DMA>
+__device__ __forceinline__ void sx_kstep(SxAcc& c, const SxFrag& f, SxFrag& g, unsigned pa, unsigned pb, int sc, XDma& db) {
+    if (DMA == 1 && FIRST)
+        asm volatile(S_KSTEP(S_MZ, X_DM(vE, b), X_DM(vO, b), , )
+                     : S_ACC_W(0), S_ACC_W(1), S_ACC_W(2), S_ACC_W(3), S_NEXT, X_DMA_OUT(b, db) : S_CUR, X_DMA_IN(b, db) : "memory");
+    else if (DMA == 1)
+        asm volatile(S_KSTEP(S_MF, X_DM(vE, b), X_DM(vO, b), , )
+                     : S_ACC_RW(0), S_ACC_RW(1), S_ACC_RW(2), S_ACC_RW(3), S_NEXT, X_DMA_OUT(b, db) : S_CUR, X_DMA_IN(b, db) : "memory");
+    else
+        asm volatile(S_KSTEP(S_MF, , , , ) : S_ACC_RW(0), S_ACC_RW(1), S_ACC_RW(2), S_ACC_RW(3), S_NEXT : S_CUR : "memory");
+    if (DMA) sx_uniform(db);
+}
+__device__ __forceinline__ void sx_klast(SxAcc& c, const SxFrag& f, SxFrag& g, unsigned pa, unsigned pb, int sc, XDma& da, XDma& db) {
+    asm volatile(S_KLAST : S_ACC_RW(0), S_ACC_RW(1), S_ACC_RW(2), S_ACC_RW(3), S_NEXT, X_DMA_OUT(a, da), X_DMA_OUT(b, db) : S_CUR, X_DMA_IN(a, da), X_DMA_IN(b, db) : "memory");
+    sx_uniform(da);
+    sx_uniform(db);
+}
+__device__ __forceinline__ void sx_prologue(SxFrag& g, unsigned pa, unsigned pb) {
+    asm volatile(X_LD(x0, pa, 0) X_LD(y0, pb, 0) X_LD(x1, pa, 4096) X_LD(y1, pb, 4096) X_LD(x2, pa, 8192) X_LD(x3, pa, 12288) X_WT(0)
+                 : S_NEXT : [pa] "v"(pa), [pb] "v"(pb) : "memory");
+}
+__device__ __forceinline__ void sx_dma6(XDma& da, XDma& db) {  // pipeline fill: what the last k-step issues behind its barrier
+    asm volatile(X_DM(vE, a) X_DM(vO, a) X_DM(vE, a) X_DM(vO, a) X_DM(vE, b) X_DM(vO, b) : X_DMA_OUT(a, da), X_DMA_OUT(b, db) : X_DMA_IN(a, da), X_DMA_IN(b, db) : "memory");
+    sx_uniform(da);
+    sx_uniform(db);
+}
+__global__ __launch_bounds__(512, 2) void k_syrk_f4p(const uint8_t* __restrict__ M4, long ld4, const int* __restrict__ pairs, int npairs,
+                                                     int nblocks, long nstages, long stages_per_split, int32_t* __restrict__ C, long ldc) {
+    __shared__ __attribute__((aligned(1024))) int8_t lds[2][2][TILE_BYTES];
+    const int cpx = (gridDim.x + 7) / 8;
+    const int lid = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+    if (lid >= nblocks) return;
+    const int split = __builtin_amdgcn_readfirstlane(lid / npairs);  // (the division runs on the vector unit)
+    const int pr = __builtin_amdgcn_readfirstlane(pairs[lid - split * npairs]);
+    const int ti = pr >> 16, tj = pr & 0xffff;
+    const int s0 = split * (int)stages_per_split;  // stage counters fit an int (ld4 * 256 < 2^31); 64-bit compares would run on the vector unit
+    int s1 = s0 + (int)stages_per_split;
+    if (s1 > (int)nstages) s1 = (int)nstages;
+    if (s0 >= s1) return;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = w >> 2, wc = w & 3;
+    const int ldi = (int)ld4;
+    const T8Lane ln = t8_lane(lane, ldi);
+    const int8_t* baseA = (const int8_t*)M4 + (long)ti * T8 * ld4;
+    const int8_t* baseB = (const int8_t*)M4 + (long)tj * T8 * ld4;
+    t8_stage(t8_rsrc(baseA, ldi), ln, ldi, s0 * BK8, lds[0][0], w);
+    t8_stage(t8_rsrc(baseB, ldi), ln, ldi, s0 * BK8, lds[0][1], w);
+    __syncthreads();
+    const T8Read rd = t8_read_init(wr, wc, lane);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) int8_t*)&lds[0][0][0];
+    const unsigned offA = lds0 + rd.offA, offB = lds0 + TILE_BYTES + rd.offB;
+    constexpr unsigned STG = 2 * TILE_BYTES;
+    XDma dA, dB;
+    dA.st = dB.st = __builtin_amdgcn_readfirstlane(8 * ldi);
+    dA.vE = dB.vE = ln.voffE; dA.vO = dB.vO = ln.voffO;
+    int snext = s0 + 1;  // the next stage to fetch
+    unsigned nrec = 0;
+    // (the descriptors are rebuilt from scalars at each use: a loop-carried SGPR vector ends up in VGPRs)
+    auto rs_fresh = [&] { dA.rs = x_rsrc(baseA, nrec); dB.rs = x_rsrc(baseB, nrec); };
+    auto dma_arm = [&](int into) {
+        const unsigned base = lds0 + into * STG + (w * 4) * 1024 - 1024;
+        dA.m0 = __builtin_amdgcn_readfirstlane(base); dB.m0 = dA.m0 + TILE_BYTES;
+        dA.so = dB.so = __builtin_amdgcn_readfirstlane((unsigned)((w * 4) * 8 * ldi + snext * BK8 - 8 * ldi));
+        // num_records = 0 when nothing is left to fetch: the loads then write zeros nobody reads
+        const int left = __builtin_amdgcn_readfirstlane(s1 - snext);
+        nrec = __builtin_amdgcn_readfirstlane((unsigned)(T8 * ldi) * (unsigned)max(min(left, 1), 0));
+        snext++;
+    };
+    dma_arm(1);
+    rs_fresh();
+    sx_dma6(dA, dB);
+    const int sc = 0x7f7f7f7f;
+    SxFrag f0, f1;
+    SxAcc c;
+    sx_prologue(f0, offA + rd.ch[0], offB + rd.ch[0]);
+    int buf = 0;
+    auto stage_rest = [&] {
+        const unsigned sa = offA + buf * STG, sb = offB + buf * STG;
+        sx_kstep<false, 0>(c, f1, f0, sa + rd.ch[2], sb + rd.ch[2], sc, dB);
+        sx_kstep<false, 0>(c, f0, f1, sa + rd.ch[3], sb + rd.ch[3], sc, dB);
+        dma_arm(buf);
+        rs_fresh();
+        buf ^= 1;
+        sx_klast(c, f1, f0, offA + buf * STG + rd.ch[0], offB + buf * STG + rd.ch[0], sc, dA, dB);
+    };
+    rs_fresh();
+    sx_kstep<true, 1>(c, f0, f1, offA + rd.ch[1], offB + rd.ch[1], sc, dB);
+    stage_rest();
+    for (int s = s0 + 1; s < s1; s++) {
+        rs_fresh();
+        sx_kstep<false, 1>(c, f0, f1, offA + buf * STG + rd.ch[1], offB + buf * STG + rd.ch[1], sc, dB);
+        stage_rest();
+    }
+    // the MFMAs are opaque to the compiler's hazard recogniser: let the last ones retire; the stale re-loads have to land before
+    // their registers are reused
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    const int col = lane & 31, rq = 4 * (lane >> 5);
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int x = 0; x < 16; x++) {
+                long i = (long)ti * T8 + wr * 128 + m * 32 + (x & 3) + 8 * (x >> 2) + rq;
+                long j = (long)tj * T8 + wc * 64 + n * 32 + col;
+                int v = (int)c[m][n][x];
+                if (v) atomicAdd(&C[i * ldc + j], v);
+            }
+}
+
 static long ctx_cu_count(eagle_ctx* ctx) {
     int cu = 0;
     (void)eagle_device_info(ctx, nullptr, 0, &cu, nullptr);
@@ -1958,8 +2107,9 @@ extern "C" int eagle_dev_mmt_accumulate_f4(eagle_ctx* ctx, const void* M4, long 
     int rc = syrk_pair_table(ctx, nt, &pairs, (hipStream_t)stream);
     if (rc) return rc;
     dim3 grid((unsigned)((nblocks + 7) / 8 * 8));
-    hipLaunchKernelGGL(k_syrk_f4, grid, dim3(512), 0, (hipStream_t)stream, (const uint8_t*)M4, ld4, pairs, (int)npairs, (int)nblocks, nstages, per,
-                       C32, n_pad);
+    // tune 9: the compiler-scheduled form, for tools/bench_syrk.py
+    if (ctx->tune == 9) hipLaunchKernelGGL(k_syrk_f4, grid, dim3(512), 0, (hipStream_t)stream, (const uint8_t*)M4, ld4, pairs, (int)npairs, (int)nblocks, nstages, per, C32, n_pad);
+    else hipLaunchKernelGGL(k_syrk_f4p, grid, dim3(512), 0, (hipStream_t)stream, (const uint8_t*)M4, ld4, pairs, (int)npairs, (int)nblocks, nstages, per, C32, n_pad);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "k_syrk_f4");
     return EAGLE_OK;
