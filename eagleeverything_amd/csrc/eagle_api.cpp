@@ -105,8 +105,12 @@ extern "C" eagle_ctx* eagle_open(int device) {
         delete ctx;
         return nullptr;
     }
+    // the loader stream outranks the compute stream: its decode / unpack / fill kernels are microseconds of work that must get
+    // onto CUs the scan kernel's long-lived workgroups fill completely (2 waves x 256 VGPRs per SIMD), as soon as one retires
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&ctx->load_stream, hipStreamNonBlocking)) != hipSuccess) {
+        (e = hipStreamCreateWithPriority(&ctx->load_stream, hipStreamNonBlocking, prio_greatest)) != hipSuccess) {
         snprintf(g_open_err, sizeof g_open_err, "hipStreamCreate: %s", hipGetErrorString(e));
         delete ctx;
         return nullptr;
@@ -445,10 +449,11 @@ static int load_tile_fixed(eagle_ctx* ctx, FileInfo& fi, long row0, long nrows, 
     if (rcs) return rcs;
     char* pin[2] = {(char*)ctx->stage_pin[0], (char*)ctx->stage_pin[1]};
     uint8_t* raw[2] = {(uint8_t*)ctx->stage_raw[0], (uint8_t*)ctx->stage_raw[1]};
-    DevBuf bad;
+    // the bad-character counter lives in the ctx scratch page: a hipMalloc / hipFree per tile would synchronise the device,
+    // i.e. wait for the kernels of the previous chunk when the tile is a chunk of a streamed file
+    int* const bad = (int*)((char*)ctx->d_scratch + 1024);
     hipEvent_t done[2] = {nullptr, nullptr};
-    HIPCHK(ctx, bad.alloc(sizeof(int)));
-    HIPCHK(ctx, hipMemsetAsync(bad.p, 0, sizeof(int), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
     for (int b = 0; b < 2; b++) HIPCHK(ctx, hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
     int rc = EAGLE_OK;
     volatile int io_err = 0;
@@ -460,18 +465,21 @@ static int load_tile_fixed(eagle_ctx* ctx, FileInfo& fi, long row0, long nrows, 
             hipError_t e = hipEventSynchronize(done[b]);  // the copy out of pin[b] two chunks ago has finished
             if (e != hipSuccess) { rc = eagle_fail_hip(ctx, e, "hipEventSynchronize"); break; }
         }
+        const double tp = now_s();
         parallel_pread(fi.fd, (uint8_t*)pin[b], stride, nr, src_bytes, (off_t)(row0 + r) * line + col0, line, threads,
                        &io_err);
+        ctx->st_pread_s += now_s() - tp;
+        ctx->st_file_bytes += nr * src_bytes;
         if (io_err) { rc = eagle_fail(ctx, EAGLE_ERR_FORMAT, "short read: file has fewer lines than requested"); break; }
         hipError_t e = hipMemcpyAsync(raw[b], pin[b], (size_t)nr * stride, hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) { rc = eagle_fail_hip(ctx, e, "hipMemcpyAsync H2D"); break; }
         e = hipEventRecord(done[b], ctx->stream);
         if (e != hipSuccess) { rc = eagle_fail_hip(ctx, e, "hipEventRecord"); break; }
-        rc = eagle_dev_decode_ascii(ctx, raw[b], nr, ncols, stride, dst + r * ld, ld, bad.as<int>(), ctx->stream);
+        rc = eagle_dev_decode_ascii(ctx, raw[b], nr, ncols, stride, dst + r * ld, ld, bad, ctx->stream);
     }
     int nbad = 0;
     if (rc == EAGLE_OK) {
-        hipError_t e = hipMemcpyAsync(&nbad, bad.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+        hipError_t e = hipMemcpyAsync(&nbad, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = eagle_fail_hip(ctx, e, "decode sync");
     } else {
@@ -505,9 +513,8 @@ static int load_tile_sidecar(eagle_ctx* ctx, const char* path, const FileInfo& f
     long chunk_rows = std::max(1L, std::min(nrows, (long)(67108864 / stride)));
     int rc = eagle_stage_ensure(ctx, (size_t)chunk_rows * stride);
     if (rc) return rc;
-    DevBuf bad;
-    HIPCHK(ctx, bad.alloc(sizeof(int)));
-    HIPCHK(ctx, hipMemsetAsync(bad.p, 0, sizeof(int), ctx->stream));
+    int* const bad = (int*)((char*)ctx->d_scratch + 1024);  // (see load_tile_fixed)
+    HIPCHK(ctx, hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
     hipEvent_t done[2] = {nullptr, nullptr};
     for (int b = 0; b < 2; b++) HIPCHK(ctx, hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
     struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int b = 0; b < 2; b++) if (e[b]) (void)hipEventDestroy(e[b]); } } evg{done};
@@ -517,16 +524,19 @@ static int load_tile_sidecar(eagle_ctx* ctx, const char* path, const FileInfo& f
         const int b = (int)(k & 1);
         const long nr = std::min(chunk_rows, nrows - r);
         if (k >= 2) HIPCHK(ctx, hipEventSynchronize(done[b]));
+        const double tp = now_s();
         parallel_pread(fd, (uint8_t*)ctx->stage_pin[b], stride, nr, nb, (off_t)sizeof h + (off_t)(row0 + r) * (off_t)h.row_bytes + b0,
                        (long)h.row_bytes, threads, &io_err);
+        ctx->st_pread_s += now_s() - tp;
+        ctx->st_file_bytes += nr * nb;
         if (io_err) { (void)hipStreamSynchronize(ctx->stream); return eagle_fail(ctx, EAGLE_ERR_FORMAT, "short read from the 2-bit sidecar"); }
         HIPCHK(ctx, hipMemcpyAsync(ctx->stage_raw[b], ctx->stage_pin[b], (size_t)nr * stride, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipEventRecord(done[b], ctx->stream));
-        rc = eagle_dev_unpack2b(ctx, (const uint8_t*)ctx->stage_raw[b], nr, ncols, stride, (int)(col0 % 4), dst + r * ld, ld, bad.as<int>(), ctx->stream);
+        rc = eagle_dev_unpack2b(ctx, (const uint8_t*)ctx->stage_raw[b], nr, ncols, stride, (int)(col0 % 4), dst + r * ld, ld, bad, ctx->stream);
         if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
     }
     int nbad = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&nbad, bad.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&nbad, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (nbad) return failf(ctx, EAGLE_ERR_FORMAT, "%d invalid genotype codes in %s", nbad, sp.c_str());
     return EAGLE_OK;
@@ -731,10 +741,18 @@ static long stream_chunk_rows(long row_bytes, long total_rows_pad) {
 struct ChunkRing {
     int8_t* buf[2] = {nullptr, nullptr};
     hipEvent_t done[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> ev;  // start / end of every chunk's kernels (timed: eagle_last_stream_stats)
     long k = 0;
-    ~ChunkRing() { for (int b = 0; b < 2; b++) if (done[b]) (void)hipEventDestroy(done[b]); }
+    double t_begin = 0;
+    ~ChunkRing() {
+        for (int b = 0; b < 2; b++) if (done[b]) (void)hipEventDestroy(done[b]);
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    }
     int init(eagle_ctx* ctx) {
         for (int b = 0; b < 2; b++) HIPCHK(ctx, hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
+        ctx->st_chunks = ctx->st_file_bytes = 0;
+        ctx->st_pread_s = ctx->st_load_wall_s = ctx->st_wait_s = ctx->st_compute_s = ctx->st_total_s = 0;
+        t_begin = now_s();
         return EAGLE_OK;
     }
     // returns the buffer holding the freshly loaded tile (zero padded to clear_bytes); the caller launches its kernels on
@@ -742,7 +760,9 @@ struct ChunkRing {
     int load(eagle_ctx* ctx, const char* path, long row0, long nrows, long col0, long ncols, long ld, size_t clear_bytes, double mem_gb,
              int threads, int8_t** out) {
         const int b = (int)(k & 1);
+        const double t0 = now_s();
         if (k >= 2) HIPCHK(ctx, hipEventSynchronize(done[b]));  // the kernels that read this buffer two chunks ago
+        const double t1 = now_s();
         hipStream_t main = ctx->stream;
         ctx->stream = ctx->load_stream;  // every loader below works on ctx->stream
         int rc = EAGLE_OK;
@@ -752,12 +772,37 @@ struct ChunkRing {
         if (!rc && (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) rc = eagle_fail_hip(ctx, e, "chunk load sync");
         ctx->stream = main;
         *out = buf[b];
+        ctx->st_wait_s += t1 - t0;
+        ctx->st_load_wall_s += now_s() - t1;
+        hipEvent_t e0 = nullptr;  // the chunk's kernels start here on ctx->stream
+        if (!rc && hipEventCreate(&e0) == hipSuccess) { ev.push_back(e0); (void)hipEventRecord(e0, ctx->stream); }
         return rc;
     }
     int computed(eagle_ctx* ctx) {
+        hipEvent_t e1 = nullptr;
+        if (ev.size() == (size_t)(2 * k + 1) && hipEventCreate(&e1) == hipSuccess) { ev.push_back(e1); (void)hipEventRecord(e1, ctx->stream); }
         HIPCHK(ctx, hipEventRecord(done[(int)(k & 1)], ctx->stream));
         k++;
         return EAGLE_OK;
+    }
+    // after the last chunk: waits for its kernels and closes the books
+    void finish(eagle_ctx* ctx) {
+        (void)hipStreamSynchronize(ctx->stream);
+        double ms = 0;
+        for (size_t i = 0; i + 1 < ev.size(); i += 2) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, ev[i], ev[i + 1]) == hipSuccess) ms += t;
+        }
+        ctx->st_chunks = k;
+        ctx->st_compute_s = ms / 1e3;
+        ctx->st_total_s = now_s() - t_begin;
+        if (timing_on())
+            fprintf(stderr, "[eaglehip] streamed: %ld chunks, %.3f GB read in %.3f s (%.2f GB/s while reading), loads %.3f s, kernels %.3f s, "
+                            "waits for a free buffer %.3f s, wall %.3f s, overlap %.0f %% of the shorter leg\n",
+                    k, ctx->st_file_bytes / 1e9, ctx->st_pread_s, ctx->st_pread_s > 0 ? ctx->st_file_bytes / 1e9 / ctx->st_pread_s : 0.0,
+                    ctx->st_load_wall_s, ctx->st_compute_s, ctx->st_wait_s, ctx->st_total_s,
+                    100.0 * std::max(0.0, ctx->st_load_wall_s + ctx->st_compute_s - ctx->st_total_s) /
+                        std::max(1e-9, std::min(ctx->st_load_wall_s, ctx->st_compute_s)));
     }
 };
 
@@ -866,6 +911,7 @@ static int mmt_range(eagle_ctx* ctx, const char* path, long n, long L, long c0, 
         }
         if ((rc = ring.computed(ctx))) return rc;
     }
+    ring.finish(ctx);
     return EAGLE_OK;
 }
 
@@ -1128,6 +1174,7 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
         if (rc) break;
         if (streamed && (rc = ring.computed(ctx))) break;
     }
+    if (streamed && !rc) ring.finish(ctx);
     if (global_cert) {
         double lb = 0.0;  // this shard's lower bound of the maximum tsq (0 for an empty shard)
         if (!rc && Lr > 0) {
@@ -1244,6 +1291,13 @@ extern "C" int eagle_scan_with_W(eagle_ctx* ctx, const char* f_name_ascii, const
     return EAGLE_OK;
 }
 
+extern "C" int eagle_last_stream_stats(eagle_ctx* ctx, eagle_stream_stats* out) {
+    if (!ctx || !out) return EAGLE_ERR_ARG;
+    out->chunks = ctx->st_chunks; out->file_bytes = ctx->st_file_bytes;
+    out->pread_s = ctx->st_pread_s; out->load_s = ctx->st_load_wall_s; out->wait_s = ctx->st_wait_s;
+    out->kernel_s = ctx->st_compute_s; out->wall_s = ctx->st_total_s;
+    return EAGLE_OK;
+}
 extern "C" int eagle_last_scan_certificate(eagle_ctx* ctx, long* n_reevaluated, long* n_flagged, int* fell_back) {
     if (!ctx) return EAGLE_ERR_ARG;
     if (n_reevaluated) *n_reevaluated = ctx->cert_reevaluated;
@@ -1389,6 +1443,7 @@ static int reduced_a_range(eagle_ctx* ctx, const char* f_name_ascii, long n, lon
         if (rc) return rc;
         if (streamed && (rc = ring.computed(ctx))) return rc;
     }
+    if (streamed) ring.finish(ctx);
     std::vector<long> in_range;
     for (long r : sel) if (r >= m0 && r < m1) in_range.push_back(r - m0);
     if (!in_range.empty()) {  // :74-78
