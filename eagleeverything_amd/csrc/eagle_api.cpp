@@ -751,8 +751,7 @@ struct ChunkRing {
     int init(eagle_ctx* ctx) {
         for (int b = 0; b < 2; b++) HIPCHK(ctx, hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
         ctx->st_chunks = ctx->st_file_bytes = 0;
-        ctx->st_pread_s = ctx->st_load_wall_s = ctx->st_wait_s = ctx->st_compute_s = ctx->st_total_s = 0;
-        t_begin = now_s();
+        ctx->st_pread_s = ctx->st_load_wall_s = ctx->st_wait_s = ctx->st_compute_s = ctx->st_total_s = ctx->st_starved_s = ctx->st_load_first_s = 0;
         return EAGLE_OK;
     }
     // returns the buffer holding the freshly loaded tile (zero padded to clear_bytes); the caller launches its kernels on
@@ -761,6 +760,7 @@ struct ChunkRing {
              int threads, int8_t** out) {
         const int b = (int)(k & 1);
         const double t0 = now_s();
+        if (k == 0) t_begin = t0;
         if (k >= 2) HIPCHK(ctx, hipEventSynchronize(done[b]));  // the kernels that read this buffer two chunks ago
         const double t1 = now_s();
         hipStream_t main = ctx->stream;
@@ -774,6 +774,9 @@ struct ChunkRing {
         *out = buf[b];
         ctx->st_wait_s += t1 - t0;
         ctx->st_load_wall_s += now_s() - t1;
+        if (k == 0) ctx->st_load_first_s = now_s() - t1;
+        if (timing_on() && getenv("EAGLE_HIP_TIMING")[0] == '2')
+            fprintf(stderr, "[eaglehip]   chunk %ld: host waits %.1f..%.1f ms, loads ..%.1f ms\n", k, (t0 - t_begin) * 1e3, (t1 - t_begin) * 1e3, (now_s() - t_begin) * 1e3);
         hipEvent_t e0 = nullptr;  // the chunk's kernels start here on ctx->stream
         if (!rc && hipEventCreate(&e0) == hipSuccess) { ev.push_back(e0); (void)hipEventRecord(e0, ctx->stream); }
         return rc;
@@ -782,27 +785,32 @@ struct ChunkRing {
         hipEvent_t e1 = nullptr;
         if (ev.size() == (size_t)(2 * k + 1) && hipEventCreate(&e1) == hipSuccess) { ev.push_back(e1); (void)hipEventRecord(e1, ctx->stream); }
         HIPCHK(ctx, hipEventRecord(done[(int)(k & 1)], ctx->stream));
+        if (timing_on() && getenv("EAGLE_HIP_TIMING")[0] == '2') fprintf(stderr, "[eaglehip]   chunk %ld: kernels launched at %.1f ms\n", k, (now_s() - t_begin) * 1e3);
         k++;
         return EAGLE_OK;
     }
     // after the last chunk: waits for its kernels and closes the books
     void finish(eagle_ctx* ctx) {
         (void)hipStreamSynchronize(ctx->stream);
-        double ms = 0;
+        double ms = 0, starved = 0;
         for (size_t i = 0; i + 1 < ev.size(); i += 2) {
             float t = 0;
             if (hipEventElapsedTime(&t, ev[i], ev[i + 1]) == hipSuccess) ms += t;
+            // the compute stream sat idle between the end of chunk k's kernels and the moment chunk k+1 was loaded
+            if (i + 2 < ev.size() && hipEventElapsedTime(&t, ev[i + 1], ev[i + 2]) == hipSuccess) starved += t;
         }
         ctx->st_chunks = k;
         ctx->st_compute_s = ms / 1e3;
+        ctx->st_starved_s = starved / 1e3;
         ctx->st_total_s = now_s() - t_begin;
-        if (timing_on())
-            fprintf(stderr, "[eaglehip] streamed: %ld chunks, %.3f GB read in %.3f s (%.2f GB/s while reading), loads %.3f s, kernels %.3f s, "
-                            "waits for a free buffer %.3f s, wall %.3f s, overlap %.0f %% of the shorter leg\n",
+        if (timing_on()) {
+            const double later = ctx->st_load_wall_s - ctx->st_load_first_s;  // loads that had kernels to hide under
+            fprintf(stderr, "[eaglehip] streamed: %ld chunks, %.3f GB read in %.3f s (%.2f GB/s while reading), loads %.3f s (first %.3f s), "
+                            "kernels %.3f s, compute stream starved for %.3f s (%.0f %% of the later loads hidden), wall %.3f s\n",
                     k, ctx->st_file_bytes / 1e9, ctx->st_pread_s, ctx->st_pread_s > 0 ? ctx->st_file_bytes / 1e9 / ctx->st_pread_s : 0.0,
-                    ctx->st_load_wall_s, ctx->st_compute_s, ctx->st_wait_s, ctx->st_total_s,
-                    100.0 * std::max(0.0, ctx->st_load_wall_s + ctx->st_compute_s - ctx->st_total_s) /
-                        std::max(1e-9, std::min(ctx->st_load_wall_s, ctx->st_compute_s)));
+                    ctx->st_load_wall_s, ctx->st_load_first_s, ctx->st_compute_s, ctx->st_starved_s,
+                    later > 0 ? 100.0 * std::max(0.0, 1.0 - ctx->st_starved_s / later) : 100.0, ctx->st_total_s);
+        }
     }
 };
 
@@ -1296,6 +1304,7 @@ extern "C" int eagle_last_stream_stats(eagle_ctx* ctx, eagle_stream_stats* out) 
     out->chunks = ctx->st_chunks; out->file_bytes = ctx->st_file_bytes;
     out->pread_s = ctx->st_pread_s; out->load_s = ctx->st_load_wall_s; out->wait_s = ctx->st_wait_s;
     out->kernel_s = ctx->st_compute_s; out->wall_s = ctx->st_total_s;
+    out->load_first_s = ctx->st_load_first_s; out->starved_s = ctx->st_starved_s;
     return EAGLE_OK;
 }
 extern "C" int eagle_last_scan_certificate(eagle_ctx* ctx, long* n_reevaluated, long* n_flagged, int* fell_back) {

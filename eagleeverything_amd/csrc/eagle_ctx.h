@@ -83,7 +83,7 @@ struct eagle_ctx {
     long cert_reevaluated = 0, cert_flagged = 0; int cert_fell_back = 0;  // certification counters of the last digit-slice scan
     // out-of-core bookkeeping of the last streamed call on this device (eagle_last_stream_stats)
     long st_chunks = 0, st_file_bytes = 0;
-    double st_pread_s = 0, st_load_wall_s = 0, st_wait_s = 0, st_compute_s = 0, st_total_s = 0;
+    double st_pread_s = 0, st_load_wall_s = 0, st_wait_s = 0, st_compute_s = 0, st_total_s = 0, st_starved_s = 0, st_load_first_s = 0;
     void* d_scratch = nullptr;
     void* arena = nullptr; size_t arena_cap = 0, arena_off = 0;  // grow-only device workspace reused across calls
     void* f4_buf = nullptr; size_t f4_cap = 0;  // fp4 image of the tile eagle_dev_mmt_accumulate is working on

@@ -250,20 +250,21 @@ def last_scan_argmax(device=0):
 
 class _StreamStats(C.Structure):
     _fields_ = [("chunks", C.c_long), ("file_bytes", C.c_long), ("pread_s", C.c_double), ("load_s", C.c_double),
-                ("wait_s", C.c_double), ("kernel_s", C.c_double), ("wall_s", C.c_double)]
+                ("wait_s", C.c_double), ("kernel_s", C.c_double), ("wall_s", C.c_double), ("load_first_s", C.c_double),
+                ("starved_s", C.c_double)]
 
 
 def last_stream_stats(device=0):
     """Out-of-core bookkeeping of the last call that streamed its file in marker chunks (include/eagle_hip.h,
-    eagle_last_stream_stats), plus the derived storage rate and overlap fraction."""
+    eagle_last_stream_stats), plus the derived storage rate and the fraction of the load time hidden under kernels."""
     L = _lib.load()
     ctx = context(device)
     st = _StreamStats()
     _check(ctx, L.eagle_last_stream_stats(ctx, C.byref(st)))
     d = {k: getattr(st, k) for k, _ in _StreamStats._fields_}
     d["read_GBps"] = d["file_bytes"] / 1e9 / d["pread_s"] if d["pread_s"] > 0 else 0.0
-    short = min(d["load_s"], d["kernel_s"])
-    d["overlap"] = max(0.0, d["load_s"] + d["kernel_s"] - d["wall_s"]) / short if short > 0 else 0.0
+    later = d["load_s"] - d["load_first_s"]
+    d["load_hidden_frac"] = max(0.0, 1.0 - d["starved_s"] / later) if later > 0 else 1.0
     return d
 
 

@@ -367,15 +367,17 @@ int eagle_last_scan_certificate(eagle_ctx* ctx, long* n_reevaluated, long* n_fla
 /* Out-of-core bookkeeping of the LAST call of this ctx that streamed its file through HBM in marker chunks (a file larger than
  * free HBM or than EAGLE_HIP_MAX_RESIDENT_GB; the lead device's share in a multi-device context): what SURVEY 8(d) asks to be
  * reported for the streamed configurations.  The loader of chunk k+1 (pread -> pinned -> H2D -> decode / 2-bit unpack) runs
- * under the kernels of chunk k; overlap = (load_s + kernel_s - wall_s) / min(load_s, kernel_s). */
+ * under the kernels of chunk k.  Fraction of the load time hidden = 1 - starved_s / (load_s - load_first_s). */
 typedef struct eagle_stream_stats {
-    long chunks;       /* marker chunks */
-    long file_bytes;   /* bytes read from the genotype file (text, or its 2-bit sidecar) */
-    double pread_s;    /* host seconds inside the parallel preads (file_bytes / pread_s = storage rate) */
-    double load_s;     /* host seconds in the chunk loaders (read + H2D + decode, synchronised per chunk) */
-    double wait_s;     /* host seconds waiting for a free chunk buffer (kernels of chunk k-2 still running) */
-    double kernel_s;   /* device seconds of the chunks' kernels (HIP events on the compute stream) */
-    double wall_s;     /* first load to last kernel */
+    long chunks;         /* marker chunks */
+    long file_bytes;     /* bytes read from the genotype file (text, or its 2-bit sidecar) */
+    double pread_s;      /* host seconds inside the parallel preads (file_bytes / pread_s = storage rate) */
+    double load_s;       /* host seconds in the chunk loaders (read + H2D + decode, synchronised per chunk) */
+    double wait_s;       /* host seconds waiting for a free chunk buffer (kernels of chunk k-2 still running) */
+    double kernel_s;     /* device seconds of the chunks' kernels (HIP events on the compute stream) */
+    double wall_s;       /* first load to last kernel (includes whatever the compute stream had queued before chunk 0, e.g. W = S V S) */
+    double load_first_s; /* the first chunk's load: nothing of this call's chunk kernels to hide under */
+    double starved_s;    /* device seconds the compute stream sat idle between chunks because the next one was not loaded yet */
 } eagle_stream_stats;
 int eagle_last_stream_stats(eagle_ctx* ctx, eagle_stream_stats* out);
 /* The same quadratic form on the block-scaled matrix path (v_mfma_scale_f32_32x32x64_f8f6f4): genotypes as fp4, balanced
