@@ -404,6 +404,11 @@ static void parallel_pread(int fd, uint8_t* dst, long dst_stride, long nrows, lo
             }
         }
     };
+    // a thread per >= 2 MiB of the read, 32 at most: num_cores comes from the caller (R hands detectCores()), and spawning
+    // hundreds of threads per 64 MiB staging buffer costs more than the reads
+    const long by_size = (nrows * nbytes) >> 21;
+    if (threads > 32) threads = 32;
+    if (threads > by_size) threads = (int)by_size;
     if (threads <= 1 || nrows < 2 * threads) { work(0, nrows); return; }
     std::vector<std::thread> pool;
     long per = (nrows + threads - 1) / threads;
