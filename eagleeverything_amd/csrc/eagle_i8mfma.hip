@@ -660,7 +660,7 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8(const int8_t* __restrict__ M
 // 8 waves sit 4 (M) x 2 (N) with a 96 x 128 wave tile = 3 x 4 MFMA tiles (192 accumulator registers): 7 fragment reads per
 // 12 MFMAs (-22 % LDS reads per MAC) and 80 KiB of fill per 48 MFMAs per wave (-17 % L2 -> LDS bytes per MAC).  Stages are
 // double buffered (2 x (48 + 32) KiB = all 160 KiB), so the tile epilogue takes its genotype bytes from global memory (L2).
-// Same integer sums as k_vara_i8: bit-identical q.  int32 butterfly over 128 columns per wave: n_pad < 32768.
+// Same integer sums as k_vara_i8: bit-identical q.  int32 butterfly over 128 columns per wave: n_pad < 32768 (k_vara_i8p<2> lifts that).
 // ------------------------------------------------------------------------------------------------
 #define TW_M 384
 #define TW_ABYTES (TW_M * BK8)
@@ -886,6 +886,9 @@ __device__ __forceinline__ void tx_kstep(TxAcc& c, i32x4 (&a)[3], i32x4 (&an)[3]
 __device__ __forceinline__ void tx_klast(TxAcc& c, i32x4 (&a)[3], i32x4 (&an)[3], i32x4 (&b)[4], unsigned pa, unsigned pb, XDma& da) {
     asm volatile(X_KLAST : X_ACC_RW(0), X_ACC_RW(1), X_ACC_RW(2), X_FRAGS, X_DMA_OUT(a, da) : [pa] "v"(pa), [pb] "v"(pb), X_DMA_IN(a, da) : "memory");
 }
+// NSUM: the tile row-dot sums 128 columns per wave in int32: |sum| <= 65536 K for a K-deep tile, i.e. n_pad < 32768 in one sum;
+// NSUM = 2 sums the two 64-column halves separately (n_pad < 65536; the 64-bit totals are the same integers).
+template <int NSUM>
 __global__ __launch_bounds__(512, 2) void k_vara_i8p(const int8_t* __restrict__ Mt8, long ld, int ntm, const int8_t* __restrict__ Bs,
                                                      long np, const VaraHdr* __restrict__ hdr, long long* __restrict__ q, long Lp, int cut_last_round) {
     extern __shared__ __attribute__((aligned(1024))) int8_t ldsv[];  // [2][A 48 KiB | B 32 KiB]
@@ -980,28 +983,31 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8p(const int8_t* __restrict__ 
             const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
 #pragma unroll
             for (int m = 0; m < 3; m++) {
-                int v16[16], v8[8], v4[4], v2[2];
 #pragma unroll
-                for (int x = 0; x < 16; x++) {
-                    const int so = (m * 32 + (x & 3) + 8 * (x >> 2)) * ldi + ecol;
-                    int sacc = 0;
+                for (int half = 0; half < NSUM; half++) {
+                    int v16[16], v8[8], v4[4], v2[2];
 #pragma unroll
-                    for (int n = 0; n < 4; n++) {
-                        const int g = (int)(int8_t)__builtin_amdgcn_raw_buffer_load_b8(rsA, evoff, so + n * 32, 0);
-                        sacc += c[m][n][x] * g;
+                    for (int x = 0; x < 16; x++) {
+                        const int so = (m * 32 + (x & 3) + 8 * (x >> 2)) * ldi + ecol;
+                        int sacc = 0;
+#pragma unroll
+                        for (int n = half * (4 / NSUM); n < (half + 1) * (4 / NSUM); n++) {
+                            const int g = (int)(int8_t)__builtin_amdgcn_raw_buffer_load_b8(rsA, evoff, so + n * 32, 0);
+                            sacc += c[m][n][x] * g;
+                        }
+                        v16[x] = sacc;
                     }
-                    v16[x] = sacc;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) { int snd = b0 ? v16[i] : v16[i + 8]; int kp = b0 ? v16[i + 8] : v16[i]; v8[i] = kp + __shfl_xor(snd, 1); }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { int snd = b1 ? v8[i] : v8[i + 4]; int kp = b1 ? v8[i + 4] : v8[i]; v4[i] = kp + __shfl_xor(snd, 2); }
+#pragma unroll
+                    for (int i = 0; i < 2; i++) { int snd = b2 ? v4[i] : v4[i + 2]; int kp = b2 ? v4[i + 2] : v4[i]; v2[i] = kp + __shfl_xor(snd, 4); }
+                    int v1 = (b3 ? v2[1] : v2[0]) + __shfl_xor(b3 ? v2[0] : v2[1], 8);
+                    v1 += __shfl_xor(v1, 16);
+                    keep[m] += v1;
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-#pragma unroll
-                for (int i = 0; i < 8; i++) { int snd = b0 ? v16[i] : v16[i + 8]; int kp = b0 ? v16[i + 8] : v16[i]; v8[i] = kp + __shfl_xor(snd, 1); }
-#pragma unroll
-                for (int i = 0; i < 4; i++) { int snd = b1 ? v8[i] : v8[i + 4]; int kp = b1 ? v8[i + 4] : v8[i]; v4[i] = kp + __shfl_xor(snd, 2); }
-#pragma unroll
-                for (int i = 0; i < 2; i++) { int snd = b2 ? v4[i] : v4[i + 2]; int kp = b2 ? v4[i + 2] : v4[i]; v2[i] = kp + __shfl_xor(snd, 4); }
-                int v1 = (b3 ? v2[1] : v2[0]) + __shfl_xor(b3 ? v2[0] : v2[1], 8);
-                v1 += __shfl_xor(v1, 16);
-                keep[m] += v1;
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -1444,13 +1450,14 @@ extern "C" int eagle_dev_vara_i8_mfma_shifted(eagle_ctx* ctx, const int8_t* Mt8s
     }
     // The 384 x 256 tile is the default (C2: 23.05 -> 21.91 ms, C3 shape: 45.2 -> 43.1 ms per 262144 markers; profiles/
     // r02_ab_vara_tile.txt), since round 2 in its asm-pipelined form k_vara_i8p (another -4 to -5 %, profiles/r02_ab_vara_pipe.txt).
-    // All forms give bit-identical q.  The 256 x 256 form serves n_pad >= 32768 (its int32 butterfly spans 64 columns per wave
-    // instead of 128).  A/B switches of tools/bench_vara.py: tune 8 = the 256 x 256 form, 9 = the compiler-scheduled 384 x 256
+    // All forms give bit-identical q.  n_pad >= 32768: the pipelined kernel sums the two 64-column halves of its tile row-dot
+    // separately (int32 range); the 256 x 256 form serves n_pad >= 65536.  A/B switches of tools/bench_vara.py: tune 8 = the 256 x 256 form, 9 = the compiler-scheduled 384 x 256
     // form (k_vara_i8w), 7 = whole workers in the last round.
-    if (ctx->tune != 8 && n_pad < 32768) {
+    if (ctx->tune != 8 && (n_pad < 32768 || (ctx->tune != 9 && n_pad < 65536))) {
         const bool piped = ctx->tune != 9;
-        const void* kfn = piped ? (const void*)k_vara_i8p : (const void*)k_vara_i8w;
-        bool& attr = piped ? ctx->attr_vara_i8p : ctx->attr_vara_i8w;
+        const bool two_sums = n_pad >= 32768;
+        const void* kfn = !piped ? (const void*)k_vara_i8w : two_sums ? (const void*)k_vara_i8p<2> : (const void*)k_vara_i8p<1>;
+        bool& attr = !piped ? ctx->attr_vara_i8w : two_sums ? ctx->attr_vara_i8p2 : ctx->attr_vara_i8p;
         if (!attr) {
             hipError_t ea = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TW_ABYTES + TILE_BYTES));
             if (ea != hipSuccess) return eagle_fail_hip(ctx, ea, "hipFuncSetAttribute(k_vara_i8p/w)");
@@ -1460,8 +1467,9 @@ extern "C" int eagle_dev_vara_i8_mfma_shifted(eagle_ctx* ctx, const int8_t* Mt8s
         // per XCD at most gw * smax workers, plus at most 32 more blocks when the last round is cut into pieces
         const dim3 gridw((unsigned)(8 * (gw * smax + 32)));
         const int cut = ctx->tune == 7 ? 0 : 1;
-        if (piped) hipLaunchKernelGGL(k_vara_i8p, gridw, dim3(512), 2 * (TW_ABYTES + TILE_BYTES), s, Mt8s, ld, ntw, Bs, n_pad, hdr, q, L_pad, cut);
-        else hipLaunchKernelGGL(k_vara_i8w, gridw, dim3(512), 2 * (TW_ABYTES + TILE_BYTES), s, Mt8s, ld, ntw, Bs, n_pad, hdr, q, L_pad, cut);
+        if (!piped) hipLaunchKernelGGL(k_vara_i8w, gridw, dim3(512), 2 * (TW_ABYTES + TILE_BYTES), s, Mt8s, ld, ntw, Bs, n_pad, hdr, q, L_pad, cut);
+        else if (two_sums) hipLaunchKernelGGL(k_vara_i8p<2>, gridw, dim3(512), 2 * (TW_ABYTES + TILE_BYTES), s, Mt8s, ld, ntw, Bs, n_pad, hdr, q, L_pad, cut);
+        else hipLaunchKernelGGL(k_vara_i8p<1>, gridw, dim3(512), 2 * (TW_ABYTES + TILE_BYTES), s, Mt8s, ld, ntw, Bs, n_pad, hdr, q, L_pad, cut);
     } else
     hipLaunchKernelGGL(k_vara_i8, dim3((unsigned)(groups * 8 * smax)), dim3(512), 5 * TILE_BYTES, s, Mt8s, ld, ntm, Bs, n_pad, hdr, q, L_pad);
     hipLaunchKernelGGL(k_vara_i8_finish, dim3((unsigned)((L_pad + 255) / 256)), dim3(256), 0, s, q, L_pad, hdr, vdiag, cshift, mrho, vara_out);
