@@ -30,12 +30,14 @@ def shard_range(L, rank, world):
 class Collectives:
     """The two exchange steps of the sharded path."""
 
-    def __init__(self, dist=None):
+    def __init__(self, dist=None, force=False):
+        """force: issue the collectives even in a group of ONE rank (the RCCL calls of a one-GPU box: tests/test_sharded_rccl1.py)."""
         self.dist = dist
         self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
-        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.active = self.world > 1 or (force and dist is not None and dist.is_initialized())
+        self.rank = dist.get_rank() if self.active else 0
         # gloo (CPU tests, and the 2-ranks-on-one-GPU rehearsal of bench.py) moves device tensors through the host
-        self.via_host = self.world > 1 and dist.get_backend() == "gloo"
+        self.via_host = self.active and dist.get_backend() == "gloo"
 
     def _staged(self, t, fn):
         if self.via_host and t.is_cuda:
@@ -52,7 +54,7 @@ class Collectives:
         dst = None: all-reduce (every rank holds the sum); dst = r: reduce to rank r only -- MM^T goes back to ONE host
         process (calculateMMt_rcpp returns it to R), so the other ranks need not receive it: half the link traffic; their
         tensors are unspecified afterwards."""
-        if self.world > 1:
+        if self.active:
             np_ = c32.shape[0]
             if dst is None:
                 red = lambda x: self.dist.all_reduce(x, op=self.dist.ReduceOp.SUM)
@@ -73,7 +75,7 @@ class Collectives:
 
     def all_gather_rows(self, full, mine):
         """full (world * rows x cols, contiguous) <- the ranks' row blocks `mine` (rows x cols), in rank order."""
-        if self.world == 1:
+        if not self.active:
             return full
         if self.via_host and full.is_cuda:
             import torch
@@ -85,7 +87,7 @@ class Collectives:
         return full
 
     def broadcast_(self, t, src=0):
-        if self.world > 1:
+        if self.active:
             self._staged(t, lambda x: self.dist.broadcast(x, src=src))
         return t
 
@@ -95,7 +97,7 @@ class Collectives:
         import torch
         mine = torch.tensor([float(local_tsqmax), float(local_index0_global)], dtype=torch.float64,
                             device=None if self.via_host else device)
-        if self.world > 1:
+        if self.active:
             allv = [torch.empty_like(mine) for _ in range(self.world)]
             self.dist.all_gather(allv, mine)
             allv = torch.stack(allv).cpu().numpy()
@@ -280,7 +282,7 @@ class DeviceShard:
             return
         world = coll.world if coll is not None else 1
         nt = self.np_ // 128
-        if world > 1 and nt % world == 0 and self.share_w:
+        if coll is not None and coll.active and nt % world == 0 and self.share_w:
             rows = self.np_ // world
             r0 = coll.rank * rows
             self._check(self.L.eagle_dev_scan_operands_rows(self.ctx, self.Sa.data_ptr(), self.Va.data_ptr(), self.ahat.data_ptr(),

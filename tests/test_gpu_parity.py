@@ -328,6 +328,11 @@ def test_streamed_paths_match_resident(big, api, oracle, monkeypatch):
             idx=api.last_scan_argmax(),
             ar=api.calculate_reduced_a_rcpp(geno["asciifileMt"], 0.7, P, y, 8.0, (n, L), NA))
         assert any("streamed" in m for m in msgs) == (budget is not None)
+        if budget:  # the library's out-of-core books (eagle_last_stream_stats) of the last streamed call: the reduced-a pass
+            st = api.last_stream_stats()
+            assert st["chunks"] >= 2 and st["file_bytes"] >= L * n // 4 and st["pread_s"] > 0.0
+            assert 0.0 < st["load_first_s"] <= st["load_s"] <= st["wall_s"] + 1e-3 and st["kernel_s"] > 0.0
+            assert 0.0 <= st["starved_s"] <= st["wall_s"] and 0.0 <= st["load_hidden_frac"] <= 1.0
     monkeypatch.delenv("EAGLE_HIP_MAX_RESIDENT_GB")
     api.drop_cache()
     for k in ("mmt", "mmt_m", "ar"):
