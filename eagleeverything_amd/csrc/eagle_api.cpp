@@ -176,7 +176,10 @@ extern "C" eagle_ctx* eagle_open_devices(const int* devices, int ndev) {
     bool distinct = true;
     for (int a = 0; a < ndev; a++) for (int b = a + 1; b < ndev; b++) if (devices[a] == devices[b]) distinct = false;
     const char* env = getenv("EAGLE_HIP_COLLECTIVES");
-    if (ndev > 1 && distinct && !(env && strcmp(env, "host") == 0)) {
+    // EAGLE_HIP_COLLECTIVES=host: host-staged stand-in instead of RCCL; =rccl with ONE device: the exchange steps run anyway, on
+    // a communicator of one rank (what a one-GPU box can exercise of the RCCL leg: tests/test_multi_device.py)
+    const bool force1 = ndev == 1 && env && strcmp(env, "rccl") == 0;
+    if ((ndev > 1 || force1) && distinct && !(env && strcmp(env, "host") == 0)) {
         lead->rccl = rccl_open(devices, ndev, g_open_err, sizeof g_open_err);
         if (!lead->rccl) { eagle_close(lead); return nullptr; }
     }
@@ -961,7 +964,7 @@ extern "C" int eagle_calculateMMt(eagle_ctx* ctx, const char* f_name_ascii, doub
         hipError_t e = hipSetDevice(c->device);
         int r = e == hipSuccess ? mmt_range(c, f_name_ascii, n, L, edge[k], edge[k + 1], sel, max_memory_in_Gbytes, threads, quiet)
                                 : eagle_fail_hip(c, e, "hipSetDevice");
-        if (nd == 1) return r;
+        if (nd == 1 && !rccl) return r;
         // ONE sum of the partials: the upper 256-tiles of every device's accumulator, packed, to the lead
         if (!r) r = ensure_buf(c, &c->d_pack, &c->pack_cap, sizeof(int32_t) * (size_t)packed, "packed MM^T hipMalloc");
         if (!r) r = eagle_dev_tiles_pack(c, c->d_c32, np, c->d_pack, 0, c->stream);
@@ -986,7 +989,7 @@ extern "C" int eagle_calculateMMt(eagle_ctx* ctx, const char* f_name_ascii, doub
         return r;
     });
     if (rc) return rc;
-    if (nd > 1 && (rc = eagle_dev_tiles_pack(ctx, ctx->d_c32, np, ctx->d_pack, 1, ctx->stream))) return rc;
+    if ((nd > 1 || rccl) && (rc = eagle_dev_tiles_pack(ctx, ctx->d_c32, np, ctx->d_pack, 1, ctx->stream))) return rc;
     if (ctx->mmt_n != n) {
         if (ctx->d_mmt) { (void)hipFree(ctx->d_mmt); ctx->d_mmt = nullptr; }
         ctx->mmt_n = 0;
@@ -1039,7 +1042,7 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
     const size_t sq = sizeof(double) * (size_t)np * np;
     const bool use_i8 = ctx->scan_mode == 1 && 64.0 * 512.0 * (double)np < 2147483648.0;
     const int nslices = ctx->scan_slices | (ctx->scan_stochastic ? EAGLE_SLICES_STOCHASTIC : 0);
-    const bool share_w = !w_direct && nd > 1 && rccl && (np / 128) % nd == 0;  // the same answer on every device
+    const bool share_w = !w_direct && rccl && (np / 128) % nd == 0;  // the same answer on every device (rccl: several devices, or one forced)
     int rc = EAGLE_OK;
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) rc = eagle_fail_hip(ctx, e, "hipSetDevice");
@@ -1265,7 +1268,7 @@ extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_asc
     RcclState* rccl = (RcclState*)ctx->rccl;
     rc = run_on_devices(ctx, [&](int k, eagle_ctx* c) -> int {
         return scan_range(c, f_name_ascii, L, n, edge[k], edge[k + 1], sel, inv_MMt_sqrt, dim_reduced_vara, a, max_memory_in_Gbytes, quiet,
-                          a_out, vara_out, k, nd, nd > 1 ? &rv : nullptr, rccl);
+                          a_out, vara_out, k, nd, nd > 1 || rccl ? &rv : nullptr, rccl);
     });
     if (rc) return rc;
     for (eagle_ctx* p : ctx->peers) {

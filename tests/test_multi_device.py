@@ -4,7 +4,8 @@ E/R/AM.R:185-196): every call shards the file's markers over the devices of the 
 The build box has ONE card, so the device list names it two / three times: the same code path -- marker ranges, worker
 threads, rendezvous, partial MM^T packed and summed, lower bounds of the shards' maxima exchanged for the certificate,
 per-device results merged -- with the device-copy sum standing in for ncclReduce and W computed on every device instead of
-shared through ncclAllGather (the RCCL leg needs distinct devices and is not exercised here).
+shared through ncclAllGather (a transfer over RCCL needs distinct devices; the calls themselves run on a communicator of ONE
+device in the last test).
 Everything must come back bit for bit as from a single-device context.
 """
 import ctypes as C
@@ -156,3 +157,38 @@ def test_multi_device_streamed_shards(api, oracle, tmp_path, monkeypatch):
     np.testing.assert_allclose(many["vara"].ravel()[differ], one["vara"].ravel()[differ], rtol=1e-9)
     assert best_one[0] == best_many[0]
     api.drop_cache(device=dev)
+
+
+def test_exchange_steps_on_an_rccl_communicator_of_one(api, oracle, tmp_path, monkeypatch):
+    """EAGLE_HIP_COLLECTIVES=rccl with ONE device: the library dlopen()s RCCL, builds a communicator of one rank and runs the
+    exchange steps of the multi-device path on it -- ncclReduce of the packed int32 tiles, W's rows + ncclAllGather, the
+    rendezvous -- which is everything of the RCCL leg a one-GPU box can execute (the calls, their types and stream order; not a
+    transfer between devices).  Against the plain single-device context: MM^T exact, a exact, vara to rounding (W's row-block
+    form sums in another order than the upper-tile form), same marker."""
+    n, L = 700, 3000   # np = 768 = 6 row tiles of 128
+    rng = np.random.default_rng(5)
+    Mt8 = synth.genotypes_marker_major(n, L, seed=23)
+    A = rng.standard_normal((n, 40)) / 6.0
+    S = np.eye(n) + A @ A.T
+    V = 0.7 * np.eye(n) - 0.03 * (A[:, :3] @ A[:, :3].T)
+    ahat = rng.standard_normal(n)
+    geno = synth.write_geno_pair(str(tmp_path), Mt8)
+    P = 0.3 * np.eye(n) + 0.01 * (A @ A.T)
+    y = rng.standard_normal((n, 1))
+    sel = np.array([7.0, 1500.0, 2999.0])
+    one = _all_calls(api, geno, n, L, S, V, ahat, P, y, sel, device=0)
+    api.drop_cache(device=0)
+    monkeypatch.setenv("EAGLE_HIP_COLLECTIVES", "rccl")
+    forced = _all_calls(api, geno, n, L, S, V, ahat, P, y, sel, device=(0,))   # opened now, with the variable set
+    monkeypatch.delenv("EAGLE_HIP_COLLECTIVES")
+    for key in one:
+        if key == "geno":
+            for x, z in zip(one[key], forced[key]):
+                np.testing.assert_array_equal(x, z)
+        elif key.startswith("best"):
+            assert one[key][0] == forced[key][0], key
+        elif key.startswith("vara"):
+            np.testing.assert_allclose(forced[key], one[key], rtol=1e-10, err_msg=key)
+        else:
+            np.testing.assert_array_equal(one[key], forced[key], err_msg=key)
+    api.drop_cache(device=(0,))
