@@ -73,16 +73,19 @@ def _zeroin(f, a, b, tol=_EPS25, maxit=1000):
 
 
 def emma_eigen_L_wo_Z(K):
-    ev, U = host_model.algebra().eigh(K)
-    return {"values": ev[::-1].copy(), "vectors": U[:, ::-1].copy()}  # R's eigen(): decreasing order
+    ev, U = host_model.algebra().eigh_desc(K)  # R's eigen(): decreasing order
+    return {"values": np.ascontiguousarray(ev), "vectors": U if U.flags.f_contiguous or U.flags.c_contiguous else U.copy()}
 
 
 def emma_eigen_R_wo_Z(K, X):
     n, q = X.shape
     la = host_model.algebra()
-    S = np.eye(n) - X @ np.linalg.solve(X.T @ X, X.T)
-    ev, U = la.eigh(la.mm(la.mm(S, K + np.eye(n)), S))
-    ev, U = ev[::-1], U[:, ::-1]
+    S = X @ np.linalg.solve(X.T @ X, X.T)      # S = diag(n) - X (X'X)^-1 X', without the n x n identity
+    np.negative(S, out=S)
+    S.flat[:: n + 1] += 1.0
+    K1 = K.copy()                              # K + diag(n)
+    K1.flat[:: n + 1] += 1.0
+    ev, U = la.eigh_desc(la.mm(la.mm(S, K1), S))
     return {"values": ev[: n - q] - 1.0, "vectors": U[:, : n - q].copy()}
 
 

@@ -28,6 +28,12 @@ class _HostLA:
         return np.linalg.eigh(A)
 
     @staticmethod
+    def eigh_desc(A):
+        """R's eigen(): values decreasing (views of LAPACK's ascending result)."""
+        w, U = np.linalg.eigh(A)
+        return w[::-1], U[:, ::-1]
+
+    @staticmethod
     def chol2inv(A):
         c, low = sla.cho_factor(A, lower=False, check_finite=False)
         return sla.cho_solve((c, low), np.eye(A.shape[0]), check_finite=False)
@@ -55,6 +61,9 @@ class _DeviceLA:
     def eigh(self, A):
         w, U = self.api.sym_eig(A, device=self.device)   # R's order (decreasing); numpy's convention is ascending
         return w[::-1].copy(), np.ascontiguousarray(U[:, ::-1])
+
+    def eigh_desc(self, A):
+        return self.api.sym_eig(A, device=self.device)   # already R's order: no 8 n^2-byte reversal copies
 
     def chol2inv(self, A):
         return np.ascontiguousarray(self.api.chol2inv(A, device=self.device))
@@ -84,7 +93,9 @@ def calculateH(MMt, varE, varG):
     if varE < 0 or varG < 0:
         raise ValueError("variance components cannot be negative")  # calculateH.R:19-30
     n = MMt.shape[0]
-    return varE * np.eye(n) + varG * MMt
+    H = varG * MMt                 # varE * diag(n) + varG * MMt with one pass and no n x n identity
+    H.flat[:: n + 1] += varE
+    return H
 
 
 def _chol2inv(A):
@@ -96,7 +107,8 @@ def calculateP(H, X):
         raise ValueError("The number of rows in H and X are not the same.")  # calculateP.R:22-25
     Hinv = _chol2inv(H)
     HX = Hinv @ X
-    return Hinv - HX @ np.linalg.solve(X.T @ HX, HX.T)
+    T = HX @ np.linalg.solve(X.T @ HX, HX.T)
+    return np.subtract(Hinv, T, out=T)
 
 
 def calculateMMt_sqrt_and_sqrtinv(MMt, checkres=True):
@@ -139,12 +151,18 @@ def calculate_reduced_vara(X, varE, varG, invMMt, MMtsqrt):
     A = r1 * (X.T @ X)
     B = r1 * (X.T @ Ze)
     Cm = r1 * (Ze.T @ X)
-    D = r1 * _la.mm(Ze.T, Ze) + g1 * np.eye(n)
+    D = _la.mm(Ze.T, Ze)           # r1 * Ze'Ze + g1 * diag(n), in place: the same operations per element, two passes fewer
+    D *= r1
+    D.flat[:: n + 1] += g1
     D1 = _la.inv(D)
     D1C = D1 @ Cm
     BD1 = B @ D1
     mid = np.linalg.solve(A - B @ D1C, BD1)
-    return varG * np.eye(n) - (D1 + D1C @ mid)
+    T = D1C @ mid
+    np.add(D1, T, out=T)
+    np.subtract(0.0, T, out=T)     # varG * diag(n) - (D1 + D1C mid): off the diagonal 0 - t, on it varG - t
+    T.flat[:: n + 1] += varG
+    return T
 
 
 def scan_operands(MMt_norm, X, y, varE, varG):

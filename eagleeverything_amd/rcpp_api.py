@@ -309,14 +309,28 @@ def createMt_ASCII_rcpp(f_name, f_name_ascii, type, max_memory_in_Gbytes, dims, 
 
 
 # ---- the dense model algebra on the device, through the C ABI (opt-in; include/eagle_hip.h section 1c) ----
+def _square_any_order(A):
+    """(buffer, transposed): a float64 n x n array usable as a column-major matrix without a copy when it is contiguous in
+    either order -- a C-ordered buffer read column-major is the transpose, which the callers below undo for free
+    (symmetric input, or inv(A^T) = inv(A)^T).  A 200 MB layout change on one host core costs more than the device call."""
+    A = np.asarray(A, dtype=np.float64)
+    if A.ndim != 2 or A.shape[0] != A.shape[1]:
+        raise ValueError("square matrix expected")
+    if A.flags.f_contiguous and A.flags.aligned:
+        return A, False
+    if A.flags.c_contiguous and A.flags.aligned:
+        return A, True
+    return _f64F(A), False
+
+
 def sym_eig(A, only_values=False, device=0):
     """eigen(A, symmetric=TRUE): (values in decreasing order, vectors in columns) like R."""
     L = _lib.load()
     ctx = context(device)
-    A = _f64F(A)
+    A, _ = _square_any_order(A)   # symmetric: the transpose is the same matrix
     n = A.shape[0]
-    w = np.zeros(n)
-    U = None if only_values else np.zeros((n, n), order="F")
+    w = np.empty(n)
+    U = None if only_values else np.empty((n, n), order="F")
     _check(ctx, L.eagle_sym_eig(ctx, _dp(A), n, _dp(w), None if only_values else _dp(U)))
     return w, U
 
@@ -325,9 +339,9 @@ def chol2inv(A, device=0):
     """chol2inv(chol(A)); raises EagleError(1, R's chol() message) when A is not positive definite."""
     L = _lib.load()
     ctx = context(device)
-    A = _f64F(A)
+    A, tr = _square_any_order(A)  # symmetric in, symmetric out: returned in the caller's order
     n = A.shape[0]
-    out = np.zeros((n, n), order="F")
+    out = np.empty((n, n), order="C" if tr else "F")
     _check(ctx, L.eagle_chol2inv(ctx, _dp(A), n, _dp(out)))
     return out
 
@@ -336,9 +350,9 @@ def inverse(A, device=0):
     """solve(A)."""
     L = _lib.load()
     ctx = context(device)
-    A = _f64F(A)
+    A, tr = _square_any_order(A)  # a C-ordered A is handed over as A^T; inv(A^T) read back row-major is inv(A)
     n = A.shape[0]
-    out = np.zeros((n, n), order="F")
+    out = np.empty((n, n), order="C" if tr else "F")
     _check(ctx, L.eagle_inverse(ctx, _dp(A), n, _dp(out)))
     return out
 
@@ -347,12 +361,19 @@ def matmul(A, B, device=0):
     """A %*% B on the library's fp64 MFMA GEMM."""
     L = _lib.load()
     ctx = context(device)
-    A, B = _f64F(np.atleast_2d(A)), _f64F(np.atleast_2d(B))
+    A, B = np.atleast_2d(np.asarray(A, dtype=np.float64)), np.atleast_2d(np.asarray(B, dtype=np.float64))
     m, k = A.shape
     k2, n = B.shape
     if k != k2:
         raise ValueError("non-conformable arguments")
-    out = np.zeros((m, n), order="F")
+    if A.flags.c_contiguous and B.flags.c_contiguous and A.flags.aligned and B.flags.aligned and not (A.flags.f_contiguous and B.flags.f_contiguous):
+        # row-major operands: their buffers read column-major are A^T (k x m) and B^T (n x k); B^T A^T = (A B)^T, whose
+        # column-major image is A B row-major -- no layout change on the host
+        out = np.empty((m, n), order="C")
+        _check(ctx, L.eagle_matmul(ctx, _dp(B), _dp(A), n, k, m, _dp(out)))
+        return out
+    A, B = _f64F(A), _f64F(B)
+    out = np.empty((m, n), order="F")
     _check(ctx, L.eagle_matmul(ctx, _dp(A), _dp(B), m, k, n, _dp(out)))
     return out
 

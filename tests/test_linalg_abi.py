@@ -33,6 +33,10 @@ def test_sym_eig_chol2inv_inverse(n, api):
     assert np.array_equal(Ai, Ai.T)
     G = rng.standard_normal((n, n)) + n * np.eye(n)                    # general, well conditioned
     np.testing.assert_allclose(api.inverse(G), np.linalg.inv(G), rtol=1e-9, atol=1e-12)
+    # either memory order goes in without a host-side layout change (row-major = the transpose read column-major) and a strided view is copied
+    np.testing.assert_allclose(api.inverse(np.asfortranarray(G)), np.linalg.inv(G), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(api.inverse(G[::-1, ::-1]), np.linalg.inv(G[::-1, ::-1]), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(api.chol2inv(np.asfortranarray(A)), Ai, rtol=1e-12, atol=1e-14)
 
 
 def test_chol2inv_and_inverse_failures(api):
@@ -53,6 +57,8 @@ def test_matmul(m, k, n, api):
     Ai = rng.integers(-9, 10, size=(m, k)).astype(np.float64)         # integer-valued: exact in fp64
     Bi = rng.integers(-9, 10, size=(k, n)).astype(np.float64)
     np.testing.assert_array_equal(api.matmul(Ai, Bi), Ai @ Bi)
+    for Ax, Bx in ((np.asfortranarray(Ai), Bi), (Ai, np.asfortranarray(Bi)), (np.asfortranarray(Ai), np.asfortranarray(Bi)), (Ai[::-1], Bi[:, ::-1])):
+        np.testing.assert_array_equal(api.matmul(Ax, Bx), Ax @ Bx)   # any memory order / strides
 
 
 def test_mmt_sqrt_and_sqrtinv(api, golden):
