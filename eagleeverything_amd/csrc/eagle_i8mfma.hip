@@ -367,8 +367,11 @@ __global__ __launch_bounds__(256) void k_vara_prep(const double* __restrict__ Wu
 
 // Bs[s][k][j] = digit s of Wu[j][k] (j != k; the diagonal goes through dW).  32x32 tiles through LDS so both sides
 // are coalesced.
+// perm128: the rows of Bs (= columns c of Wu) are stored permuted inside every block of 128, row (c & 3) * 32 + ((c & 127) >> 2)
+// holds column c: lane r of the pipelined kernel's four 32-column MFMA tiles then owns the four CONSECUTIVE columns 4r .. 4r+3 of
+// its wave's 128, and the tile epilogue fetches their genotype bytes with one dword load instead of four byte loads.
 __global__ __launch_bounds__(256) void k_slice_w(const double* __restrict__ Wu, long np, const VaraHdr* __restrict__ hdr,
-                                                 int8_t* __restrict__ Bs) {
+                                                 int8_t* __restrict__ Bs, int perm128) {
     __shared__ double tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const long bj = (long)blockIdx.y * 32, bk = (long)blockIdx.x * 32;
@@ -401,10 +404,12 @@ __global__ __launch_bounds__(256) void k_slice_w(const double* __restrict__ Wu, 
                 Q = llrint(yv);
             }
         }
+        const long c = bk + r;
+        const long crow = perm128 ? (c & ~127L) | ((c & 3) << 5) | ((c & 127) >> 2) : c;
         for (int s = nslices - 1; s >= 0; s--) {
             long long d = ((Q + 128) & 255) - 128;
             Q = (Q - d) >> 8;
-            Bs[(long)s * np * np + (bk + r) * np + bj + tx] = (int8_t)d;
+            Bs[(long)s * np * np + crow * np + bj + tx] = (int8_t)d;
         }
     }
 }
@@ -929,7 +934,7 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8p(const int8_t* __restrict__ 
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) ch[ks] = ((2 * ks + h) ^ swz) << 4;
     const int xsel = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
-    const int evoff = (wr * 96 + 4 * h) * ldi + wc * 128 + r;
+    const int evoff = (wr * 96 + 4 * h) * ldi + wc * 128 + 4 * r;  // epilogue: this lane's four genotype columns (see k_slice_w, perm128)
     // stage 0 as a burst, then the pipeline: eight waves issue the DMA of a stage, A 48 row groups (6 per wave), B 32 (4 per wave)
     tw_stage<6>(rsA, lnA, ldi, nxt.kt * BK8, ldsv, w);
     tw_stage<4>(t8_rsrc(Bsl + (long)nxt.ct * T8 * np, npi), lnB, npi, nxt.kt * BK8, ldsv + TW_ABYTES, w);
@@ -983,18 +988,21 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8p(const int8_t* __restrict__ 
             const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
 #pragma unroll
             for (int m = 0; m < 3; m++) {
+                // the digit slices are stored with their columns permuted (k_slice_w, perm128): lane r of the four column tiles
+                // n = 0..3 owns the consecutive columns 4r + n, so ONE dword holds the row's four genotype bytes of this lane
+                int g4[16];
+#pragma unroll
+                for (int x = 0; x < 16; x++)
+                    g4[x] = __builtin_amdgcn_raw_buffer_load_b32(rsA, evoff, (m * 32 + (x & 3) + 8 * (x >> 2)) * ldi + ecol, 0);
 #pragma unroll
                 for (int half = 0; half < NSUM; half++) {
                     int v16[16], v8[8], v4[4], v2[2];
 #pragma unroll
                     for (int x = 0; x < 16; x++) {
-                        const int so = (m * 32 + (x & 3) + 8 * (x >> 2)) * ldi + ecol;
                         int sacc = 0;
 #pragma unroll
-                        for (int n = half * (4 / NSUM); n < (half + 1) * (4 / NSUM); n++) {
-                            const int g = (int)(int8_t)__builtin_amdgcn_raw_buffer_load_b8(rsA, evoff, so + n * 32, 0);
-                            sacc += c[m][n][x] * g;
-                        }
+                        for (int n = half * (4 / NSUM); n < (half + 1) * (4 / NSUM); n++)
+                            sacc += c[m][n][x] * ((g4[x] << (24 - 8 * n)) >> 24);
                         v16[x] = sacc;
                     }
 #pragma unroll
@@ -1394,6 +1402,11 @@ static int vara_i8_check(eagle_ctx* ctx, long L_pad, long n_pad, long ld, int ns
 
 // Phase 1: max |off-diagonal|, slice count, diagonal vector, ONE fused pass over the genotypes for
 // vdiag_i = sum_k m_ik^2 W_kk (and a = Mt8 v if v != NULL), digit slices of the off-diagonal part.
+// Which vara kernel a context runs at this size (the prepare step lays the digit slices out for it): the pipelined 384 x 256 kernel
+// below 65,536 padded individuals unless a tune switch asks for one of the others (tools/bench_vara.py: 8 = the 256 x 256 form,
+// 9 = the compiler-scheduled 384 x 256 form).
+static bool vara_piped(const eagle_ctx* ctx, long n_pad) { return ctx->tune != 8 && ctx->tune != 9 && n_pad < 65536; }
+
 extern "C" int eagle_dev_vara_i8_prepare(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu,
                                          int nslices, void* ws, const double* v, double* a_out, void* stream) {
     int rc = vara_i8_check(ctx, L_pad, n_pad, ld, nslices);
@@ -1420,7 +1433,7 @@ extern "C" int eagle_dev_vara_i8_prepare(eagle_ctx* ctx, const int8_t* Mt8, long
     rc = eagle_dev_gemv3_i8(ctx, Mt8, L_pad, n_pad, ld, v ? v : dW, dW, rho, 1.0, v ? a_out : nullptr, vdiag, mrho, stream);
     if (rc) return rc;
     dim3 g2((unsigned)(n_pad / 32), (unsigned)(n_pad / 32));
-    hipLaunchKernelGGL(k_slice_w, g2, dim3(256), 0, s, Wu, n_pad, hdr, Bs);
+    hipLaunchKernelGGL(k_slice_w, g2, dim3(256), 0, s, Wu, n_pad, hdr, Bs, vara_piped(ctx, n_pad) ? 1 : 0);
     e = hipGetLastError();
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "vara_i8_prepare");
     return EAGLE_OK;
@@ -1453,8 +1466,8 @@ extern "C" int eagle_dev_vara_i8_mfma_shifted(eagle_ctx* ctx, const int8_t* Mt8s
     // All forms give bit-identical q.  n_pad >= 32768: the pipelined kernel sums the two 64-column halves of its tile row-dot
     // separately (int32 range); the 256 x 256 form serves n_pad >= 65536.  A/B switches of tools/bench_vara.py: tune 8 = the 256 x 256 form, 9 = the compiler-scheduled 384 x 256
     // form (k_vara_i8w), 7 = whole workers in the last round.
-    if (ctx->tune != 8 && (n_pad < 32768 || (ctx->tune != 9 && n_pad < 65536))) {
-        const bool piped = ctx->tune != 9;
+    if (vara_piped(ctx, n_pad) || (ctx->tune == 9 && n_pad < 32768)) {
+        const bool piped = vara_piped(ctx, n_pad);
         const bool two_sums = n_pad >= 32768;
         const void* kfn = !piped ? (const void*)k_vara_i8w : two_sums ? (const void*)k_vara_i8p<2> : (const void*)k_vara_i8p<1>;
         bool& attr = !piped ? ctx->attr_vara_i8w : two_sums ? ctx->attr_vara_i8p2 : ctx->attr_vara_i8p;
