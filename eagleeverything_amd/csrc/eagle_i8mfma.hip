@@ -218,7 +218,9 @@ static int syrk_pair_table(eagle_ctx* ctx, int nt, const int** out, hipStream_t 
     return EAGLE_OK;
 }
 
-// Experiment switch for the tile-engine schedule (tools/bench_i8_engine.py); 0 is the shipped default.  Per ctx.
+// Experiment switch for the tile-engine schedule (tools/bench_*.py); 0 is the shipped default.  Per ctx.  Not part of the public
+// ABI.  The switch also decides the layout eagle_dev_vara_i8_prepare gives the digit slices (vara_piped below): set it BEFORE the
+// prepare call of the scan it is meant for.
 extern "C" void eagle_dev_set_tune(eagle_ctx* ctx, int v) { if (ctx) ctx->tune = v; }
 
 // The int8 form of the MM^T kernel (the shipped one is k_syrk_f4 below: same engine, fp4 operands, twice the markers per
