@@ -682,6 +682,20 @@ __device__ __forceinline__ void tw_kstep(i32x16 (&acc)[3][4], const int8_t* pa, 
 #pragma unroll
         for (int n = 0; n < 4; n++) acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b[n], acc[m][n], 0, 0, 0);
 }
+// Pieces per worker of an XCD's last, partly filled round of `tail` workers on 32 CUs (0 < tail < 32): the workers are cut along
+// their column-tile pairs into p equal pieces, the tail * p pieces run in ceil(tail * p / 32) rounds of 1/p worker-time each; p <=
+// min(npair, VARA_TAIL_PMAX) minimising that cost (p = 1: one whole worker-time for a round that may be 1/32 full; large p: tail/32).
+#define VARA_TAIL_PMAX 16
+__host__ __device__ static inline int vara_tail_pieces(int tail, int npair) {
+    if (tail <= 0) return 1;
+    int best = 1, bn = 1, bd = 1;  // cost bn / bd
+    const int pmax = npair < VARA_TAIL_PMAX ? npair : VARA_TAIL_PMAX;
+    for (int p = 2; p <= pmax; p++) {
+        const int rounds = (tail * p + 31) >> 5;
+        if (rounds * bd < bn * p) { best = p; bn = rounds; bd = p; }
+    }
+    return best;
+}
 // `groups` row groups (8 rows each) of an operand tile per wave: wave w issues groups w*groups .. (groups is even)
 template <int GROUPS>
 __device__ __forceinline__ void tw_stage(__amdgpu_buffer_rsrc_t rs, const T8Lane& ln, int ld, int k0, int8_t* ldsTile, int w) {
@@ -700,12 +714,12 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8w(const int8_t* __restrict__ 
     const int nslices = hdr->S;
     const int nct = (int)(np / T8), npair = (nct + 1) / 2;
     // Work per XCD: its marker tiles (mt = 8 g + xcd) x the S slices = `wx` workers on 32 CUs.  The workers of the last, partly
-    // filled round are cut into `psplit` pieces along their column-tile pairs when that round is less than half full, so that
-    // it costs 1/psplit of a worker instead of a whole one (a 125,000-marker shard -- the headline problem on 8 GPUs -- is
-    // 5.1 rounds: 6 worker-times without the cut, 5.2 with it).  Integer atomics into q: the result does not change.
+    // filled round are cut into `psplit` pieces along their column-tile pairs (vara_tail_pieces), so that the round costs about
+    // tail/32 of a worker-time instead of a whole one (a 125,000-marker shard -- the headline problem on 8 GPUs -- is 5.1 rounds:
+    // 6 worker-times without the cut, 5.2 with it).  Integer atomics into q: the result does not change.
     const int groups = (ntm + 7) >> 3, wx = groups * nslices, full = (wx >> 5) << 5, tail = wx - full;
-    int psplit = 1;
-    if (cut_last_round && tail > 0 && tail <= 16) { psplit = 32 / tail; if (psplit > npair) psplit = npair; }
+    const int psplit_tail = cut_last_round ? vara_tail_pieces(tail, npair) : 1;
+    int psplit = psplit_tail;
     int worker = slot, piece = 0;
     if (slot >= full) { const int u = slot - full; worker = full + u / psplit; piece = u - (u / psplit) * psplit; }
     else psplit = 1;  // only the workers of the last round are cut
@@ -904,8 +918,8 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8p(const int8_t* __restrict__ 
     const int nslices = hdr->S;
     const int nct = (int)(np / T8), npair = (nct + 1) / 2;
     const int groups = (ntm + 7) >> 3, wx = groups * nslices, full = (wx >> 5) << 5, tail = wx - full;  // see k_vara_i8w
-    int psplit = 1;
-    if (cut_last_round && tail > 0 && tail <= 16) { psplit = 32 / tail; if (psplit > npair) psplit = npair; }
+    const int psplit_tail = cut_last_round ? vara_tail_pieces(tail, npair) : 1;
+    int psplit = psplit_tail;
     int worker = slot, piece = 0;
     if (slot >= full) { const int u = slot - full; worker = full + u / psplit; piece = u - (u / psplit) * psplit; }
     else psplit = 1;
@@ -1479,8 +1493,8 @@ extern "C" int eagle_dev_vara_i8_mfma_shifted(eagle_ctx* ctx, const int8_t* Mt8s
             attr = true;
         }
         const int ntw = (int)((L_pad + TW_M - 1) / TW_M), gw = (ntw + 7) / 8;
-        // per XCD at most gw * smax workers, plus at most 32 more blocks when the last round is cut into pieces
-        const dim3 gridw((unsigned)(8 * (gw * smax + 32)));
+        // per XCD at most gw * smax workers, plus at most 31 * VARA_TAIL_PMAX more blocks when the last round is cut into pieces
+        const dim3 gridw((unsigned)(8 * (gw * smax + 31 * VARA_TAIL_PMAX)));
         const int cut = ctx->tune == 7 ? 0 : 1;
         if (!piped) hipLaunchKernelGGL(k_vara_i8w, gridw, dim3(512), 2 * (TW_ABYTES + TILE_BYTES), s, Mt8s, ld, ntw, Bs, n_pad, hdr, q, L_pad, cut);
         else if (two_sums) hipLaunchKernelGGL(k_vara_i8p<2>, gridw, dim3(512), 2 * (TW_ABYTES + TILE_BYTES), s, Mt8s, ld, ntw, Bs, n_pad, hdr, q, L_pad, cut);

@@ -4,19 +4,32 @@ wrong map before a box is spent on it."""
 import random
 
 
+PMAX = 16  # VARA_TAIL_PMAX
+
+
+def vara_tail_pieces(tail, npair):
+    """csrc/eagle_i8mfma.hip vara_tail_pieces: pieces per worker of the last, partly filled round of an XCD."""
+    if tail <= 0:
+        return 1
+    best, bn, bd = 1, 1, 1
+    for p in range(2, min(npair, PMAX) + 1):
+        rounds = (tail * p + 31) >> 5
+        if rounds * bd < bn * p:
+            best, bn, bd = p, rounds, p
+    return best
+
+
 def vara_i8w_cover(ntm, S, npair, smax=7, cut=True):
     """k_vara_i8p / k_vara_i8w (csrc/eagle_i8mfma.hip): block b -> (xcd = b & 7, slot = b >> 3) -> worker -> (marker tile, slice) and, for the
-    workers of a last round that is less than half full, a piece [pair0, pair1) of the column-tile pairs."""
+    workers of the last, partly filled round, a piece [pair0, pair1) of the column-tile pairs."""
     groups = (ntm + 7) >> 3
     wx = groups * S
     full = (wx >> 5) << 5
     tail = wx - full
-    psplit0 = 1
-    if cut and 0 < tail <= 16:
-        psplit0 = min(32 // tail, npair)
+    psplit0 = vara_tail_pieces(tail, npair) if cut else 1
     seen = {}
     for xcd in range(8):
-        for slot in range(groups * smax + 32):          # the launch: 8 * (groups * smax + 32) blocks
+        for slot in range(groups * smax + 31 * PMAX):     # the launch: 8 * (groups * smax + 31 * VARA_TAIL_PMAX) blocks
             worker, piece, psplit = slot, 0, psplit0
             if slot >= full:
                 u = slot - full
@@ -31,6 +44,18 @@ def vara_i8w_cover(ntm, S, npair, smax=7, cut=True):
             for p in range(npair * piece // psplit, npair * (piece + 1) // psplit):
                 seen[(mt, sl, p)] = seen.get((mt, sl, p), 0) + 1
     return len(seen) == ntm * S * npair and all(v == 1 for v in seen.values())
+
+
+def test_tail_pieces_rule():
+    for npair in (1, 2, 5, 20, 100):
+        for tail in range(0, 32):
+            p = vara_tail_pieces(tail, npair)
+            assert 1 <= p <= max(1, min(npair, PMAX))
+            cost = lambda q: ((tail * q + 31) >> 5) / q
+            if tail:
+                assert all(cost(p) <= cost(q) + 1e-12 for q in range(1, min(npair, PMAX) + 1))   # the minimum ...
+                assert all(cost(q) > cost(p) - 1e-12 or q >= p for q in range(1, min(npair, PMAX) + 1))  # ... with the fewest pieces
+    assert vara_tail_pieces(3, 20) == 10
 
 
 def test_vara_i8w_every_marker_tile_slice_and_column_pair_exactly_once():
