@@ -187,3 +187,39 @@ def test_extract_geno(golden, oracle, tmp_path):
     n, L = g["M8"].shape
     for c in (0, 17, L - 1):
         np.testing.assert_array_equal(oracle.extract_geno_rcpp(geno["asciifileM"], 8.0, c, (n, L)), g["M8"][:, c].astype(np.int32))
+
+
+def test_scan_against_exact_rational_arithmetic(oracle):
+    """The mathematical definition, with no rounding at all: a = Mt (S a_hat), vara_i = m_i^T (S (V S)) m_i
+    (calculate_a_and_vara_rcpp.cpp:90-112) and MM^T, evaluated in exact rational arithmetic (Python fractions) from the very
+    doubles the oracle is given.  What this pins is that the C restatement (and the numpy one the golden vectors come from)
+    computes these quantities to fp64 rounding -- not the reference's own rounding, which no file records (parity unpinned)."""
+    from fractions import Fraction as F
+    from oracle import oracle_np
+    rng = np.random.default_rng(11)
+    n, L = 7, 9
+    Mt8 = rng.integers(-1, 2, size=(L, n)).astype(np.int8)
+    A = rng.standard_normal((n, n))
+    S = A @ A.T / n + np.eye(n)
+    B = rng.standard_normal((n, n))
+    V = 0.5 * (B + B.T) / n + 2.0 * np.eye(n)
+    ahat = rng.standard_normal(n)
+    Sq = [[F(float(x)) for x in row] for row in S]
+    Vq = [[F(float(x)) for x in row] for row in V]
+    aq = [F(float(x)) for x in ahat]
+    Mq = [[int(x) for x in row] for row in Mt8]
+    mat = lambda X, Y: [[sum(X[i][k] * Y[k][j] for k in range(n)) for j in range(n)] for i in range(n)]
+    Wq = mat(Sq, mat(Vq, Sq))
+    vq = [sum(Sq[i][j] * aq[j] for j in range(n)) for i in range(n)]
+    a_exact = [sum(Mq[i][j] * vq[j] for j in range(n)) for i in range(L)]
+    vara_exact = [sum(Mq[i][j] * Wq[j][k] * Mq[i][k] for j in range(n) for k in range(n)) for i in range(L)]
+    for name, (a, vara) in (("C oracle", oracle.scan_from_i8(Mt8, S, V, ahat)), ("numpy", oracle_np.a_and_vara(Mt8, S, V, ahat))):
+        a, vara = np.ravel(a), np.ravel(vara)
+        scale_a = max(abs(float(x)) for x in a_exact)
+        for i in range(L):
+            assert abs(F(float(a[i])) - a_exact[i]) <= F(1, 10 ** 14) * F(scale_a), (name, "a", i)
+            assert abs(F(float(vara[i])) - vara_exact[i]) <= F(1, 10 ** 13) * abs(vara_exact[i]) + F(1, 10 ** 300), (name, "vara", i)
+    G = Mt8.astype(np.int64)
+    mmt_exact = [[sum(Mq[l][i] * Mq[l][j] for l in range(L)) for j in range(n)] for i in range(n)]
+    assert np.array_equal(oracle_np.mmt_int64(np.ascontiguousarray(Mt8.T)), np.array(mmt_exact, dtype=np.int64))
+    assert np.array_equal(G.T @ G, np.array(mmt_exact, dtype=np.int64))
