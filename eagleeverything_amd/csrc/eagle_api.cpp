@@ -105,6 +105,9 @@ extern "C" eagle_ctx* eagle_open(int device) {
         delete ctx;
         return nullptr;
     }
+    // EAGLE_HIP_TUNE=9: the compiler-scheduled forms of the two hand-scheduled kernels (k_vara_i8w, k_syrk_f4) for a whole session:
+    // same results bit for bit, 3-8 % slower; a switch for ruling the inline-asm kernels out when chasing a problem
+    if (const char* tv = getenv("EAGLE_HIP_TUNE")) ctx->tune = atoi(tv);
     // the loader stream outranks the compute stream: its decode / unpack / fill kernels are microseconds of work that must get
     // onto CUs the scan kernel's long-lived workgroups fill completely (2 waves x 256 VGPRs per SIMD), as soon as one retires
     int prio_least = 0, prio_greatest = 0;
