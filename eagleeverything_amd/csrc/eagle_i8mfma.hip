@@ -369,9 +369,10 @@ __global__ __launch_bounds__(256) void k_vara_prep(const double* __restrict__ Wu
 
 // Bs[s][k][j] = digit s of Wu[j][k] (j != k; the diagonal goes through dW).  32x32 tiles through LDS so both sides
 // are coalesced.
-// perm128: the rows of Bs (= columns c of Wu) are stored permuted inside every block of 128, row (c & 3) * 32 + ((c & 127) >> 2)
-// holds column c: lane r of the pipelined kernel's four 32-column MFMA tiles then owns the four CONSECUTIVE columns 4r .. 4r+3 of
-// its wave's 128, and the tile epilogue fetches their genotype bytes with one dword load instead of four byte loads.
+// perm128: the rows of Bs (= columns c of Wu) are stored permuted inside every block of 128 for k_vara_i8p, whose 32 x 32 result
+// tiles hold the W columns in the register dimension: lane half h, column tile n, register x is row n * 32 + 8 (x >> 2) + (x & 3) + 4 h
+// of the wave's 128; storing column c = 64 h + 16 n + x there makes the 64 columns of a lane CONSECUTIVE, and the tile epilogue
+// fetches their genotype bytes with four 16-byte loads from the lane's own marker row.
 __global__ __launch_bounds__(256) void k_slice_w(const double* __restrict__ Wu, long np, const VaraHdr* __restrict__ hdr,
                                                  int8_t* __restrict__ Bs, int perm128) {
     __shared__ double tile[32][33];
@@ -407,7 +408,8 @@ __global__ __launch_bounds__(256) void k_slice_w(const double* __restrict__ Wu, 
             }
         }
         const long c = bk + r;
-        const long crow = perm128 ? (c & ~127L) | ((c & 3) << 5) | ((c & 127) >> 2) : c;
+        const long c7 = c & 127, cx = c7 & 15;
+        const long crow = perm128 ? (c & ~127L) | (((c7 >> 4) & 3) << 5) | ((cx >> 2) << 3) | (cx & 3) | ((c7 >> 6) << 2) : c;
         for (int s = nslices - 1; s >= 0; s--) {
             long long d = ((Q + 128) & 255) - 128;
             Q = (Q - d) >> 8;
@@ -833,8 +835,12 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8w(const int8_t* __restrict__ 
 //   * the stage barrier sits in the middle of the last k-step (after 6 of its 12 MFMAs: all fragment reads of this stage have
 //     returned; the re-loads behind the barrier read the other buffer), so each wave reaches it with matrix work in flight.
 // ------------------------------------------------------------------------------------------------
-#define X_MF(c, a, b) "v_mfma_i32_32x32x32_i8 %[" #c "], %[" #a "], %[" #b "], %[" #c "]\n\t"
-#define X_MZ(c, a, b) "v_mfma_i32_32x32x32_i8 %[" #c "], %[" #a "], %[" #b "], 0\n\t"
+// SrcA = the W-digit fragment b, SrcB = the genotype fragment a: the matrix unit draws far less power when its SrcB operand is the
+// low-entropy one (tools/ubench/mfma_ceiling.hip: a bare loop on these operand statistics holds 3.75 POP/s this way round,
+// 3.29 POP/s the other), and this kernel runs against the power limit.  The 32 x 32 result tiles come out transposed: lane =
+// marker, register = W column.
+#define X_MF(c, a, b) "v_mfma_i32_32x32x32_i8 %[" #c "], %[" #b "], %[" #a "], %[" #c "]\n\t"
+#define X_MZ(c, a, b) "v_mfma_i32_32x32x32_i8 %[" #c "], %[" #b "], %[" #a "], 0\n\t"
 #define X_LD(d, p, off) "ds_read_b128 %[" #d "], %[" #p "] offset:" #off "\n\t"
 #define X_WT(n) "s_waitcnt lgkmcnt(" #n ")\n\t"
 // one LDS-DMA load of the stage being fetched, operand set s (a = genotype rows, b = W-digit rows): next row group
@@ -907,9 +913,7 @@ __device__ __forceinline__ void tx_kstep(TxAcc& c, i32x4 (&a)[3], i32x4 (&an)[3]
 __device__ __forceinline__ void tx_klast(TxAcc& c, i32x4 (&a)[3], i32x4 (&an)[3], i32x4 (&b)[4], unsigned pa, unsigned pb, XDma& da) {
     asm volatile(X_KLAST : X_ACC_RW(0), X_ACC_RW(1), X_ACC_RW(2), X_FRAGS, X_DMA_OUT(a, da) : [pa] "v"(pa), [pb] "v"(pb), X_DMA_IN(a, da) : "memory");
 }
-// NSUM: the tile row-dot sums 128 columns per wave in int32: |sum| <= 65536 K for a K-deep tile, i.e. n_pad < 32768 in one sum;
-// NSUM = 2 sums the two 64-column halves separately (n_pad < 65536; the 64-bit totals are the same integers).
-template <int NSUM>
+// (the tile row-dot of a lane sums 64 products in int32: |sum| <= 32768 K for a K-deep tile, i.e. n_pad < 65536)
 __global__ __launch_bounds__(512, 2) void k_vara_i8p(const int8_t* __restrict__ Mt8, long ld, int ntm, const int8_t* __restrict__ Bs,
                                                      long np, const VaraHdr* __restrict__ hdr, long long* __restrict__ q, long Lp, int cut_last_round) {
     extern __shared__ __attribute__((aligned(1024))) int8_t ldsv[];  // [2][A 48 KiB | B 32 KiB]
@@ -950,7 +954,7 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8p(const int8_t* __restrict__ 
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) ch[ks] = ((2 * ks + h) ^ swz) << 4;
     const int xsel = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
-    const int evoff = (wr * 96 + 4 * h) * ldi + wc * 128 + 4 * r;  // epilogue: this lane's four genotype columns (see k_slice_w, perm128)
+    const int evoff = (wr * 96 + r) * ldi + wc * 128 + h * 64;  // epilogue: this lane's marker row and its 64 genotype columns (k_slice_w, perm128)
     // stage 0 as a burst, then the pipeline: eight waves issue the DMA of a stage, A 48 row groups (6 per wave), B 32 (4 per wave)
     tw_stage<6>(rsA, lnA, ldi, nxt.kt * BK8, ldsv, w);
     tw_stage<4>(t8_rsrc(Bsl + (long)nxt.ct * T8 * np, npi), lnB, npi, nxt.kt * BK8, ldsv + TW_ABYTES, w);
@@ -1001,45 +1005,28 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8p(const int8_t* __restrict__ 
             // read; and have the re-loads landed, in case the fragments are dead from here (last tile)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
             const int ecol = done_ct * T8;
-            const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
 #pragma unroll
             for (int m = 0; m < 3; m++) {
-                // the digit slices are stored with their columns permuted (k_slice_w, perm128): lane r of the four column tiles
-                // n = 0..3 owns the consecutive columns 4r + n, so ONE dword holds the row's four genotype bytes of this lane
-                int g4[16];
+                // lane (r, h) holds, for its marker row wr*96 + m*32 + r, the sums over K against the 64 W columns 64 h + 16 n + x of
+                // the wave's 128 (k_slice_w, perm128): their genotype bytes are 64 consecutive bytes of that row
+                i32x4 g[4];
 #pragma unroll
-                for (int x = 0; x < 16; x++)
-                    g4[x] = __builtin_amdgcn_raw_buffer_load_b32(rsA, evoff, (m * 32 + (x & 3) + 8 * (x >> 2)) * ldi + ecol, 0);
+                for (int n = 0; n < 4; n++) g[n] = __builtin_amdgcn_raw_buffer_load_b128(rsA, evoff + m * 32 * ldi, ecol + n * 16, 0);
+                int sacc = 0;
 #pragma unroll
-                for (int half = 0; half < NSUM; half++) {
-                    int v16[16], v8[8], v4[4], v2[2];
+                for (int n = 0; n < 4; n++)
 #pragma unroll
-                    for (int x = 0; x < 16; x++) {
-                        int sacc = 0;
-#pragma unroll
-                        for (int n = half * (4 / NSUM); n < (half + 1) * (4 / NSUM); n++)
-                            sacc += c[m][n][x] * ((g4[x] << (24 - 8 * n)) >> 24);
-                        v16[x] = sacc;
-                    }
-#pragma unroll
-                    for (int i = 0; i < 8; i++) { int snd = b0 ? v16[i] : v16[i + 8]; int kp = b0 ? v16[i + 8] : v16[i]; v8[i] = kp + __shfl_xor(snd, 1); }
-#pragma unroll
-                    for (int i = 0; i < 4; i++) { int snd = b1 ? v8[i] : v8[i + 4]; int kp = b1 ? v8[i + 4] : v8[i]; v4[i] = kp + __shfl_xor(snd, 2); }
-#pragma unroll
-                    for (int i = 0; i < 2; i++) { int snd = b2 ? v4[i] : v4[i + 2]; int kp = b2 ? v4[i + 2] : v4[i]; v2[i] = kp + __shfl_xor(snd, 4); }
-                    int v1 = (b3 ? v2[1] : v2[0]) + __shfl_xor(b3 ? v2[0] : v2[1], 8);
-                    v1 += __shfl_xor(v1, 16);
-                    keep[m] += v1;
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                    for (int x = 0; x < 16; x++) sacc += c[m][n][x] * ((g[n][x >> 2] << (24 - 8 * (x & 3))) >> 24);
+                keep[m] += sacc;
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
-    const long qrow = row0 + wr * 96 + 4 * h + (xsel & 3) + 8 * (xsel >> 2);
+    const long qrow = row0 + wr * 96 + r;  // both halves h of a marker's lane pair add their part
     long long* qs = q + (long)sl * Lp + qrow;
 #pragma unroll
     for (int m = 0; m < 3; m++)
-        if ((lane & 16) == 0 && keep[m] && qrow + m * 32 < Lp) atomicAdd((unsigned long long*)&qs[m * 32], (unsigned long long)keep[m]);
+        if (keep[m] && qrow + m * 32 < Lp) atomicAdd((unsigned long long*)&qs[m * 32], (unsigned long long)keep[m]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1479,14 +1466,12 @@ extern "C" int eagle_dev_vara_i8_mfma_shifted(eagle_ctx* ctx, const int8_t* Mt8s
     }
     // The 384 x 256 tile is the default (C2: 23.05 -> 21.91 ms, C3 shape: 45.2 -> 43.1 ms per 262144 markers; profiles/
     // r02_ab_vara_tile.txt), since round 2 in its asm-pipelined form k_vara_i8p (another -4 to -5 %, profiles/r02_ab_vara_pipe.txt).
-    // All forms give bit-identical q.  n_pad >= 32768: the pipelined kernel sums the two 64-column halves of its tile row-dot
-    // separately (int32 range); the 256 x 256 form serves n_pad >= 65536.  A/B switches of tools/bench_vara.py: tune 8 = the 256 x 256 form, 9 = the compiler-scheduled 384 x 256
+    // All forms give bit-identical q.  The 256 x 256 form serves n_pad >= 65536 (int32 range of the tile row-dots).  A/B switches of tools/bench_vara.py: tune 8 = the 256 x 256 form, 9 = the compiler-scheduled 384 x 256
     // form (k_vara_i8w), 7 = whole workers in the last round.
     if (vara_piped(ctx, n_pad) || (ctx->tune == 9 && n_pad < 32768)) {
         const bool piped = vara_piped(ctx, n_pad);
-        const bool two_sums = n_pad >= 32768;
-        const void* kfn = !piped ? (const void*)k_vara_i8w : two_sums ? (const void*)k_vara_i8p<2> : (const void*)k_vara_i8p<1>;
-        bool& attr = !piped ? ctx->attr_vara_i8w : two_sums ? ctx->attr_vara_i8p2 : ctx->attr_vara_i8p;
+        const void* kfn = !piped ? (const void*)k_vara_i8w : (const void*)k_vara_i8p;
+        bool& attr = !piped ? ctx->attr_vara_i8w : ctx->attr_vara_i8p;
         if (!attr) {
             hipError_t ea = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TW_ABYTES + TILE_BYTES));
             if (ea != hipSuccess) return eagle_fail_hip(ctx, ea, "hipFuncSetAttribute(k_vara_i8p/w)");
@@ -1497,8 +1482,7 @@ extern "C" int eagle_dev_vara_i8_mfma_shifted(eagle_ctx* ctx, const int8_t* Mt8s
         const dim3 gridw((unsigned)(8 * (gw * smax + 31 * VARA_TAIL_PMAX)));
         const int cut = ctx->tune == 7 ? 0 : 1;
         if (!piped) hipLaunchKernelGGL(k_vara_i8w, gridw, dim3(512), 2 * (TW_ABYTES + TILE_BYTES), s, Mt8s, ld, ntw, Bs, n_pad, hdr, q, L_pad, cut);
-        else if (two_sums) hipLaunchKernelGGL(k_vara_i8p<2>, gridw, dim3(512), 2 * (TW_ABYTES + TILE_BYTES), s, Mt8s, ld, ntw, Bs, n_pad, hdr, q, L_pad, cut);
-        else hipLaunchKernelGGL(k_vara_i8p<1>, gridw, dim3(512), 2 * (TW_ABYTES + TILE_BYTES), s, Mt8s, ld, ntw, Bs, n_pad, hdr, q, L_pad, cut);
+        else hipLaunchKernelGGL(k_vara_i8p, gridw, dim3(512), 2 * (TW_ABYTES + TILE_BYTES), s, Mt8s, ld, ntw, Bs, n_pad, hdr, q, L_pad, cut);
     } else
     hipLaunchKernelGGL(k_vara_i8, dim3((unsigned)(groups * 8 * smax)), dim3(512), 5 * TILE_BYTES, s, Mt8s, ld, ntm, Bs, n_pad, hdr, q, L_pad);
     hipLaunchKernelGGL(k_vara_i8_finish, dim3((unsigned)((L_pad + 255) / 256)), dim3(256), 0, s, q, L_pad, hdr, vdiag, cshift, mrho, vara_out);
