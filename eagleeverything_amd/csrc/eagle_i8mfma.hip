@@ -462,16 +462,23 @@ __global__ __launch_bounds__(256) void k_marker_shift(const int8_t* __restrict__
             l1norm[2 * row + 1] = c == 0 ? neg + pos : (c < 0 ? zer + 4 * pos : zer + 4 * neg);
         }
     }
+    // The digit kernel's term is a quadratic form in the re-centred row, so the row may be stored with either sign: the one with
+    // fewer negative entries (none at all when a homozygote is the majority) -- the matrix unit draws measurably less power on an
+    // operand of small non-negative bytes than on one with 0xFF / 0xFE bytes in it (tools/ubench/mfma_ceiling.hip: +3 %).
+    const bool flip = c > 0 || (c == 0 && neg > pos);
     int8_t* dst = Mt8s + row * ld;
     for (int j = lane * 16; j < (int)ld; j += 64 * 16) {
         i32x4 x = {0, 0, 0, 0};
         if (j < n) {
             x = *(const i32x4*)(src + j);
-            if (c != 0) {
+            if (c != 0 || flip) {
                 union { i32x4 v; int8_t b[16]; } u;
                 u.v = x;
 #pragma unroll
-                for (int q = 0; q < 16; q++) u.b[q] = (j + q < n) ? (int8_t)(u.b[q] - c) : (int8_t)0;
+                for (int q = 0; q < 16; q++) {
+                    const int v = u.b[q] - c;
+                    u.b[q] = (j + q < n) ? (int8_t)(flip ? -v : v) : (int8_t)0;
+                }
                 x = u.v;
             }
         }
