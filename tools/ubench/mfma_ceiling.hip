@@ -33,6 +33,29 @@ __global__ __launch_bounds__(512, 2) void k_loop(const i32x4* __restrict__ A, co
     out[blockIdx.x * 512 + t] = s;
 }
 
+// the MM^T kernel's instruction: fp4 x fp4 on the block-scaled MFMA (K = 64), wave shape of k_syrk_f4p (4 x 2 tiles)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(512, 2) void k_loop_f4(const i32x4* __restrict__ A, const i32x4* __restrict__ B, float* __restrict__ out, int iters) {
+    const int t = threadIdx.x;
+    i32x8 a[4], b[2];
+    for (int m = 0; m < 4; m++) { const i32x4 v = A[(t + 512 * m) & 4095]; a[m] = i32x8{v[0], v[1], v[2], v[3], 0, 0, 0, 0}; }
+    for (int n = 0; n < 2; n++) { const i32x4 v = B[(t + 512 * n) & 4095]; b[n] = i32x8{v[0], v[1], v[2], v[3], 0, 0, 0, 0}; }
+    f32x16 c[4][2];
+    for (int m = 0; m < 4; m++) for (int n = 0; n < 2; n++) for (int i = 0; i < 16; i++) c[m][n][i] = 0.f;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int n = 0; n < 2; n++) c[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[m], b[n], c[m][n], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        const i32x8 ta = a[0]; a[0] = a[1]; a[1] = a[2]; a[2] = a[3]; a[3] = ta;
+        const i32x8 tb = b[0]; b[0] = b[1]; b[1] = tb;
+    }
+    float s = 0;
+    for (int m = 0; m < 4; m++) for (int n = 0; n < 2; n++) for (int i = 0; i < 16; i++) s += c[m][n][i];
+    out[blockIdx.x * 512 + t] = s;
+}
+
 int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 400000;   // 12 MFMAs per iteration and wave; 2 waves per SIMD -> ~0.15-0.25 s
     srand(5);
@@ -76,6 +99,38 @@ int main(int argc, char** argv) {
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
             const double ops = 2.0 * 256 * 8 * (double)iters * 12 * 32 * 32 * 32;
             if (rep) printf("%s: %8.2f ms  %.2f POP/s  (= %.3f of 5 POP/s)\n", cs.name, ms, ops / ms / 1e12, ops / ms / 1e12 / 5.0);
+        }
+    }
+    // fp4 codes (e2m1), two per byte: -1 / 0 / +1 as 0xA / 0x0 / 0x2 (the g - 1 coding of MM^T) against 0 / 1 / 2 as 0x0 / 0x2 / 0x4
+    std::vector<int8_t> f4m(65536), f4p(65536);
+    for (size_t r = 0; r < f4m.size(); r += 16) {
+        const double p = 0.05 + 0.45 * (rand() / (double)RAND_MAX), q = 1 - p;
+        for (int i = 0; i < 16; i++) {
+            int codes_m = 0, codes_p = 0;
+            for (int hnib = 0; hnib < 2; hnib++) {
+                const double u = rand() / (double)RAND_MAX;
+                const int g = u < q * q ? 0 : (u < q * q + 2 * p * q ? 1 : 2);
+                codes_m |= (g == 0 ? 0xA : (g == 1 ? 0x0 : 0x2)) << (4 * hnib);
+                codes_p |= (g == 0 ? 0x0 : (g == 1 ? 0x2 : 0x4)) << (4 * hnib);
+            }
+            f4m[r + i] = (int8_t)codes_m; f4p[r + i] = (int8_t)codes_p;
+        }
+    }
+    struct { const char* name; const int8_t* a; } cases4[] = {
+        {"fp4 x fp4, genotypes as -1 / 0 / +1 (MM^T as shipped)", f4m.data()},
+        {"fp4 x fp4, genotypes as  0 / 1 / 2  (non-negative)    ", f4p.data()},
+        {"fp4 x fp4, random nibbles                              ", rnd.data()},
+    };
+    for (auto& cs : cases4) {
+        CHECK(hipMemcpy(dA, cs.a, 65536, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(dB, cs.a, 65536, hipMemcpyHostToDevice));
+        for (int rep = 0; rep < 2; rep++) {
+            CHECK(hipEventRecord(e0));
+            hipLaunchKernelGGL(k_loop_f4, dim3(256), dim3(512), 0, 0, dA, dB, (float*)dOut, iters * 3 / 2);
+            CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            const double ops = 2.0 * 256 * 8 * (double)(iters * 3 / 2) * 8 * 32 * 32 * 64;
+            if (rep) printf("%s: %8.2f ms  %.2f POP/s  (= %.3f of 10 POP/s)\n", cs.name, ms, ops / ms / 1e12, ops / ms / 1e12 / 10.0);
         }
     }
     return 0;
