@@ -852,6 +852,7 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8w(const int8_t* __restrict__ 
 #define X_WT(n) "s_waitcnt lgkmcnt(" #n ")\n\t"
 // one LDS-DMA load of the stage being fetched, operand set s (a = genotype rows, b = W-digit rows): next row group
 // (LDS +1 KiB, source + 8 rows), even / odd group lane offsets
+// (the asm statements that use it declare the "scc" clobber: s_add_u32 writes SCC, and hipcc keeps compare results live across asm)
 #define X_DM(vo, s) "s_add_u32 %[m0" #s "], %[m0" #s "], 0x400\n\ts_mov_b32 m0, %[m0" #s "]\n\ts_add_u32 %[so" #s "], %[so" #s "], %[st" #s "]\n\t" \
                     "buffer_load_dwordx4 %[" #vo #s "], %[rs" #s "], %[so" #s "] offen lds\n\t"
 #define X_NO(vo, s)
@@ -865,13 +866,14 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8w(const int8_t* __restrict__ 
     X_WT(6) M(c03, a0, b3) D5 M(c13, a1, b3) M(c23, a2, b3) X_LD(b3, pb, 12288) D6
 // the stage's last k-step: no loads before the barrier; behind it the loads of the next stage's first k-step in queue order
 // and the first three DMA loads of the stage after next
-#define X_KLAST                                                                                             \
-    X_WT(4) X_MF(c00, a0, b0) X_MF(c10, a1, b0) X_WT(3) X_MF(c20, a2, b0)                                   \
-    X_WT(2) X_MF(c01, a0, b1) X_MF(c11, a1, b1) X_MF(c21, a2, b1)                                           \
+#define X_KLAST_G(M, DA1, DA2, DA3)                                                                          \
+    X_WT(4) M(c00, a0, b0) M(c10, a1, b0) X_WT(3) M(c20, a2, b0)                                            \
+    X_WT(2) M(c01, a0, b1) M(c11, a1, b1) M(c21, a2, b1)                                                    \
     "s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier\n\t"                                                        \
     X_LD(x0, pa, 0) X_LD(x1, pa, 4096) X_LD(b0, pb, 0) X_LD(x2, pa, 8192) X_LD(b1, pb, 4096)                \
-    X_MF(c02, a0, b2) X_MF(c12, a1, b2) X_DM(vE, a) X_MF(c22, a2, b2) X_LD(b2, pb, 8192)                    \
-    X_MF(c03, a0, b3) X_DM(vO, a) X_MF(c13, a1, b3) X_MF(c23, a2, b3) X_LD(b3, pb, 12288) X_DM(vE, a)
+    M(c02, a0, b2) M(c12, a1, b2) DA1 M(c22, a2, b2) X_LD(b2, pb, 8192)                                     \
+    M(c03, a0, b3) DA2 M(c13, a1, b3) M(c23, a2, b3) X_LD(b3, pb, 12288) DA3
+#define X_KLAST X_KLAST_G(X_MF, X_DM(vE, a), X_DM(vO, a), X_DM(vE, a))
 #define X_ACC_RW(m) [c##m##0] "+v"(c[m][0]), [c##m##1] "+v"(c[m][1]), [c##m##2] "+v"(c[m][2]), [c##m##3] "+v"(c[m][3])
 #define X_ACC_W(m) [c##m##0] "=&v"(c[m][0]), [c##m##1] "=&v"(c[m][1]), [c##m##2] "=&v"(c[m][2]), [c##m##3] "=&v"(c[m][3])
 #define X_FRAGS [a0] "+v"(a[0]), [a1] "+v"(a[1]), [a2] "+v"(a[2]), [x0] "=&v"(an[0]), [x1] "=&v"(an[1]), [x2] "=&v"(an[2]), \
@@ -898,7 +900,7 @@ __device__ __forceinline__ void tx_prologue(i32x4 (&an)[3], i32x4 (&b)[4], unsig
                  : [pa] "v"(pa), [pb] "v"(pb) : "memory");
 }
 __device__ __forceinline__ void tx_dma3(XDma& da) {  // three loads on their own (pipeline fill)
-    asm volatile(X_DM(vE, a) X_DM(vO, a) X_DM(vE, a) : X_DMA_OUT(a, da) : X_DMA_IN(a, da) : "memory");
+    asm volatile(X_DM(vE, a) X_DM(vO, a) X_DM(vE, a) : X_DMA_OUT(a, da) : X_DMA_IN(a, da) : "memory", "scc");
 }
 // k-step on fragments a (genotype rows) / b, loading an / b for the next k-step from LDS byte addresses pa / pb.
 // DMA: 0 = none; 1 = the stage's first k-step: loads 3-5 of the genotype sequence, 0-2 of the W-digit one; 2 = the second: the last
@@ -906,19 +908,19 @@ template <bool FIRST, int DMA>
 __device__ __forceinline__ void tx_kstep(TxAcc& c, i32x4 (&a)[3], i32x4 (&an)[3], i32x4 (&b)[4], unsigned pa, unsigned pb, XDma& da, XDma& db) {
     if (DMA == 1 && FIRST)
         asm volatile(X_KSTEP(X_MZ, X_DM(vO, a), X_DM(vE, a), X_DM(vO, a), X_DM(vE, b), X_DM(vO, b), X_DM(vE, b))
-                     : X_ACC_W(0), X_ACC_W(1), X_ACC_W(2), X_FRAGS, X_DMA_OUT(a, da), X_DMA_OUT(b, db) : [pa] "v"(pa), [pb] "v"(pb), X_DMA_IN(a, da), X_DMA_IN(b, db) : "memory");
+                     : X_ACC_W(0), X_ACC_W(1), X_ACC_W(2), X_FRAGS, X_DMA_OUT(a, da), X_DMA_OUT(b, db) : [pa] "v"(pa), [pb] "v"(pb), X_DMA_IN(a, da), X_DMA_IN(b, db) : "memory", "scc");
     else if (DMA == 1)
         asm volatile(X_KSTEP(X_MF, X_DM(vO, a), X_DM(vE, a), X_DM(vO, a), X_DM(vE, b), X_DM(vO, b), X_DM(vE, b))
-                     : X_ACC_RW(0), X_ACC_RW(1), X_ACC_RW(2), X_FRAGS, X_DMA_OUT(a, da), X_DMA_OUT(b, db) : [pa] "v"(pa), [pb] "v"(pb), X_DMA_IN(a, da), X_DMA_IN(b, db) : "memory");
+                     : X_ACC_RW(0), X_ACC_RW(1), X_ACC_RW(2), X_FRAGS, X_DMA_OUT(a, da), X_DMA_OUT(b, db) : [pa] "v"(pa), [pb] "v"(pb), X_DMA_IN(a, da), X_DMA_IN(b, db) : "memory", "scc");
     else if (DMA == 2)
         asm volatile(X_KSTEP(X_MF, X_DM(vO, b), , , , , )
-                     : X_ACC_RW(0), X_ACC_RW(1), X_ACC_RW(2), X_FRAGS, X_DMA_OUT(b, db) : [pa] "v"(pa), [pb] "v"(pb), X_DMA_IN(b, db) : "memory");
+                     : X_ACC_RW(0), X_ACC_RW(1), X_ACC_RW(2), X_FRAGS, X_DMA_OUT(b, db) : [pa] "v"(pa), [pb] "v"(pb), X_DMA_IN(b, db) : "memory", "scc");
     else
         asm volatile(X_KSTEP(X_MF, , , , , , ) : X_ACC_RW(0), X_ACC_RW(1), X_ACC_RW(2), X_FRAGS : [pa] "v"(pa), [pb] "v"(pb) : "memory");
 }
 // last k-step of a stage; da: the genotype DMA sequence of the stage after next (armed before the call), three of its loads go out here
 __device__ __forceinline__ void tx_klast(TxAcc& c, i32x4 (&a)[3], i32x4 (&an)[3], i32x4 (&b)[4], unsigned pa, unsigned pb, XDma& da) {
-    asm volatile(X_KLAST : X_ACC_RW(0), X_ACC_RW(1), X_ACC_RW(2), X_FRAGS, X_DMA_OUT(a, da) : [pa] "v"(pa), [pb] "v"(pb), X_DMA_IN(a, da) : "memory");
+    asm volatile(X_KLAST : X_ACC_RW(0), X_ACC_RW(1), X_ACC_RW(2), X_FRAGS, X_DMA_OUT(a, da) : [pa] "v"(pa), [pb] "v"(pb), X_DMA_IN(a, da) : "memory", "scc");
 }
 // (the tile row-dot of a lane sums 64 products in int32: |sum| <= 32768 K for a K-deep tile, i.e. n_pad < 65536)
 __global__ __launch_bounds__(512, 2) void k_vara_i8p(const int8_t* __restrict__ Mt8, long ld, int ntm, const int8_t* __restrict__ Bs,
@@ -1991,16 +1993,16 @@ template <bool FIRST, int DMA>
 __device__ __forceinline__ void sx_kstep(SxAcc& c, const SxFrag& f, SxFrag& g, unsigned pa, unsigned pb, int sc, XDma& db) {
     if (DMA == 1 && FIRST)
         asm volatile(S_KSTEP(S_MZ, X_DM(vE, b), X_DM(vO, b), , )
-                     : S_ACC_W(0), S_ACC_W(1), S_ACC_W(2), S_ACC_W(3), S_NEXT, X_DMA_OUT(b, db) : S_CUR, X_DMA_IN(b, db) : "memory");
+                     : S_ACC_W(0), S_ACC_W(1), S_ACC_W(2), S_ACC_W(3), S_NEXT, X_DMA_OUT(b, db) : S_CUR, X_DMA_IN(b, db) : "memory", "scc");
     else if (DMA == 1)
         asm volatile(S_KSTEP(S_MF, X_DM(vE, b), X_DM(vO, b), , )
-                     : S_ACC_RW(0), S_ACC_RW(1), S_ACC_RW(2), S_ACC_RW(3), S_NEXT, X_DMA_OUT(b, db) : S_CUR, X_DMA_IN(b, db) : "memory");
+                     : S_ACC_RW(0), S_ACC_RW(1), S_ACC_RW(2), S_ACC_RW(3), S_NEXT, X_DMA_OUT(b, db) : S_CUR, X_DMA_IN(b, db) : "memory", "scc");
     else
         asm volatile(S_KSTEP(S_MF, , , , ) : S_ACC_RW(0), S_ACC_RW(1), S_ACC_RW(2), S_ACC_RW(3), S_NEXT : S_CUR : "memory");
     if (DMA) sx_uniform(db);
 }
 __device__ __forceinline__ void sx_klast(SxAcc& c, const SxFrag& f, SxFrag& g, unsigned pa, unsigned pb, int sc, XDma& da, XDma& db) {
-    asm volatile(S_KLAST : S_ACC_RW(0), S_ACC_RW(1), S_ACC_RW(2), S_ACC_RW(3), S_NEXT, X_DMA_OUT(a, da), X_DMA_OUT(b, db) : S_CUR, X_DMA_IN(a, da), X_DMA_IN(b, db) : "memory");
+    asm volatile(S_KLAST : S_ACC_RW(0), S_ACC_RW(1), S_ACC_RW(2), S_ACC_RW(3), S_NEXT, X_DMA_OUT(a, da), X_DMA_OUT(b, db) : S_CUR, X_DMA_IN(a, da), X_DMA_IN(b, db) : "memory", "scc");
     sx_uniform(da);
     sx_uniform(db);
 }
@@ -2009,7 +2011,7 @@ __device__ __forceinline__ void sx_prologue(SxFrag& g, unsigned pa, unsigned pb)
                  : S_NEXT : [pa] "v"(pa), [pb] "v"(pb) : "memory");
 }
 __device__ __forceinline__ void sx_dma6(XDma& da, XDma& db) {  // pipeline fill: what the last k-step issues behind its barrier
-    asm volatile(X_DM(vE, a) X_DM(vO, a) X_DM(vE, a) X_DM(vO, a) X_DM(vE, b) X_DM(vO, b) : X_DMA_OUT(a, da), X_DMA_OUT(b, db) : X_DMA_IN(a, da), X_DMA_IN(b, db) : "memory");
+    asm volatile(X_DM(vE, a) X_DM(vO, a) X_DM(vE, a) X_DM(vO, a) X_DM(vE, b) X_DM(vO, b) : X_DMA_OUT(a, da), X_DMA_OUT(b, db) : X_DMA_IN(a, da), X_DMA_IN(b, db) : "memory", "scc");
     sx_uniform(da);
     sx_uniform(db);
 }
@@ -2098,6 +2100,157 @@ __global__ __launch_bounds__(512, 2) void k_syrk_f4p(const uint8_t* __restrict__
             }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_syrk_f4w: MM^T on 384 x 256 tiles (row tile I of 384 individuals x column tile J of 256), the tile shape and the pipelined
+// k-step of k_vara_i8p with the fp4 x fp4 instruction.  The 256 x 256 kernel is bound by the L2 -> LDS fill, not by the matrix unit
+// (a stage's 64 KiB take longer to arrive than its 32 MFMAs per wave take to run; tools/ubench: the bare loop holds 7 POP/s on
+// genotype operands, the kernel 4.8): this tile moves 80 KiB per 48 MFMAs per wave, 17 % fewer bytes per MAC.  Rectangular tiles on
+// a symmetric output: tile (I, J) is needed when it holds an element of a 256-block on or above the diagonal, i.e. 3 I / 2 <= J
+// (2.4 % more MACs than the square tiling at n = 10,000); elements of blocks below the diagonal are not stored; the last row
+// tile may be short (rows beyond n_pad read as zero and are not stored).  Same exact integers as the other forms: bit-identical C.
+// ------------------------------------------------------------------------------------------------
+typedef f32x16 WxAcc[3][4];
+template <bool FIRST, int DMA>
+__device__ __forceinline__ void wx_kstep(WxAcc& c, i32x4 (&a)[3], i32x4 (&an)[3], i32x4 (&b)[4], unsigned pa, unsigned pb, int sc, XDma& da, XDma& db) {
+    if (DMA == 1 && FIRST)
+        asm volatile(X_KSTEP(S_MZ, X_DM(vO, a), X_DM(vE, a), X_DM(vO, a), X_DM(vE, b), X_DM(vO, b), X_DM(vE, b))
+                     : X_ACC_W(0), X_ACC_W(1), X_ACC_W(2), X_FRAGS, X_DMA_OUT(a, da), X_DMA_OUT(b, db) : [pa] "v"(pa), [pb] "v"(pb), [sc] "v"(sc), X_DMA_IN(a, da), X_DMA_IN(b, db) : "memory", "scc");
+    else if (DMA == 1)
+        asm volatile(X_KSTEP(S_MF, X_DM(vO, a), X_DM(vE, a), X_DM(vO, a), X_DM(vE, b), X_DM(vO, b), X_DM(vE, b))
+                     : X_ACC_RW(0), X_ACC_RW(1), X_ACC_RW(2), X_FRAGS, X_DMA_OUT(a, da), X_DMA_OUT(b, db) : [pa] "v"(pa), [pb] "v"(pb), [sc] "v"(sc), X_DMA_IN(a, da), X_DMA_IN(b, db) : "memory", "scc");
+    else if (DMA == 2)
+        asm volatile(X_KSTEP(S_MF, X_DM(vO, b), , , , , )
+                     : X_ACC_RW(0), X_ACC_RW(1), X_ACC_RW(2), X_FRAGS, X_DMA_OUT(b, db) : [pa] "v"(pa), [pb] "v"(pb), [sc] "v"(sc), X_DMA_IN(b, db) : "memory", "scc");
+    else
+        asm volatile(X_KSTEP(S_MF, , , , , , ) : X_ACC_RW(0), X_ACC_RW(1), X_ACC_RW(2), X_FRAGS : [pa] "v"(pa), [pb] "v"(pb), [sc] "v"(sc) : "memory");
+    if (DMA == 1) sx_uniform(da);
+    if (DMA) sx_uniform(db);
+}
+__device__ __forceinline__ void wx_klast(WxAcc& c, i32x4 (&a)[3], i32x4 (&an)[3], i32x4 (&b)[4], unsigned pa, unsigned pb, int sc, XDma& da) {
+    asm volatile(X_KLAST_G(S_MF, X_DM(vE, a), X_DM(vO, a), X_DM(vE, a))
+                 : X_ACC_RW(0), X_ACC_RW(1), X_ACC_RW(2), X_FRAGS, X_DMA_OUT(a, da) : [pa] "v"(pa), [pb] "v"(pb), [sc] "v"(sc), X_DMA_IN(a, da) : "memory", "scc");
+    sx_uniform(da);
+}
+__global__ __launch_bounds__(512, 2) void k_syrk_f4w(const uint8_t* __restrict__ M4, long ld4, const int* __restrict__ pairs, int npairs,
+                                                     int nblocks, long nstages, long stages_per_split, int32_t* __restrict__ C, long ldc, long n_pad) {
+    extern __shared__ __attribute__((aligned(1024))) int8_t ldsv[];  // [2][A 48 KiB | B 32 KiB]
+    const int cpx = (gridDim.x + 7) / 8;
+    const int lid = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+    if (lid >= nblocks) return;
+    const int split = __builtin_amdgcn_readfirstlane(lid / npairs);
+    const int pr = __builtin_amdgcn_readfirstlane(pairs[lid - split * npairs]);
+    const int ti = pr >> 16, tj = pr & 0xffff;   // row tile of 384, column tile of 256
+    const int s0 = split * (int)stages_per_split;
+    int s1 = s0 + (int)stages_per_split;
+    if (s1 > (int)nstages) s1 = (int)nstages;
+    if (s0 >= s1) return;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = w >> 1, wc = w & 1;   // 4 x 2 waves, wave tile 96 x 128
+    const int ldi = (int)ld4;
+    const T8Lane ln = t8_lane(lane, ldi);
+    const int8_t* baseA = (const int8_t*)M4 + (long)ti * TW_M * ld4;
+    const int8_t* baseB = (const int8_t*)M4 + (long)tj * T8 * ld4;
+    const long rows_left = n_pad - (long)ti * TW_M;
+    const int rows_here = __builtin_amdgcn_readfirstlane((int)(rows_left < TW_M ? rows_left : TW_M));
+    tw_stage<6>(__builtin_amdgcn_make_buffer_rsrc((void*)baseA, 0, rows_here * ldi, 0x00020000), ln, ldi, s0 * BK8, ldsv, w);
+    tw_stage<4>(t8_rsrc(baseB, ldi), ln, ldi, s0 * BK8, ldsv + TW_ABYTES, w);
+    __syncthreads();
+    const int r = lane & 31, h = lane >> 5, swz = (r >> 1) & 7;
+    constexpr int STG = TW_ABYTES + TILE_BYTES;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) int8_t*)ldsv;
+    const unsigned offA = lds0 + wr * (96 * BK8) + r * BK8, offB = lds0 + TW_ABYTES + wc * (128 * BK8) + r * BK8;
+    unsigned ch[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) ch[ks] = ((2 * ks + h) ^ swz) << 4;
+    XDma dA, dB;
+    dA.st = dB.st = __builtin_amdgcn_readfirstlane(8 * ldi);
+    dA.vE = dB.vE = ln.voffE; dA.vO = dB.vO = ln.voffO;
+    int snext = s0 + 1;  // the next stage to fetch
+    unsigned nrecA = 0, nrecB = 0;
+    // (the descriptors are rebuilt from scalars at each use: a loop-carried SGPR vector ends up in VGPRs)
+    auto rs_fresh = [&] { dA.rs = x_rsrc(baseA, nrecA); dB.rs = x_rsrc(baseB, nrecB); };
+    auto dma_arm = [&](int into) {
+        const unsigned base = lds0 + into * STG;
+        dA.m0 = __builtin_amdgcn_readfirstlane(base + (w * 6) * 1024 - 1024);
+        dB.m0 = __builtin_amdgcn_readfirstlane(base + TW_ABYTES + (w * 4) * 1024 - 1024);
+        dA.so = __builtin_amdgcn_readfirstlane((unsigned)((w * 6) * 8 * ldi + snext * BK8 - 8 * ldi));
+        dB.so = __builtin_amdgcn_readfirstlane((unsigned)((w * 4) * 8 * ldi + snext * BK8 - 8 * ldi));
+        // num_records = 0 when nothing is left to fetch: the loads then write zeros nobody reads
+        const int left = __builtin_amdgcn_readfirstlane(s1 - snext);
+        const unsigned on = (unsigned)max(min(left, 1), 0);
+        nrecA = __builtin_amdgcn_readfirstlane((unsigned)(rows_here * ldi) * on);
+        nrecB = __builtin_amdgcn_readfirstlane((unsigned)(T8 * ldi) * on);
+        snext++;
+    };
+    dma_arm(1);
+    rs_fresh();
+    tx_dma3(dA);
+    sx_uniform(dA);
+    const int sc = 0x7f7f7f7f;
+    int buf = 0;
+    i32x4 fa[2][3], fb[4];
+    WxAcc c;
+    tx_prologue(fa[0], fb, offA + ch[0], offB + ch[0]);
+    auto stage_rest = [&] {
+        const unsigned sa = offA + buf * STG, sb = offB + buf * STG;
+        rs_fresh();
+        wx_kstep<false, 2>(c, fa[1], fa[0], fb, sa + ch[2], sb + ch[2], sc, dA, dB);
+        wx_kstep<false, 0>(c, fa[0], fa[1], fb, sa + ch[3], sb + ch[3], sc, dA, dB);
+        dma_arm(buf);
+        rs_fresh();
+        buf ^= 1;
+        wx_klast(c, fa[1], fa[0], fb, offA + buf * STG + ch[0], offB + buf * STG + ch[0], sc, dA);
+    };
+    rs_fresh();
+    wx_kstep<true, 1>(c, fa[0], fa[1], fb, offA + ch[1], offB + ch[1], sc, dA, dB);
+    stage_rest();
+    for (int s = s0 + 1; s < s1; s++) {
+        rs_fresh();
+        wx_kstep<false, 1>(c, fa[0], fa[1], fb, offA + buf * STG + ch[1], offB + buf * STG + ch[1], sc, dA, dB);
+        stage_rest();
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    // element (i, j): lane = column j, register = row i; only 256-blocks on or above the diagonal are live in C
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+#pragma unroll
+        for (int n = 0; n < 4; n++)
+#pragma unroll
+            for (int x = 0; x < 16; x++) {
+                const long i = (long)ti * TW_M + wr * 96 + m * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
+                const long j = (long)tj * T8 + wc * 128 + n * 32 + r;
+                const int v = (int)c[m][n][x];
+                if (v && i < n_pad && (i >> 8) <= (j >> 8)) atomicAdd(&C[i * ldc + j], v);
+            }
+}
+// pair table of the 384 x 256 tiling: (I << 16) | J for 3 I / 2 <= J, in super-tiles of 4 row tiles x 8 column tiles (32 workgroups
+// = what an XCD runs at a time share 4 row panels + 8 column panels)
+static int syrk_pair_table_w(eagle_ctx* ctx, int nti, int ntj, const int** out, long* npairs) {
+    std::lock_guard<std::mutex> lock(g_pair_mutex);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static std::map<std::pair<int, int>, std::pair<int*, long>> tables;
+    auto key = std::make_pair(dev, ntj);
+    auto it = tables.find(key);
+    if (it != tables.end()) { *out = it->second.first; *npairs = it->second.second; return EAGLE_OK; }
+    std::vector<int> h;
+    for (int si = 0; si < nti; si += 4)
+        for (int sj = (3 * si / 2) / 8 * 8; sj < ntj; sj += 8)
+            for (int i = si; i < si + 4 && i < nti; i++)
+                for (int j = sj; j < sj + 8 && j < ntj; j++)
+                    if (3 * i / 2 <= j) h.push_back((i << 16) | j);
+    int* d = nullptr;
+    hipError_t e = hipMalloc((void**)&d, h.size() * sizeof(int));
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "pair table alloc");
+    e = hipMemcpy(d, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); return eagle_fail_hip(ctx, e, "pair table copy"); }
+    tables[key] = std::make_pair(d, (long)h.size());
+    *out = d;
+    *npairs = (long)h.size();
+    return EAGLE_OK;
+}
+
 static long ctx_cu_count(eagle_ctx* ctx) {
     int cu = 0;
     (void)eagle_device_info(ctx, nullptr, 0, &cu, nullptr);
@@ -2109,8 +2262,16 @@ extern "C" int eagle_dev_mmt_accumulate_f4(eagle_ctx* ctx, const void* M4, long 
         return eagle_fail(ctx, EAGLE_ERR_ARG, "mmt_accumulate_f4: layout contract violated (n_pad % 256, L_pad % 256, ld4 % 128)");
     if (L_pad == 0) return EAGLE_OK;
     const int nt = (int)(n_pad / T8);
-    const long npairs = (long)nt * (nt + 1) / 2;
     const long nstages = L_pad / 256;
+    // tune 9: k_syrk_f4 (256 x 256 tiles, compiler-scheduled), 10: k_syrk_f4p (256 x 256, pipelined k-step), else k_syrk_f4w (384 x 256)
+    // (below ~3,000 individuals the 384-row tiles pad too much and leave too few workgroups: the 256 x 256 form is as fast or faster)
+    const bool wide = ctx->tune != 9 && ctx->tune != 10 && (n_pad >= 3072 || ctx->tune == 11) && (double)ld4 * TW_M < 2147483648.0;
+    const int* pairs = nullptr;
+    long npairs = (long)nt * (nt + 1) / 2;
+    int rc;
+    if (wide) rc = syrk_pair_table_w(ctx, (int)((n_pad + TW_M - 1) / TW_M), nt, &pairs, &npairs);
+    else rc = syrk_pair_table(ctx, nt, &pairs, (hipStream_t)stream);
+    if (rc) return rc;
     long want = (10L * 256 + npairs - 1) / npairs;
     long maxsplit = nstages / 16 > 0 ? nstages / 16 : 1;
     long nsplit = want < maxsplit ? want : maxsplit;
@@ -2131,12 +2292,15 @@ extern "C" int eagle_dev_mmt_accumulate_f4(eagle_ctx* ctx, const void* M4, long 
     nsplit = (nstages + per - 1) / per;
     const long nblocks = npairs * nsplit;
     if (nblocks >= (1L << 30)) return eagle_fail(ctx, EAGLE_ERR_ARG, "mmt_accumulate_f4: too many workgroups");
-    const int* pairs = nullptr;
-    int rc = syrk_pair_table(ctx, nt, &pairs, (hipStream_t)stream);
-    if (rc) return rc;
     dim3 grid((unsigned)((nblocks + 7) / 8 * 8));
-    // tune 9: the compiler-scheduled form, for tools/bench_syrk.py
-    if (ctx->tune == 9) hipLaunchKernelGGL(k_syrk_f4, grid, dim3(512), 0, (hipStream_t)stream, (const uint8_t*)M4, ld4, pairs, (int)npairs, (int)nblocks, nstages, per, C32, n_pad);
+    if (wide) {
+        if (!ctx->attr_syrk_f4w) {
+            hipError_t ea = hipFuncSetAttribute((const void*)k_syrk_f4w, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TW_ABYTES + TILE_BYTES));
+            if (ea != hipSuccess) return eagle_fail_hip(ctx, ea, "hipFuncSetAttribute(k_syrk_f4w)");
+            ctx->attr_syrk_f4w = true;
+        }
+        hipLaunchKernelGGL(k_syrk_f4w, grid, dim3(512), 2 * (TW_ABYTES + TILE_BYTES), (hipStream_t)stream, (const uint8_t*)M4, ld4, pairs, (int)npairs, (int)nblocks, nstages, per, C32, n_pad, n_pad);
+    } else if (ctx->tune == 9) hipLaunchKernelGGL(k_syrk_f4, grid, dim3(512), 0, (hipStream_t)stream, (const uint8_t*)M4, ld4, pairs, (int)npairs, (int)nblocks, nstages, per, C32, n_pad);
     else hipLaunchKernelGGL(k_syrk_f4p, grid, dim3(512), 0, (hipStream_t)stream, (const uint8_t*)M4, ld4, pairs, (int)npairs, (int)nblocks, nstages, per, C32, n_pad);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "k_syrk_f4");

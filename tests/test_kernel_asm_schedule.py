@@ -19,7 +19,7 @@ def macro_body(name):
     return m.group(2)
 
 
-TOKEN = re.compile(r'(X_WT|X_LD|X_DM|X_MF|X_MZ|S_MF|S_MZ|\bM)\(([^)]*)\)|(s_waitcnt vmcnt\(0\) lgkmcnt\(0\))|(s_barrier)')
+TOKEN = re.compile(r'(X_WT|X_LD|X_DM|X_MF|X_MZ|S_MF|S_MZ|\bM)\(([^)]*)\)|(s_waitcnt vmcnt\(0\) lgkmcnt\(0\))|(s_barrier)|\b(DA[123])\b')
 
 
 def run(body, entry, loads_expected):
@@ -35,6 +35,9 @@ def run(body, entry, loads_expected):
         if t.group(4):
             assert not queue, "barrier with LDS reads of this buffer outstanding"
             seq.append(("barrier",))
+            continue
+        if t.group(5):   # a DMA slot of a generic macro (its operand set is the instantiation's business)
+            seq.append(("dma", t.group(5)))
             continue
         kind, args = t.group(1), [a.strip() for a in t.group(2).split(",")]
         if kind == "X_WT":
@@ -72,13 +75,18 @@ def test_vara_kstep_queue_discipline():
     assert len(mf) == 12 and len({s[1] for s in mf}) == 12       # 3 x 4 tiles, each once
     assert {(s[2], s[3]) for s in mf} == {("a%d" % m, "b%d" % n) for m in range(3) for n in range(4)}
     assert all(s[1] == "c%s%s" % (s[2][1], s[3][1]) for s in mf)  # accumulator c<m><n> gets a<m> x b<n>
-    last, seq = run(macro_body("X_KLAST"), entry, ["x0", "x1", "x2", "b0", "b1", "b2", "b3"])
+    last, seq = run(macro_body("X_KLAST_G"), entry, ["x0", "x1", "x2", "b0", "b1", "b2", "b3"])
     assert rename(last, x_to_a) == entry
     kinds = [s[0] for s in seq]
     assert kinds.index("wait_all") < kinds.index("barrier") < kinds.index("dma")   # DMA into the freed buffer only behind the barrier
     assert sum(k == "mfma" for k in kinds) == 12 and sum(k == "dma" for k in kinds) == 3
     # the DMA slots of a stage: 3 genotype loads behind the barrier + (3 genotype, 3 digit) + 1 digit = 6 + 4 row groups per wave
-    assert [s[1:] for s in seq if s[0] == "dma"] == [("vE", "a"), ("vO", "a"), ("vE", "a")]
+    assert [s[1] for s in seq if s[0] == "dma"] == ["DA1", "DA2", "DA3"]
+    inst = re.search(r"#define X_KLAST X_KLAST_G\((.*)\)\n", SRC).group(1)
+    assert [a.strip() for a in re.findall(r"X_DM\(([^)]*)\)", inst)] == ["vE, a", "vO, a", "vE, a"] and inst.startswith("X_MF")
+    # and the 384 x 256 MM^T kernel instantiates the same macro with the fp4 instruction and the same DMA slots
+    inst = re.search(r"asm volatile\(X_KLAST_G\((.*?)\)\n", SRC).group(1)
+    assert [a.strip() for a in re.findall(r"X_DM\(([^)]*)\)", inst)] == ["vE, a", "vO, a", "vE, a"] and inst.startswith("S_MF")
 
 
 def test_syrk_kstep_queue_discipline():

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """GPU A/B of the MM^T kernel forms (tune switch) on one resident shard, interleaved rounds in one process.
-VARIANTS: 0 = shipped (asm-pipelined k-step, k_syrk_f4p), 9 = the same tile scheduled by hipcc (k_syrk_f4)."""
+VARIANTS: 0 = shipped (k_syrk_f4w: 384 x 256 tiles, asm-pipelined k-step, from 3,072 padded individuals; 11 forces it), 10 = 256 x 256 tiles with the pipelined k-step
+(k_syrk_f4p), 9 = 256 x 256 tiles scheduled by hipcc (k_syrk_f4)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,7 +11,7 @@ from eagleeverything_amd import _lib
 from eagleeverything_amd.sharded import DeviceShard
 
 n, L = int(os.environ.get("N", 5000)), int(os.environ.get("LM", 500000))
-variants = [int(v) for v in os.environ.get("VARIANTS", "0,9").split(",")]
+variants = [int(v) for v in os.environ.get("VARIANTS", "0,10,9").split(",")]
 lib = _lib.load()
 sh = DeviceShard(n, L)
 sh.fill_synthetic()
