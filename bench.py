@@ -354,7 +354,7 @@ def main():
         "genotype_pass": {"bound": "hbm", "kernel": "k_slice_vec + k_gemv_mfma (a = Mt v; algorithmic bytes = L_pad*n_pad genotype bytes)",
                           "achieved": Lp * np_ / gpass_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": Lp * np_ / gpass_s / 1e9 / HBM_PEAK_GBS, "kernel_ms": gpass_s * 1e3},
-        "syrk_f4": {"bound": "mfma", "kernel": "k_syrk_f4p (v_mfma_scale_f32_32x32x64_f8f6f4, fp4 x fp4, exact)", "dtype": "fp4",
+        "syrk_f4": {"bound": "mfma", "kernel": "k_syrk_f4w (v_mfma_scale_f32_32x32x64_f8f6f4, fp4 x fp4, exact; 384 x 256 tiles)", "dtype": "fp4",
                     "achieved": (np_ * (np_ + 256.0)) * Lp / syrk_s / 1e12, "peak": FP4_MFMA_PEAK_TOPS,
                     "unit": "TFLOP/s", "frac": (np_ * (np_ + 256.0)) * Lp / syrk_s / 1e12 / FP4_MFMA_PEAK_TOPS,
                     "kernel_ms": syrk_s * 1e3},

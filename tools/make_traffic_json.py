@@ -49,7 +49,7 @@ lpad = (markers + 255) // 256 * 256
 out = {"kernel_sha16": kernel_sha16(),
        "k_vara_i8": entry("k_vara_i8p", float(lpad) * npad + slices * npad * npad / 2.0),
        "k_gemv_mfma": entry("k_gemv_mfma", float(lpad) * npad),
-       "k_syrk_f4": entry("k_syrk_f4p", float(lpad) * npad / 2.0),
+       "k_syrk_f4": entry("k_syrk_f4w", float(lpad) * npad / 2.0),
        "k_gemm_f64_list": entry("k_gemm_f64_list", 3.0 * 8 * npad * npad)}
 json.dump(out, open(os.path.join(ROOT, "profiles", "r02_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
