@@ -803,3 +803,24 @@ def test_dev_gemm_f64_layout(api):
     assert rc == 0
     torch.cuda.synchronize()
     np.testing.assert_array_equal(dC.cpu().numpy(), A @ B)
+
+
+@pytest.mark.parametrize("n", [3001, 3100, 3500])
+def test_mmt_on_384_row_tiles_every_last_tile_shape(n):
+    """k_syrk_f4w (384 x 256 tiles on the symmetric output; from 3,072 padded individuals): padded sizes 3072 = 8 x 384, 3328
+    (last row tile 256 rows) and 3584 (128 rows), a marker count that splits K unevenly: the live 256-tiles of the exact int32
+    accumulator against an fp64 product of the same integers (exact: far below 2^53), the dead tiles untouched."""
+    import torch
+    from eagleeverything_amd.sharded import DeviceShard
+    L = 9000
+    sh = DeviceShard(n, L)
+    sh.fill_synthetic(seed=n)
+    c32 = torch.full((sh.np_, sh.np_), -7, dtype=torch.int32, device=sh.dev)
+    upper = torch.triu(torch.ones((sh.np_ // 256, sh.np_ // 256), dtype=torch.bool, device=sh.dev)).repeat_interleave(256, 0).repeat_interleave(256, 1)
+    c32[upper] = 0
+    M4 = sh.individual_major_fp4()
+    assert sh.L.eagle_dev_mmt_accumulate_f4(sh.ctx, M4.data_ptr(), sh.np_, sh.Lp, sh.Lp // 2, c32.data_ptr(), sh._stream()) == 0
+    G = sh.Mt8.to(torch.float64)                               # padded rows / columns are zero
+    ref = (G.T @ G).to(torch.int32)
+    assert torch.equal(c32[upper], ref[upper])
+    assert bool((c32[~upper] == -7).all())
