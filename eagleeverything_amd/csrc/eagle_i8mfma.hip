@@ -840,7 +840,12 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8w(const int8_t* __restrict__ 
 //     the next k-step, the last in the one after) instead of as a burst at the top of the stage (the burst alone costs 3-4 %, tune 11-15 experiments);
 //   * the first k-step of a tile uses the inline constant 0 as the C operand: no zeroing pass;
 //   * the stage barrier sits in the middle of the last k-step (after 6 of its 12 MFMAs: all fragment reads of this stage have
-//     returned; the re-loads behind the barrier read the other buffer), so each wave reaches it with matrix work in flight.
+//     returned; the re-loads behind the barrier read the other buffer), so each wave reaches it with matrix work in flight;
+//   * the W digits are SrcA and the genotypes SrcB (below): transposed result tiles, lane = marker, register = W column; with
+//     the digit slices' columns permuted inside blocks of 128 (k_slice_w) a lane's 64 columns are 64 consecutive genotype bytes
+//     of its own marker row, and the tile epilogue is four 16-byte loads and 64 multiply-adds per lane, no cross-lane reduction.
+// Every asm block that advances DMA addresses with s_add_u32 declares the "scc" clobber (hipcc keeps compare results in SCC
+// across asm statements that do not).
 // ------------------------------------------------------------------------------------------------
 // SrcA = the W-digit fragment b, SrcB = the genotype fragment a: the matrix unit draws far less power when its SrcB operand is the
 // low-entropy one (tools/ubench/mfma_ceiling.hip: a bare loop on these operand statistics holds 3.75 POP/s this way round,
@@ -962,7 +967,6 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8p(const int8_t* __restrict__ 
     unsigned ch[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) ch[ks] = ((2 * ks + h) ^ swz) << 4;
-    const int xsel = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
     const int evoff = (wr * 96 + r) * ldi + wc * 128 + h * 64;  // epilogue: this lane's marker row and its 64 genotype columns (k_slice_w, perm128)
     // stage 0 as a burst, then the pipeline: eight waves issue the DMA of a stage, A 48 row groups (6 per wave), B 32 (4 per wave)
     tw_stage<6>(rsA, lnA, ldi, nxt.kt * BK8, ldsv, w);
