@@ -33,6 +33,28 @@ __global__ __launch_bounds__(512, 2) void k_loop(const i32x4* __restrict__ A, co
     out[blockIdx.x * 512 + t] = s;
 }
 
+// the other int8 shape, 16 x 16 x 64 (same MACs per wave as 12 tiles of 32 x 32 x 32: 24 tiles of 16 x 16, 8 accumulator registers each)
+typedef int i32x4b __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512, 2) void k_loop16(const i32x4* __restrict__ A, const i32x4* __restrict__ B, int* __restrict__ out, int iters) {
+    const int t = threadIdx.x;
+    i32x4 a[6], b[8];
+    for (int m = 0; m < 6; m++) a[m] = A[(t + 512 * m) & 4095];
+    for (int n = 0; n < 8; n++) b[n] = B[(t + 512 * n) & 4095];
+    i32x4 c[6][8];
+    for (int m = 0; m < 6; m++) for (int n = 0; n < 8; n++) for (int i = 0; i < 4; i++) c[m][n][i] = 0;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int m = 0; m < 6; m++)
+#pragma unroll
+            for (int n = 0; n < 8; n++) c[m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[m], b[n], c[m][n], 0, 0, 0);
+        const i32x4 ta = a[0]; a[0] = a[1]; a[1] = a[2]; a[2] = a[3]; a[3] = a[4]; a[4] = a[5]; a[5] = ta;
+        const i32x4 tb = b[0]; b[0] = b[1]; b[1] = b[2]; b[2] = b[3]; b[3] = b[4]; b[4] = b[5]; b[5] = b[6]; b[6] = b[7]; b[7] = tb;
+    }
+    int s = 0;
+    for (int m = 0; m < 6; m++) for (int n = 0; n < 8; n++) for (int i = 0; i < 4; i++) s += c[m][n][i];
+    out[blockIdx.x * 512 + t] = s;
+}
+
 // the MM^T kernel's instruction: fp4 x fp4 on the block-scaled MFMA (K = 64), wave shape of k_syrk_f4p (4 x 2 tiles)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -98,6 +120,22 @@ int main(int argc, char** argv) {
             CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
             const double ops = 2.0 * 256 * 8 * (double)iters * 12 * 32 * 32 * 32;
+            if (rep) printf("%s: %8.2f ms  %.2f POP/s  (= %.3f of 5 POP/s)\n", cs.name, ms, ops / ms / 1e12, ops / ms / 1e12 / 5.0);
+        }
+    }
+    struct { const char* name; const int8_t* a; const int8_t* b; } cases16[] = {
+        {"16x16x64: A random digits x B genotypes", rnd.data(), genof.data()},
+        {"16x16x64: A genotypes x B random digits", genof.data(), rnd.data()},
+    };
+    for (auto& cs : cases16) {
+        CHECK(hipMemcpy(dA, cs.a, 65536, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(dB, cs.b, 65536, hipMemcpyHostToDevice));
+        for (int rep = 0; rep < 2; rep++) {
+            CHECK(hipEventRecord(e0));
+            hipLaunchKernelGGL(k_loop16, dim3(256), dim3(512), 0, 0, dA, dB, dOut, iters / 2);
+            CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            const double ops = 2.0 * 256 * 8 * (double)(iters / 2) * 48 * 16 * 16 * 64;
             if (rep) printf("%s: %8.2f ms  %.2f POP/s  (= %.3f of 5 POP/s)\n", cs.name, ms, ops / ms / 1e12, ops / ms / 1e12 / 5.0);
         }
     }
