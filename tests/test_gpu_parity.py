@@ -492,7 +492,9 @@ def test_vara_rare_variants_and_monomorphic_markers(api, oracle):
     used, bound, _ = sh.vara_i8_info()
     vara = sh.vara[:L].cpu().numpy()
     cs = sh.cshift[:L].cpu().numpy()
-    assert set(np.unique(cs)) == {-1, 0, 1}
+    # every marker is centred on a homozygote (the majority genotype, or the commoner homozygote when the heterozygote is the
+    # majority), so that the stored rows have no negative entries; only an all-heterozygote marker would keep c = 0
+    assert set(np.unique(cs)) == {-1, 1}
     typical = np.median(v_ref[maf > 0.05])
     mono = (Mt8 == Mt8[:, :1]).all(axis=1)   # includes rare markers that drew no minor allele
     assert mono.sum() >= 64
