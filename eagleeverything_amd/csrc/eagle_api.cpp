@@ -269,6 +269,8 @@ extern "C" void eagle_close(eagle_ctx* ctx) {
     if (ctx->d_a) (void)hipFree(ctx->d_a);
     if (ctx->d_vara) (void)hipFree(ctx->d_vara);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_Scache) (void)hipFree(ctx->d_Scache);
+    if (ctx->d_Sscr) (void)hipFree(ctx->d_Sscr);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->gemv_ws) (void)hipFree(ctx->gemv_ws);
     if (ctx->f4_buf) (void)hipFree(ctx->f4_buf);
@@ -825,6 +827,18 @@ struct ChunkRing {
     }
 };
 
+// any bit of two device arrays different -> *flag != 0 (the cached S against the caller's)
+__global__ __launch_bounds__(256) void k_bits_differ(const unsigned long long* __restrict__ a, const unsigned long long* __restrict__ b, long count,
+                                                     int* __restrict__ flag) {
+    int d = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) d |= a[i] != b[i];
+    if (__any(d) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+static int upload_square_on(eagle_ctx* ctx, const double* host, long n, long np, double* dev, hipStream_t st) {
+    HIPCHK(ctx, hipMemsetAsync(dev, 0, sizeof(double) * np * np, st));
+    HIPCHK(ctx, hipMemcpy2DAsync(dev, sizeof(double) * np, host, sizeof(double) * n, sizeof(double) * n, n, hipMemcpyHostToDevice, st));
+    return EAGLE_OK;
+}
 // column-major n x n host matrix -> zero padded np x np device image (row-major image of the transpose)
 static int upload_square(eagle_ctx* ctx, const double* host, long n, long np, double* dev) {
     HIPCHK(ctx, hipMemsetAsync(dev, 0, sizeof(double) * np * np, ctx->stream));
@@ -1073,6 +1087,7 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
     const size_t certb = use_i8 ? (size_t)eagle_scan_certify_workspace_bytes(np) : 0;
     const double t0 = now_s();
     double *Sa = nullptr, *Va = nullptr, *tmp = nullptr, *Wu = nullptr, *ah = nullptr, *v = nullptr;
+    bool s_from_cache = false;  // the product runs on the device copy of the last call's S; the caller's S is verified under it
     void *ws = nullptr, *cert = nullptr;
     long* cert_totals = (long*)((char*)ctx->d_scratch + 256);  // {re-evaluated, flagged, fell back}, summed over marker blocks
     ChunkRing ring;
@@ -1106,9 +1121,26 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
             if ((r = upload_square(ctx, inv_MMt_sqrt, n, np, Wu))) return r;
             if ((r = upload_vec(ctx, a, n, np, v))) return r;
         } else {
-            if ((r = upload_square(ctx, inv_MMt_sqrt, n, np, Sa))) return r;
+            // V and a_hat first: the first product needs all of V.  S = inv_MMt_sqrt is MMt^-1/2, the same matrix in every call of an
+            // AM() run, but R builds it anew each time (no pointer identity, and hashing 800 MB costs what copying them costs): the
+            // copy of the last call stays on the device, this call computes on it at once, and the caller's matrix is uploaded on
+            // the loader stream and compared bit for bit while the n^3 product runs; a difference starts the product over (below).
             if ((r = upload_square(ctx, dim_reduced_vara, n, np, Va))) return r;
             if ((r = upload_vec(ctx, a, n, np, ah))) return r;
+            const bool cacheable = !share_w && np <= 16384 && !getenv("EAGLE_HIP_NO_SCACHE");
+            if (cacheable && ctx->scache_np != np) {
+                if (ctx->d_Scache) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->d_Scache); ctx->d_Scache = nullptr; }
+                if (ctx->d_Sscr) { (void)hipFree(ctx->d_Sscr); ctx->d_Sscr = nullptr; }
+                ctx->scache_n = ctx->scache_np = 0;
+                if (hipMalloc((void**)&ctx->d_Scache, sq) == hipSuccess && hipMalloc((void**)&ctx->d_Sscr, sq) == hipSuccess) ctx->scache_np = np;
+                else { if (ctx->d_Scache) (void)hipFree(ctx->d_Scache); ctx->d_Scache = nullptr; (void)hipGetLastError(); }
+            }
+            if (cacheable && ctx->scache_np == np) {
+                s_from_cache = ctx->scache_n == n;
+                if (!s_from_cache && (r = upload_square(ctx, inv_MMt_sqrt, n, np, ctx->d_Scache))) return r;
+                ctx->scache_n = n;
+                Sa = ctx->d_Scache;
+            } else if ((r = upload_square(ctx, inv_MMt_sqrt, n, np, Sa))) return r;
         }
         if ((r = ensure_scan_out(ctx, Lp))) return r;
         HIPCHK(ctx, hipMemsetAsync(cert_totals, 0, 3 * sizeof(long), ctx->stream));
@@ -1129,6 +1161,27 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
         if (!rc) rc = eagle_dev_fold_upper(ctx, Wu, np, ctx->stream);
     } else if (!rc) {
         rc = w_direct ? eagle_dev_fold_upper(ctx, Wu, np, ctx->stream) : eagle_dev_scan_operands(ctx, Sa, Va, ah, n, np, v, Wu, tmp, ctx->stream);
+        if (!rc && s_from_cache) {
+            // under the product: the caller's S to the scratch copy (loader stream), compared with the cached one
+            int* flag = (int*)((char*)ctx->d_scratch + 2048);
+            int differ = 0;
+            e = hipMemsetAsync(flag, 0, sizeof(int), ctx->load_stream);
+            if (e == hipSuccess) rc = upload_square_on(ctx, inv_MMt_sqrt, n, np, ctx->d_Sscr, ctx->load_stream);
+            if (e == hipSuccess && !rc) {
+                hipLaunchKernelGGL(k_bits_differ, dim3(1024), dim3(256), 0, ctx->load_stream, (const unsigned long long*)ctx->d_Sscr,
+                                   (const unsigned long long*)ctx->d_Scache, np * np, flag);
+                e = hipMemcpyAsync(&differ, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->load_stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->load_stream);
+            }
+            if (e != hipSuccess && !rc) rc = eagle_fail_hip(ctx, e, "verification of the cached S");
+            if (!rc && differ) {  // another S: it is already on the device -- start the product over with it
+                if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) rc = eagle_fail_hip(ctx, e, "scan operands");
+                std::swap(ctx->d_Scache, ctx->d_Sscr);
+                Sa = ctx->d_Scache;
+                if (!rc) rc = eagle_dev_scan_operands(ctx, Sa, Va, ah, n, np, v, Wu, tmp, ctx->stream);
+                ctx->scache_misses++;
+            } else if (!rc) ctx->scache_hits++;
+        }
     }
     if (!rc && streamed && !quiet) say(ctx, " Mt.ascii streamed through HBM in blocks of %ld markers", Lc);
     // one pass per marker block: the whole shard when it is resident, else chunks read back from the file
@@ -1310,6 +1363,14 @@ extern "C" int eagle_scan_with_W(eagle_ctx* ctx, const char* f_name_ascii, const
     return EAGLE_OK;
 }
 
+extern "C" int eagle_scan_operand_cache_stats(eagle_ctx* ctx, long* hits, long* misses) {
+    if (!ctx) return EAGLE_ERR_ARG;
+    long h = ctx->scache_hits, m = ctx->scache_misses;
+    for (eagle_ctx* p : ctx->peers) { h += p->scache_hits; m += p->scache_misses; }
+    if (hits) *hits = h;
+    if (misses) *misses = m;
+    return EAGLE_OK;
+}
 extern "C" int eagle_last_stream_stats(eagle_ctx* ctx, eagle_stream_stats* out) {
     if (!ctx || !out) return EAGLE_ERR_ARG;
     out->chunks = ctx->st_chunks; out->file_bytes = ctx->st_file_bytes;

@@ -81,6 +81,9 @@ struct eagle_ctx {
     double* d_mmt = nullptr; long mmt_n = 0; double* d_mmt_max = nullptr;
     double* d_a = nullptr; double* d_vara = nullptr; long scan_L = 0; long scan_cap = 0;
     long cert_reevaluated = 0, cert_flagged = 0; int cert_fell_back = 0;  // certification counters of the last digit-slice scan
+    // S = inv_MMt_sqrt of the last scan, kept on the device: MMt^-1/2 is the same matrix in every find_qtl call of an AM() run
+    // (scan_range: the next call computes on this copy while the caller's matrix is uploaded and compared under the product)
+    double* d_Scache = nullptr; double* d_Sscr = nullptr; long scache_n = 0, scache_np = 0; long scache_hits = 0, scache_misses = 0;
     // out-of-core bookkeeping of the last streamed call on this device (eagle_last_stream_stats)
     long st_chunks = 0, st_file_bytes = 0;
     double st_pread_s = 0, st_load_wall_s = 0, st_wait_s = 0, st_compute_s = 0, st_total_s = 0, st_starved_s = 0, st_load_first_s = 0;

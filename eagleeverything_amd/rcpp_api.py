@@ -268,6 +268,15 @@ def last_stream_stats(device=0):
     return d
 
 
+def scan_operand_cache_stats(device=0):
+    """(hits, misses) of the device copy of S = inv_MMt_sqrt kept between calculate_a_and_vara_rcpp calls (include/eagle_hip.h)."""
+    L = _lib.load()
+    ctx = context(device)
+    h, m = C.c_long(), C.c_long()
+    _check(ctx, L.eagle_scan_operand_cache_stats(ctx, C.byref(h), C.byref(m)))
+    return h.value, m.value
+
+
 def last_mmt_normalised(n, device=0):
     """calcMMt.R:13 applied on the device to the last calculateMMt result."""
     L = _lib.load()

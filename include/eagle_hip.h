@@ -380,6 +380,12 @@ typedef struct eagle_stream_stats {
     double starved_s;    /* device seconds the compute stream sat idle between chunks because the next one was not loaded yet */
 } eagle_stream_stats;
 int eagle_last_stream_stats(eagle_ctx* ctx, eagle_stream_stats* out);
+/* eagle_calculate_a_and_vara keeps the last call's S = inv_MMt_sqrt on the device (MMt^-1/2 is the same matrix in every find_qtl
+ * call of an AM() run; n_pad <= 16,384, 2 x 8 n_pad^2 bytes): the next call starts its n^3 products on that copy and meanwhile
+ * uploads the caller's matrix and compares the two bit for bit; a difference starts the products over with the new matrix, so the
+ * result never depends on the cache.  hits: calls whose S was the cached one (its PCIe upload hidden under the product);
+ * misses: calls that started over.  EAGLE_HIP_NO_SCACHE=1 disables the mechanism. */
+int eagle_scan_operand_cache_stats(eagle_ctx* ctx, long* hits, long* misses);
 /* The same quadratic form on the block-scaled matrix path (v_mfma_scale_f32_32x32x64_f8f6f4): genotypes as fp4, balanced
  * base-33 digits of Wu as fp6 (every integer in [-16,16] is an e2m3 number / 8), exact fp32 sums, twice the MAC rate of
  * the int8 instruction.  Mt4: [L_pad][n_pad/2] bytes made once per genotype matrix by eagle_dev_pack_fp4 (two genotypes

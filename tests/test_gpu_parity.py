@@ -826,3 +826,39 @@ def test_mmt_on_384_row_tiles_every_last_tile_shape(n):
     ref = (G.T @ G).to(torch.int32)
     assert torch.equal(c32[upper], ref[upper])
     assert bool((c32[~upper] == -7).all())
+
+
+def test_cached_S_is_verified_and_never_changes_a_result(api, tmp_path, monkeypatch):
+    """calculate_a_and_vara keeps the last call's S on the device and starts the next call's products on it while the caller's S is
+    uploaded and compared under them (AM(): MMt^-1/2 is the same matrix in every find_qtl call).  Same S -> a hit; one entry of S
+    changed -> the products start over; either way the arrays are bit for bit those of a call with the mechanism switched off."""
+    n, L = 900, 5000
+    rng = np.random.default_rng(8)
+    Mt8 = synth.genotypes_marker_major(n, L, seed=31)
+    geno = synth.write_geno_pair(str(tmp_path), Mt8)
+    A = rng.standard_normal((n, 30)) / 6.0
+    S = np.asfortranarray(np.eye(n) + A @ A.T)
+    V1 = np.asfortranarray(0.6 * np.eye(n) - 0.02 * (A[:, :5] @ A[:, :5].T))
+    V2 = np.asfortranarray(0.9 * np.eye(n) - 0.01 * (A[:, 5:9] @ A[:, 5:9].T))
+    ahat = rng.standard_normal(n)
+    S2 = S.copy(order="F")
+    S2[n // 2, n // 3] += 1e-3                                       # one entry, far from the corner
+    call = lambda Sx, Vx: api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, Sx, Vx, 8.0, (L, n), ahat)
+    monkeypatch.setenv("EAGLE_HIP_NO_SCACHE", "1")
+    ref = {k: call(*k_args) for k, k_args in (("S,V1", (S, V1)), ("S,V2", (S, V2)), ("S2,V2", (S2, V2)))}
+    monkeypatch.delenv("EAGLE_HIP_NO_SCACHE")
+    h0, m0 = api.scan_operand_cache_stats()
+    first = call(S, V1)                       # whatever the cache held before: filled or started over
+    h1, m1 = api.scan_operand_cache_stats()
+    again = call(S, V2)                       # the same S: computed on the device copy, verified under the product
+    h2, m2 = api.scan_operand_cache_stats()
+    other = call(S2, V2)                      # another S: detected, started over
+    h3, m3 = api.scan_operand_cache_stats()
+    back = call(S2, V2)                       # and now that one is the cached S
+    h4, m4 = api.scan_operand_cache_stats()
+    assert (h2 - h1, m2 - m1) == (1, 0) and (h3 - h2, m3 - m2) == (0, 1) and (h4 - h3, m4 - m3) == (1, 0)
+    for got, key in ((first, "S,V1"), (again, "S,V2"), (other, "S2,V2"), (back, "S2,V2")):
+        np.testing.assert_array_equal(got["a"], ref[key]["a"])
+        np.testing.assert_array_equal(got["vara"], ref[key]["vara"])
+    assert not np.array_equal(again["a"], other["a"])     # the changed entry does reach the result
+    api.drop_cache()
