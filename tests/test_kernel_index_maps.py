@@ -75,3 +75,23 @@ def test_split_markers_ranges():
             edge = [0] + [min(L, (tiles * k // nd) * 256) for k in range(1, nd)] + [L]
             assert all(a <= b for a, b in zip(edge, edge[1:])) and edge[0] == 0 and edge[-1] == L
             assert all(e % 256 == 0 for e in edge[1:-1])
+
+
+def test_slice_permutation_matches_the_transposed_tile_layout():
+    """k_slice_w (perm128) against k_vara_i8p's epilogue (csrc/eagle_i8mfma.hip): inside every block of 128, column c of Wu is
+    stored at row n*32 + 8*(x>>2) + (x&3) + 4*h with h = c>>6, n = (c>>4)&3, x = c&15 -- the row of the wave's W-digit tile that the
+    32 x 32 x 32 MFMA (W digits as SrcA) turns into register x of column tile n in lane half h.  The epilogue reads, for lane
+    half h and column tile n, the 16 genotype bytes at columns 64 h + 16 n + x of the wave's 128: byte x must belong to
+    register x.  A bijection on 0..127, block by block."""
+    def stored_row(c):                       # k_slice_w
+        c7, cx = c & 127, c & 15
+        return (c & ~127) | (((c7 >> 4) & 3) << 5) | ((cx >> 2) << 3) | (cx & 3) | ((c7 >> 6) << 2)
+    assert sorted(stored_row(c) for c in range(256)) == list(range(256))
+    for c in range(256):
+        assert stored_row(c) >> 7 == c >> 7                                    # stays inside its block of 128
+    for h in range(2):
+        for n in range(4):
+            for x in range(16):
+                mfma_row = n * 32 + 8 * (x >> 2) + (x & 3) + 4 * h             # D-tile row of register x in lane half h (32 x 32 layout)
+                col_read = 64 * h + 16 * n + x                                 # epilogue: g[n] byte x at column offset h*64 + n*16
+                assert stored_row(col_read) == mfma_row
