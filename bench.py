@@ -244,7 +244,162 @@ def vara_roofline(sh, kern_s, S_used):
     return roof
 
 
-def main():
+def abi_leg(args, torch, geno, n, L, S, V, ahat, device, steps, warmup, mmt_reps=2):
+    """The reference-shaped calls (host files -> host results) on `device` (an int, or a tuple of devices behind ONE context):
+    eagle_calculateMMt and eagle_calculate_a_and_vara + eagle_last_scan_argmax through ctypes -- what the R package's .Call
+    sees (E/R/calcMMt.R:1-15, E/R/calculate_a_and_vara.R:20-31, E/R/find_qtl.R:71-83).  S, V: column-major host matrices as R
+    hands them; every call uploads them over PCIe (S is verified against the device copy of the last call instead, when it is
+    the same matrix) and brings a, vara (16 bytes per marker) back.  PCIe-inclusive: never bench.py's `value` in the default form."""
+    from eagleeverything_amd import rcpp_api
+    ncores = os.cpu_count() or 1
+    out = {}
+    nan = float("nan")
+    mm_cold = mm_warm = None
+    MMt = None
+    if geno.get("asciifileM"):
+        t = time.perf_counter()
+        MMt = rcpp_api.calculateMMt_rcpp(geno["asciifileM"], 8.0, ncores, nan, (n, L), device=device)
+        mm_cold = time.perf_counter() - t
+        ts = []
+        for _ in range(mmt_reps):
+            t = time.perf_counter()
+            MMt = rcpp_api.calculateMMt_rcpp(geno["asciifileM"], 8.0, ncores, nan, (n, L), device=device)
+            ts.append(time.perf_counter() - t)
+        mm_warm = float(np.mean(ts))
+        out["calculateMMt_s"] = {"cold (2-bit sidecar -> HBM -> MM^T -> host)": mm_cold, "warm (genotypes resident; 8 n^2 bytes back)": mm_warm}
+    if S is None:
+        return out, MMt
+    t = time.perf_counter()
+    r = rcpp_api.calculate_a_and_vara_rcpp(geno["asciifileMt"], nan, S, V, 8.0, (L, n), ahat, device=device)
+    scan_cold = time.perf_counter() - t
+    for _ in range(warmup):
+        r = rcpp_api.calculate_a_and_vara_rcpp(geno["asciifileMt"], nan, S, V, 8.0, (L, n), ahat, device=device)
+    t = time.perf_counter()
+    for _ in range(steps):
+        r = rcpp_api.calculate_a_and_vara_rcpp(geno["asciifileMt"], nan, S, V, 8.0, (L, n), ahat, device=device)
+        idx, tsqmax, near = rcpp_api.last_scan_argmax(device=device)
+    elapsed = time.perf_counter() - t
+    ndev = len(device) if isinstance(device, tuple) else 1
+    out["calculate_a_and_vara_s"] = {"cold (2-bit sidecar -> HBM, then the scan)": scan_cold, "warm": elapsed / steps}
+    out["markers_per_s"] = L * steps / elapsed
+    out["ms_per_call"] = elapsed / steps * 1e3
+    out["phases_per_device"] = [rcpp_api.last_scan_timing(device=device, device_index=k) for k in range(ndev)]
+    out["s_cache (hits, misses)"] = list(rcpp_api.scan_operand_cache_stats(device=device))
+    a, v = np.asarray(r["a"]).ravel(), np.asarray(r["vara"]).ravel()
+    with np.errstate(all="ignore"):
+        tsq = a * a / v
+    out["selected_marker"] = int(idx)
+    out["tsqmax"] = float(tsqmax)
+    out["selected_marker_is_first_argmax_of_returned_arrays"] = bool(idx == int(np.nanargmax(tsq)) + 1)   # find_qtl.R:76-80 on what R receives
+    out["results"] = (a, v)
+    return out, MMt
+
+
+def main_abi(args):
+    """--form abi: ONE process, N GPUs behind the reference-shaped C ABI (eagle_open_devices: worker thread + stream per device,
+    ncclReduce of the packed int32 MM^T tiles, W's rows + ncclAllGather, lower bounds through the host).  Same workload, data,
+    operands and metric as the default form; host files in, host arrays out, so every call includes its PCIe traffic."""
+    import tempfile
+    N = args.gpus
+    devs = [int(x) for x in args.abi_devices.split(",")] if args.abi_devices else list(range(N))
+    if len(devs) != N:
+        print("bench.py: --abi-devices names %d devices but --gpus is %d" % (len(devs), N), file=sys.stderr)
+        return 2
+    if args.dry_run:
+        print(json.dumps({"dry_run": True, "form": "abi", "n_gpus": N, "devices": devs, "launcher": "single process (eagle_open_devices)"}))
+        return 0
+    import torch
+    have = torch.cuda.device_count()
+    if have == 0 or max(devs) >= have:
+        print("bench.py: --form abi wants devices %s but this node shows %d GPU(s)" % (devs, have), file=sys.stderr)
+        return 3
+    from eagleeverything_amd import rcpp_api, synth
+    from eagleeverything_amd.sharded import DeviceShard
+    n, L = args.n, args.markers
+    device = devs[0] if N == 1 else tuple(devs)
+    dev0 = torch.device("cuda", devs[0])
+    t0 = time.time()
+    sh = DeviceShard(n, L, first_marker=0, device=devs[0])
+    sh.fill_synthetic()
+    tmp = tempfile.mkdtemp(dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        geno = synth.write_geno_pair_sidecars(tmp, sh)
+        # the trait needs ten genotype rows of rank 0's range (as in the default form): keep them, drop the images
+        gen = torch.Generator(device=dev0)
+        gen.manual_seed(7)
+        qtl = torch.linspace(0, max(1, L // 8) - 1, 12, device=dev0).long()[1:-1].clamp(max=L - 1)
+        y = 0.5 * sh.Mt8[qtl, :n].double().sum(0) + torch.randn(n, generator=gen, device=dev0, dtype=torch.float64)
+        del sh
+        torch.cuda.empty_cache()
+        t_gen = time.time() - t0
+        part, MMt = abi_leg(args, torch, geno, n, L, None, None, None, device, 0, 0, args.mmt_reps)
+        t1 = time.time()
+        if args.load_operands:
+            S, V, ahat = [x.to(dev0) for x in torch.load(args.load_operands, weights_only=True)]
+        else:
+            Md = torch.as_tensor(MMt, device=dev0)
+            Md = Md / Md.max() + 0.95 * torch.eye(n, dtype=torch.float64, device=dev0)   # calcMMt.R:13
+            X = torch.ones((n, 1), dtype=torch.float64, device=dev0)
+            S, V, ahat, _, _ = host_operands_torch(torch, Md, X, y, 1.0, 0.5)
+            del Md
+        # what R hands over: column-major n x n doubles (rcpp_api takes MATRICES; .T of the C-ordered copy is the F-ordered matrix)
+        S_h = np.asfortranarray(S.cpu().numpy())
+        V_h = np.asfortranarray(V.cpu().numpy())
+        a_h = ahat.cpu().numpy()
+        del S, V, MMt
+        torch.cuda.empty_cache()
+        t_ops = time.time() - t1
+        geno_scan = {"asciifileMt": geno["asciifileMt"]}
+        leg, _ = abi_leg(args, torch, geno_scan, n, L, S_h, V_h, a_h, device, args.steps, args.warmup)
+        leg.pop("results")
+        ph = leg["phases_per_device"][0]
+        info = rcpp_api.device_info(device)
+        np_ = (n + 255) // 256 * 256
+        Lp0 = (ph["markers"] + 255) // 256 * 256
+        roof = None
+        if args.mode == "i8" and ph["vara_ms"] > 0:
+            # the digit count is chosen inside the library from the error bound (4 at this shape); the line states the assumption
+            S_used = args.slices or 4
+            ops = sum(2.0 * Lp0 * 256 * min((ct + 1) * 256, np_) for ct in range(np_ // 256)) * S_used
+            roof = {"bound": "mfma", "kernel": "k_vara_i8p on the lead device's shard (%d markers), HIP events inside the library "
+                                               "(eagle_last_scan_timing.vara_ms), %d digit slices assumed" % (ph["markers"], S_used),
+                    "achieved": ops / (ph["vara_ms"] / 1e3) / 1e12, "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s",
+                    "frac": ops / (ph["vara_ms"] / 1e3) / 1e12 / I8_MFMA_PEAK_TOPS, "kernel_ms": ph["vara_ms"], "traffic": None}
+        distinct = len(set(devs)) == len(devs)
+        out = {
+            "metric": "markers/sec in calculate_a_and_vara scan (+ MMt build wall-clock: mmt_build_s)", "value": leg["markers_per_s"], "unit": "markers/s",
+            "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": leg["ms_per_call"], "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64" if args.mode == "f64" else "i8 (int32/int64 exact sums, f64 finish, fp64 re-evaluation of uncertified markers)",
+            "data": "synthetic", "form": "abi",
+            "config": {"workload": "BASELINE configs[2] / north_star: synthetic %d individuals x %d SNPs through the REFERENCE-SHAPED C ABI "
+                                   "(eagle_calculate_a_and_vara + eagle_last_scan_argmax per step: host S, V, a_hat in over PCIe, host a, vara out), "
+                                   "genotypes resident in HBM after the first call, %d device(s) behind one context" % (n, L, N),
+                       "n": n, "markers_total": L, "devices": devs,
+                       "parallelism": "eagle_open_devices x%d: worker thread + stream per device" % N,
+                       "collectives": ("none (one device)" if N == 1 else
+                                       ("RCCL inside the library: ncclReduce (MM^T tiles), ncclAllGather (rows of W)" if distinct and os.environ.get("EAGLE_HIP_COLLECTIVES") != "host"
+                                        else "host-staged stand-in (the list names one card more than once, or EAGLE_HIP_COLLECTIVES=host): REHEARSAL, not a measurement")),
+                       "scan_mode": args.mode},
+            "includes_pcie": True,
+            "mmt_build_s": part["calculateMMt_s"]["warm (genotypes resident; 8 n^2 bytes back)"],
+            "calculateMMt_s": part["calculateMMt_s"], "calculate_a_and_vara_s": leg["calculate_a_and_vara_s"],
+            "selected_marker": leg["selected_marker"], "tsqmax": leg["tsqmax"],
+            "selected_marker_is_first_argmax_of_returned_arrays": leg["selected_marker_is_first_argmax_of_returned_arrays"],
+            "phases_per_device": leg["phases_per_device"], "s_cache (hits, misses)": leg["s_cache (hits, misses)"],
+            "roofline": roof, "cpu_baseline": None, "device": info, "kernel_sha16": kernel_sha16(),
+            "setup_s": {"genotypes + sidecars": t_gen, "operands": t_ops},
+        }
+        print(json.dumps(out))
+    finally:
+        for f in os.listdir(tmp):
+            os.unlink(os.path.join(tmp, f))
+        os.rmdir(tmp)
+        rcpp_api.close_all()
+    return 0
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -260,7 +415,71 @@ def main():
     ap.add_argument("--simple-operands", action="store_true", help="seeded random SPD S / V instead of the model algebra")
     ap.add_argument("--save-operands", default=None, help="write S, V, a_hat (torch.save) after computing them")
     ap.add_argument("--load-operands", default=None, help="read S, V, a_hat written by --save-operands (used by the PMC passes of\n                    tools/profile_gpu.sh: rocSOLVER's eigh crashes under rocprofv3 counter collection)")
-    args = ap.parse_args()
+    ap.add_argument("--form", choices=["ranks", "abi"], default="ranks",
+                    help="ranks (default): one process per GPU over torch.distributed / RCCL, device-resident entry points; "
+                         "abi: ONE process, the N GPUs behind the reference-shaped C ABI (eagle_open_devices), host files -> host results: "
+                         "the path the R package takes (E/R/AM.R:185-196,214,450-455)")
+    ap.add_argument("--abi-devices", default=os.environ.get("EAGLE_BENCH_ABI_DEVICES"),
+                    help="--form abi: comma-separated device list instead of 0..N-1 (naming one card twice rehearses the path on a one-GPU box)")
+    ap.add_argument("--dry-run", action="store_true", help="print what would be launched (the child command for N > 1) as JSON and exit")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def child_command(args, argv):
+    """`python -m torch.distributed.run ... bench.py <the same arguments>`: one rank per GPU, rendezvous on 127.0.0.1."""
+    port = int(os.environ.get("EAGLE_BENCH_MASTER_PORT", 0)) or _free_port()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + [a for a in argv if a != "--dry-run"]
+
+
+def self_spawn(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process (torch.distributed.run) before anything in
+    this process has touched the GPU (torch.cuda.device_count() does not initialise it), relay its output and exit with its code.
+    Never an exec: a process that has initialised the GPU must not be replaced."""
+    import subprocess
+    cmd = child_command(args, argv)
+    backend = os.environ.get("EAGLE_BENCH_BACKEND", "nccl")
+    if args.dry_run:
+        print(json.dumps({"dry_run": True, "launcher": "self-spawn", "n_gpus": args.gpus, "backend": backend, "child_command": cmd}))
+        return 0
+    import torch
+    have = torch.cuda.device_count()
+    if backend != "gloo" and args.gpus > have:
+        print("bench.py: --gpus %d but this node shows %d GPU(s); nothing was launched" % (args.gpus, have), file=sys.stderr)
+        return 3
+    if have == 0:
+        print("bench.py: no GPU visible; nothing was launched", file=sys.stderr)
+        return 3
+    env = dict(os.environ)
+    env["EAGLE_BENCH_SPAWNED"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    sys.stdout.flush()
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        sys.exit(2)
+    if args.form == "abi":
+        sys.exit(main_abi(args))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_spawn(args, argv))
+    if args.dry_run:
+        print(json.dumps({"dry_run": True, "launcher": "external" if "WORLD_SIZE" in os.environ else "none (single process)", "n_gpus": args.gpus}))
+        sys.exit(0)
 
     import torch
     import torch.distributed as dist
@@ -270,11 +489,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world), file=sys.stderr)
+            print("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
     # EAGLE_BENCH_BACKEND=gloo rehearses the N > 1 rank logic with several ranks on ONE card (collectives through the
     # host); the measured configuration is always one rank per GPU over RCCL.
     backend = os.environ.get("EAGLE_BENCH_BACKEND", "nccl")
+    if backend != "gloo" and local_rank >= torch.cuda.device_count():
+        print("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()), file=sys.stderr)
+        sys.exit(3)
     if backend == "gloo":
         local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
@@ -285,7 +507,7 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from eagleeverything_amd import rcpp_api
-    from eagleeverything_amd.sharded import Collectives
+    from eagleeverything_amd.sharded import Collectives, shard_range
 
     coll = Collectives(dist if world > 1 else None)
     info = rcpp_api.device_info(local_rank)
@@ -300,6 +522,7 @@ def main():
     t_ops = run.make_operands(MMt)
     del MMt
     w_choice = run.choose_w_sharing()
+    sh_share_w = bool(sh.share_w)
     sel, elapsed, parts = run.timed(args.steps, args.warmup)
     ms_per_step = elapsed / args.steps * 1e3
     value = Ltot * args.steps / elapsed
@@ -404,6 +627,31 @@ def main():
     # ---- secondary entries (N = 1): fp64-mode and 7-digit scans of the headline shape, and BASELINE configs[1] --------
     if world == 1 and not args.no_secondary and sh.mode == 1:
         sel_i8 = sel
+        # the same step through the REFERENCE-SHAPED entry points (host files -> host results; what R's .Call sees), PCIe included,
+        # with the phase clock of the library: every ms between the device-resident step above and the .Call-shaped time
+        import tempfile
+        from eagleeverything_amd import synth
+        tmpd = tempfile.mkdtemp(dir=os.environ.get("TMPDIR", "/tmp"))
+        try:
+            geno = synth.write_geno_pair_sidecars(tmpd, sh)
+            S_h, V_h, a_h = np.asfortranarray(run.S.cpu().numpy()), np.asfortranarray(run.V.cpu().numpy()), run.ahat.cpu().numpy()
+            leg, _ = abi_leg(args, torch, geno, n, Ltot, S_h, V_h, a_h, local_rank, 3, 1)
+            a_e, v_e = leg.pop("results")
+            leg["a_bitwise_equal_to_device_resident_step"] = bool(np.array_equal(a_e, sh.a[:Ltot].cpu().numpy()))
+            leg["vara_bitwise_equal_to_device_resident_step"] = bool(np.array_equal(v_e, sh.vara[:Ltot].cpu().numpy()))
+            leg["selected_marker_equal"] = bool(leg["selected_marker"] == sel_i8[0])
+            leg["device_resident_step_ms"] = ms_per_step
+            leg["gap_ms (call - device-resident step)"] = leg["ms_per_call"] - ms_per_step
+            leg["note"] = ("PCIe-inclusive and never `value`: per call V (8 n^2 bytes) up, S up and compared with the device copy of the last call "
+                           "under the n^3 products, a_hat up, a and vara (16 bytes per marker) down; genotypes resident after the cold call "
+                           "(loaded from the 2-bit sidecars beside sparse text placeholders)")
+            secondary["e2e_reference_shaped"] = leg
+            del S_h, V_h, a_e, v_e
+        finally:
+            for f in os.listdir(tmpd):
+                os.unlink(os.path.join(tmpd, f))
+            os.rmdir(tmpd)
+            rcpp_api.drop_cache(local_rank)
         sh.mode = 0
         s64, el64, p64 = run.timed(1, 1)
         secondary["scan_fp64_mode"] = {"value": Ltot / el64, "unit": "markers/s", "ms_per_step": el64 * 1e3,
@@ -526,6 +774,11 @@ def main():
                        "scan_mode": args.mode, "slices": S_used, "vara_abs_error_bound_worst_case": vara_bound,
                        "certificate": cert,
                        "operands": "simple" if args.simple_operands else "model algebra on MM^T" + (" (reloaded)" if args.load_operands else "")},
+            "rccl_ranks": dist.get_world_size() if world > 1 and backend == "nccl" else 0,   # ranks in the RCCL process group (0: none was made)
+            "collective_backend": ("nccl (RCCL)" if backend == "nccl" else backend) if world > 1 else "none (one rank: no collective is issued)",
+            "launcher": "self-spawned child torch.distributed.run" if os.environ.get("EAGLE_BENCH_SPAWNED") else ("external launcher" if world > 1 else "single process"),
+            "markers_per_rank": [shard_range(Ltot, r, world)[1] - shard_range(Ltot, r, world)[0] for r in range(world)],
+            "w_sharing": ("rows 1/%d per rank + one all-gather" % world if world > 1 and sh_share_w else ("replicated on every rank" if world > 1 else "n/a (one rank)")),
             "mmt_build_s": mmt_build_s, "selected_marker": int(sel[0]), "tsqmax": sel[1],
             "roofline": roof, "roofline_secondary": secondary, "cpu_baseline": cpu, "parity": parity,
             "device": info, "kernel_sha16": sha, "setup_s": {"genotypes": t_gen, "operands": t_ops},

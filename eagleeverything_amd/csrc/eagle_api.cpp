@@ -100,7 +100,7 @@ extern "C" eagle_ctx* eagle_open(int device) {
     snprintf(ctx->arch, sizeof ctx->arch, "%s", prop.gcnArchName);
     ctx->cu_count = prop.multiProcessorCount;
     ctx->hbm_bytes = (int64_t)prop.totalGlobalMem;
-    if ((e = hipMalloc(&ctx->d_scratch, 4096)) != hipSuccess) {
+    if ((e = hipMalloc(&ctx->d_scratch, EAGLE_SCR_BYTES)) != hipSuccess) {
         snprintf(g_open_err, sizeof g_open_err, "hipMalloc: %s", hipGetErrorString(e));
         delete ctx;
         return nullptr;
@@ -209,14 +209,6 @@ extern "C" int eagle_device_count(eagle_ctx* ctx) { return ctx ? 1 + (int)ctx->p
 
 static inline int ndev_of(eagle_ctx* ctx) { return 1 + (int)ctx->peers.size(); }
 static inline eagle_ctx* dev_ctx(eagle_ctx* ctx, int k) { return k == 0 ? ctx : ctx->peers[k - 1]; }
-// Contiguous marker ranges, one per device; boundaries at multiples of 256 (kernel tiles, and so that the lead's range is a
-// prefix view of a whole-file image the converters may have left resident).
-static void split_markers(long L, int ndev, std::vector<long>& edge) {
-    edge.assign(ndev + 1, 0);
-    const long tiles = (L + 255) / 256;
-    for (int k = 1; k < ndev; k++) edge[k] = std::min(L, (tiles * k / ndev) * 256);
-    edge[ndev] = L;
-}
 // fn(k, ctx_k) on every device: the lead's share on the calling thread (the only one that may send messages to R), one
 // worker thread per further device; all joined before return.  First hard error wins, then the soft sentinel.
 template <class F> static int run_on_devices(eagle_ctx* ctx, F fn) {
@@ -328,15 +320,8 @@ extern "C" int eagle_set_scan_slices(eagle_ctx* ctx, int nslices) {
 // masking fires iff element 0 is not NA.  NA arrives as NaN.
 // ------------------------------------------------------------------------------------------------
 static int parse_selected(eagle_ctx* ctx, const double* sel, long nsel, long bound, std::vector<long>& out) {
-    out.clear();
-    if (nsel <= 0 || !sel || isnan(sel[0])) return EAGLE_OK;
-    for (long i = 0; i < nsel; i++) {
-        if (isnan(sel[i])) return eagle_fail(ctx, EAGLE_ERR_ARG, "NA in selected_loci after element 0");
-        long v = (long)sel[i];
-        if (v < 0 || v >= bound) return eagle_fail(ctx, EAGLE_ERR_ARG, "selected_loci index out of range");
-        out.push_back(v);
-    }
-    return EAGLE_OK;
+    const char* msg = parse_selected_core(sel, nsel, bound, out);  // eagle_host.h
+    return msg ? eagle_fail(ctx, EAGLE_ERR_ARG, msg) : EAGLE_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -464,7 +449,7 @@ static int load_tile_fixed(eagle_ctx* ctx, FileInfo& fi, long row0, long nrows, 
     uint8_t* raw[2] = {(uint8_t*)ctx->stage_raw[0], (uint8_t*)ctx->stage_raw[1]};
     // the bad-character counter lives in the ctx scratch page: a hipMalloc / hipFree per tile would synchronise the device,
     // i.e. wait for the kernels of the previous chunk when the tile is a chunk of a streamed file
-    int* const bad = (int*)((char*)ctx->d_scratch + 1024);
+    int* const bad = (int*)((char*)ctx->d_scratch + EAGLE_SCR_LOADER_BAD);
     hipEvent_t done[2] = {nullptr, nullptr};
     HIPCHK(ctx, hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
     for (int b = 0; b < 2; b++) HIPCHK(ctx, hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
@@ -526,7 +511,7 @@ static int load_tile_sidecar(eagle_ctx* ctx, const char* path, const FileInfo& f
     long chunk_rows = std::max(1L, std::min(nrows, (long)(67108864 / stride)));
     int rc = eagle_stage_ensure(ctx, (size_t)chunk_rows * stride);
     if (rc) return rc;
-    int* const bad = (int*)((char*)ctx->d_scratch + 1024);  // (see load_tile_fixed)
+    int* const bad = (int*)((char*)ctx->d_scratch + EAGLE_SCR_LOADER_BAD);  // (see load_tile_fixed)
     HIPCHK(ctx, hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
     hipEvent_t done[2] = {nullptr, nullptr};
     for (int b = 0; b < 2; b++) HIPCHK(ctx, hipEventCreateWithFlags(&done[b], hipEventDisableTiming));
@@ -742,11 +727,7 @@ size_t eagle_resident_budget() { return resident_budget(); }
 
 // Rows (multiple of 256) of a streamed chunk whose padded row length is `row_bytes`.
 static long stream_chunk_rows(long row_bytes, long total_rows_pad) {
-    size_t budget = resident_budget();
-    if (budget == (size_t)-1) budget = (size_t)8 << 30;  // 8 GiB chunks when streaming because HBM is full
-    long rows = (long)(budget / 2 / (size_t)row_bytes) / 256 * 256;  // two chunk buffers share the budget
-    if (rows < 256) rows = 256;
-    return rows < total_rows_pad ? rows : total_rows_pad;
+    return stream_chunk_rows_core(resident_budget(), row_bytes, total_rows_pad);  // eagle_host.h
 }
 
 // Out-of-core streaming: chunk k+1 is read (pread -> pinned -> H2D -> decode, all on ctx->load_stream) while the kernels
@@ -823,6 +804,28 @@ struct ChunkRing {
                     k, ctx->st_file_bytes / 1e9, ctx->st_pread_s, ctx->st_pread_s > 0 ? ctx->st_file_bytes / 1e9 / ctx->st_pread_s : 0.0,
                     ctx->st_load_wall_s, ctx->st_load_first_s, ctx->st_compute_s, ctx->st_starved_s,
                     later > 0 ? 100.0 * std::max(0.0, 1.0 - ctx->st_starved_s / later) : 100.0, ctx->st_total_s);
+        }
+    }
+};
+
+// Phase clock of one scan call: HIP events on the compute stream, read after the call's final synchronisation
+// (eagle_last_scan_timing).  The interval that ENDS at an event is booked under the event's tag.
+enum { PH_START = 0, PH_UPLOAD, PH_W, PH_LOADWAIT, PH_PREPARE, PH_VARA, PH_CERT, PH_D2H, PH_COUNT };
+struct PhaseEvents {
+    std::vector<hipEvent_t> ev;
+    std::vector<int> tag;
+    ~PhaseEvents() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
+    void mark(hipStream_t st, int t) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        if (hipEventRecord(e, st) != hipSuccess) { (void)hipEventDestroy(e); return; }
+        ev.push_back(e); tag.push_back(t);
+    }
+    void sum(double* ms) const {  // ms[PH_COUNT]; the stream has been synchronised
+        for (int i = 0; i < PH_COUNT; i++) ms[i] = 0.0;
+        for (size_t i = 1; i < ev.size(); i++) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, ev[i - 1], ev[i]) == hipSuccess) ms[tag[i]] += t;
         }
     }
 };
@@ -1089,11 +1092,12 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
     double *Sa = nullptr, *Va = nullptr, *tmp = nullptr, *Wu = nullptr, *ah = nullptr, *v = nullptr;
     bool s_from_cache = false;  // the product runs on the device copy of the last call's S; the caller's S is verified under it
     void *ws = nullptr, *cert = nullptr;
-    long* cert_totals = (long*)((char*)ctx->d_scratch + 256);  // {re-evaluated, flagged, fell back}, summed over marker blocks
+    long* cert_totals = (long*)((char*)ctx->d_scratch + EAGLE_SCR_CERT_TOTALS);  // {re-evaluated, flagged, fell back}, summed over marker blocks
     ChunkRing ring;
     int8_t* shifted[2] = {nullptr, nullptr};
     int8_t* cs[2] = {nullptr, nullptr};
     int32_t* l1s[2] = {nullptr, nullptr};
+    PhaseEvents ph;
     auto setup = [&]() -> int {
         int r = arena_reserve(ctx, 4 * arena_round(sq) + 2 * arena_round(sizeof(double) * np) + arena_round(wsb) + arena_round(certb) +
                                        (streamed ? (use_i8 ? 4 : 2) * arena_round((size_t)Lc * np) + 2 * arena_round((size_t)Lc) +
@@ -1107,6 +1111,7 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
         v = arena_take<double>(ctx, sizeof(double) * np);
         ws = arena_take<char>(ctx, wsb);
         cert = arena_take<char>(ctx, certb);
+        ph.mark(ctx->stream, PH_START);
         if (streamed) {
             if ((r = ring.init(ctx))) return r;
             ring.buf[0] = arena_take<int8_t>(ctx, (size_t)Lc * np);
@@ -1144,9 +1149,11 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
         }
         if ((r = ensure_scan_out(ctx, Lp))) return r;
         HIPCHK(ctx, hipMemsetAsync(cert_totals, 0, 3 * sizeof(long), ctx->stream));
+        ph.mark(ctx->stream, PH_UPLOAD);
         return EAGLE_OK;
     };
     if (!rc) rc = setup();
+    const double t_setup = now_s();
     double t1 = 0;
     if (timing_on() && !rc) { (void)hipStreamSynchronize(ctx->stream); t1 = now_s(); }
     // W = S (V S) and v = S a_hat.  Several devices: each computes 1/nd of the rows of W's image and ONE all-gather completes
@@ -1163,7 +1170,7 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
         rc = w_direct ? eagle_dev_fold_upper(ctx, Wu, np, ctx->stream) : eagle_dev_scan_operands(ctx, Sa, Va, ah, n, np, v, Wu, tmp, ctx->stream);
         if (!rc && s_from_cache) {
             // under the product: the caller's S to the scratch copy (loader stream), compared with the cached one
-            int* flag = (int*)((char*)ctx->d_scratch + 2048);
+            int* flag = (int*)((char*)ctx->d_scratch + EAGLE_SCR_SCACHE_FLAG);
             int differ = 0;
             e = hipMemsetAsync(flag, 0, sizeof(int), ctx->load_stream);
             if (e == hipSuccess) rc = upload_square_on(ctx, inv_MMt_sqrt, n, np, ctx->d_Sscr, ctx->load_stream);
@@ -1183,6 +1190,7 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
             } else if (!rc) ctx->scache_hits++;
         }
     }
+    if (!rc) ph.mark(ctx->stream, PH_W);
     if (!rc && streamed && !quiet) say(ctx, " Mt.ascii streamed through HBM in blocks of %ld markers", Lc);
     // one pass per marker block: the whole shard when it is resident, else chunks read back from the file
     for (long r0 = 0; r0 < Lr && !rc; r0 += Lc) {
@@ -1194,6 +1202,7 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
             rc = ring.load(ctx, f_name_ascii, m0 + r0, nr, 0, n, np, (size_t)nrp * np, max_memory_in_Gbytes, host_threads(), &tile);
             if (rc) break;
             Mt8 = tile;
+            ph.mark(ctx->stream, PH_LOADWAIT);
         }
         if (use_i8) {
             // re-centred image of the markers (kept with a resident file, rebuilt per chunk when streaming)
@@ -1225,8 +1234,10 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
             // one pass over the genotypes gives a = Mt v and the diagonal term of vara; then the int8 MFMA kernel
             rc = eagle_dev_vara_i8_prepare(ctx, Mt8, nrp, np, ldm, Wu, nslices, ws, v, ctx->d_a + r0, ctx->stream);
             if (rc) break;
+            ph.mark(ctx->stream, PH_PREPARE);
             rc = eagle_dev_vara_i8_mfma_shifted(ctx, Ms, cv, nrp, np, ldm, nslices, ws, ctx->d_vara + r0, nullptr, ctx->stream);
             if (rc) break;
+            ph.mark(ctx->stream, PH_VARA);
             // a-posteriori certificate: markers the digit bounds cannot settle are re-evaluated by the fp64 kernel, so that
             // which(tsq == max(tsq))[1] on the returned arrays is the marker the fp64 scan selects (find_qtl.R:71-83).  A
             // streamed file is certified block by block against the block's own maximum (a superset of the global candidates);
@@ -1241,9 +1252,12 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
         } else {
             rc = eagle_dev_gemv_i8(ctx, Mt8, nrp, np, ldm, v, 1.0, ctx->d_a + r0, ctx->stream);
             if (rc) break;
+            ph.mark(ctx->stream, PH_PREPARE);
             rc = eagle_dev_vara_f64(ctx, Mt8, nrp, np, ldm, Wu, ctx->d_vara + r0, ctx->stream);
+            if (!rc) ph.mark(ctx->stream, PH_VARA);
         }
         if (rc) break;
+        if (use_i8) ph.mark(ctx->stream, PH_CERT);
         if (streamed && (rc = ring.computed(ctx))) break;
     }
     if (streamed && !rc) ring.finish(ctx);
@@ -1259,6 +1273,7 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
             rc = eagle_dev_scan_certify_apply(ctx, g->dev, Lr, Lp, np, g->ld, g->cshift, g->l1, nslices, ws, Wu, ctx->d_a, ctx->d_vara, cert,
                                               rv->vmax, ctx->stream);
             if (!rc) rc = eagle_dev_cert_accumulate(ctx, cert, cert_totals, ctx->stream);
+            if (!rc) ph.mark(ctx->stream, PH_CERT);
         }
     }
 #undef EAGLE_ARRIVE
@@ -1284,8 +1299,13 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
         HIPCHK(ctx, hipMemcpyAsync(vara_out + m0, ctx->d_vara, sizeof(double) * (size_t)Lr, hipMemcpyDeviceToHost, ctx->stream));
     }
     HIPCHK(ctx, hipMemcpyAsync(totals, cert_totals, sizeof totals, hipMemcpyDeviceToHost, ctx->stream));
+    ph.mark(ctx->stream, PH_D2H);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cert_reevaluated = totals[0]; ctx->cert_flagged = totals[1]; ctx->cert_fell_back = totals[2] != 0;
+    ph.sum(ctx->scan_phase_ms);
+    ctx->scan_blocks = streamed ? ring.k : 1;
+    ctx->scan_host_setup_s = t_setup - t0;
+    ctx->scan_range_wall_s = now_s() - t0;
     return EAGLE_OK;
 }
 
@@ -1322,10 +1342,12 @@ extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_asc
     Rendezvous rv;
     rv.n = nd;
     RcclState* rccl = (RcclState*)ctx->rccl;
+    const double t_call = now_s();
     rc = run_on_devices(ctx, [&](int k, eagle_ctx* c) -> int {
         return scan_range(c, f_name_ascii, L, n, edge[k], edge[k + 1], sel, inv_MMt_sqrt, dim_reduced_vara, a, max_memory_in_Gbytes, quiet,
                           a_out, vara_out, k, nd, nd > 1 || rccl ? &rv : nullptr, rccl);
     });
+    ctx->scan_call_wall_s = now_s() - t_call;
     if (rc) return rc;
     for (eagle_ctx* p : ctx->peers) {
         ctx->cert_reevaluated += p->cert_reevaluated; ctx->cert_flagged += p->cert_flagged; ctx->cert_fell_back |= p->cert_fell_back;
@@ -1377,6 +1399,25 @@ extern "C" int eagle_last_stream_stats(eagle_ctx* ctx, eagle_stream_stats* out) 
     out->pread_s = ctx->st_pread_s; out->load_s = ctx->st_load_wall_s; out->wait_s = ctx->st_wait_s;
     out->kernel_s = ctx->st_compute_s; out->wall_s = ctx->st_total_s;
     out->load_first_s = ctx->st_load_first_s; out->starved_s = ctx->st_starved_s;
+    return EAGLE_OK;
+}
+// Where the last eagle_calculate_a_and_vara / eagle_scan_with_W call spent its time on device `device_index` of the context
+// (0 = the lead): host seconds until the operand uploads were enqueued, then the phases on that device's compute stream.
+extern "C" int eagle_last_scan_timing(eagle_ctx* ctx, int device_index, eagle_scan_timing* out) {
+    if (!ctx || !out || device_index < 0 || device_index >= ndev_of(ctx)) return EAGLE_ERR_ARG;
+    const eagle_ctx* c = dev_ctx(ctx, device_index);
+    out->call_wall_s = ctx->scan_call_wall_s;
+    out->device_wall_s = c->scan_range_wall_s;
+    out->host_setup_s = c->scan_host_setup_s;
+    out->upload_ms = c->scan_phase_ms[PH_UPLOAD];
+    out->w_ms = c->scan_phase_ms[PH_W];
+    out->load_wait_ms = c->scan_phase_ms[PH_LOADWAIT];
+    out->prepare_ms = c->scan_phase_ms[PH_PREPARE];
+    out->vara_ms = c->scan_phase_ms[PH_VARA];
+    out->certify_ms = c->scan_phase_ms[PH_CERT];
+    out->d2h_ms = c->scan_phase_ms[PH_D2H];
+    out->blocks = c->scan_blocks;
+    out->markers = c->scan_L;
     return EAGLE_OK;
 }
 extern "C" int eagle_last_scan_certificate(eagle_ctx* ctx, long* n_reevaluated, long* n_flagged, int* fell_back) {

@@ -17,6 +17,7 @@
 
 #include "../../include/eagle_hip.h"
 #include "eagle_internal.h"
+#include "eagle_host.h"
 
 struct GenoEntry {
     std::string path;
@@ -29,31 +30,6 @@ struct GenoEntry {
     int8_t* dev_s = nullptr;    // re-centred image m - c_i (eagle_dev_marker_shift), made on the first digit-slice scan of the file
     int8_t* cshift = nullptr;   // c_i per row
     int32_t* l1 = nullptr;      // {sum_j |m_ij - c_i|, sum_j (m_ij - c_i)^2} per row (error bounds of the digit-slice scan)
-};
-
-// Meeting point of the per-device worker threads of one multi-device call.  arrive(ok, v) blocks until every device has
-// arrived, returns false if any of them reported a failure (then nobody enters the collective that follows), and leaves the
-// largest v of this round in `vmax`.  Every worker calls it the same number of times, failed or not.
-struct Rendezvous {
-    std::mutex mu;
-    std::condition_variable cv;
-    int n = 1, waiting = 0;
-    long gen = 0;
-    bool failed = false;
-    double acc = -1.0 / 0.0, vmax = -1.0 / 0.0;
-    bool arrive(bool ok, double v = -1.0 / 0.0) {
-        std::unique_lock<std::mutex> lk(mu);
-        if (!ok) failed = true;
-        if (v == v && v > acc) acc = v;
-        const long g = gen;
-        if (++waiting == n) {
-            waiting = 0; vmax = acc; acc = -1.0 / 0.0; gen++;
-            cv.notify_all();
-        } else {
-            cv.wait(lk, [&] { return gen != g; });
-        }
-        return !failed;
-    }
 };
 
 struct eagle_ctx {
@@ -81,6 +57,8 @@ struct eagle_ctx {
     double* d_mmt = nullptr; long mmt_n = 0; double* d_mmt_max = nullptr;
     double* d_a = nullptr; double* d_vara = nullptr; long scan_L = 0; long scan_cap = 0;
     long cert_reevaluated = 0, cert_flagged = 0; int cert_fell_back = 0;  // certification counters of the last digit-slice scan
+    double scan_phase_ms[8] = {0}; long scan_blocks = 0;                  // phase clock of the last scan on this device (eagle_last_scan_timing)
+    double scan_host_setup_s = 0, scan_range_wall_s = 0, scan_call_wall_s = 0;
     // S = inv_MMt_sqrt of the last scan, kept on the device: MMt^-1/2 is the same matrix in every find_qtl call of an AM() run
     // (scan_range: the next call computes on this copy while the caller's matrix is uploaded and compared under the product)
     double* d_Scache = nullptr; double* d_Sscr = nullptr; long scache_n = 0, scache_np = 0; long scache_hits = 0, scache_misses = 0;

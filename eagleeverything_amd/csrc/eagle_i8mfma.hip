@@ -695,20 +695,7 @@ __device__ __forceinline__ void tw_kstep(i32x16 (&acc)[3][4], const int8_t* pa, 
 #pragma unroll
         for (int n = 0; n < 4; n++) acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b[n], acc[m][n], 0, 0, 0);
 }
-// Pieces per worker of an XCD's last, partly filled round of `tail` workers on 32 CUs (0 < tail < 32): the workers are cut along
-// their column-tile pairs into p equal pieces, the tail * p pieces run in ceil(tail * p / 32) rounds of 1/p worker-time each; p <=
-// min(npair, VARA_TAIL_PMAX) minimising that cost (p = 1: one whole worker-time for a round that may be 1/32 full; large p: tail/32).
-#define VARA_TAIL_PMAX 16
-__host__ __device__ static inline int vara_tail_pieces(int tail, int npair) {
-    if (tail <= 0) return 1;
-    int best = 1, bn = 1, bd = 1;  // cost bn / bd
-    const int pmax = npair < VARA_TAIL_PMAX ? npair : VARA_TAIL_PMAX;
-    for (int p = 2; p <= pmax; p++) {
-        const int rounds = (tail * p + 31) >> 5;
-        if (rounds * bd < bn * p) { best = p; bn = rounds; bd = p; }
-    }
-    return best;
-}
+// vara_tail_pieces (pieces per worker of an XCD's last, partly filled round): eagle_host.h
 // `groups` row groups (8 rows each) of an operand tile per wave: wave w issues groups w*groups .. (groups is even)
 template <int GROUPS>
 __device__ __forceinline__ void tw_stage(__amdgpu_buffer_rsrc_t rs, const T8Lane& ln, int ld, int k0, int8_t* ldsTile, int w) {

@@ -58,66 +58,8 @@ bool map_file(const char* path, MappedFile& m) {
     return true;
 }
 
-void parallel_for(long n, int threads, const std::function<void(long, long, int)>& fn) {
-    if (n <= 0) return;
-    if (threads <= 1 || n < 2 * threads) { fn(0, n, 0); return; }
-    std::vector<std::thread> pool;
-    const long per = (n + threads - 1) / threads;
-    for (int t = 0; t < threads; t++) {
-        const long a = t * per, b = std::min(n, a + per);
-        if (a >= b) break;
-        pool.emplace_back(fn, a, b, t);
-    }
-    for (auto& th : pool) th.join();
-}
-
-// getline() semantics: lines end at '\n'; a non-empty tail without '\n' is a line too.  starts has nlines+1 entries,
-// line i is [starts[i], starts[i+1] - 1) except for an unterminated last line, whose end is the file size (`tail`).
-struct LineIndex {
-    std::vector<size_t> starts;
-    bool tail = false;
-    size_t size = 0;
-    long nlines() const { return (long)starts.size() - 1; }
-    size_t begin(long i) const { return starts[i]; }
-    size_t end(long i) const { return (tail && i == nlines() - 1) ? size : starts[i + 1] - 1; }
-};
-
-void index_lines(const MappedFile& m, int threads, LineIndex& ix) {
-    ix.size = m.size;
-    std::vector<std::vector<size_t>> part((size_t)std::max(1, threads));
-    parallel_for((long)m.size, threads, [&](long a, long b, int t) {
-        auto& v = part[(size_t)t];
-        const char* p = m.p + a;
-        const char* e = m.p + b;
-        while (p < e) {
-            const char* q = (const char*)memchr(p, '\n', (size_t)(e - p));
-            if (!q) break;
-            v.push_back((size_t)(q - m.p) + 1);
-            p = q + 1;
-        }
-    });
-    ix.starts.clear();
-    ix.starts.push_back(0);
-    for (auto& v : part) ix.starts.insert(ix.starts.end(), v.begin(), v.end());
-    if (ix.starts.back() < m.size) { ix.starts.push_back(m.size + 1); ix.tail = true; }
-    if (m.size == 0) ix.starts.assign(1, 0);
-}
-
-inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }
-inline const char* next_token(const char* p, const char* end, const char** tok, long* len) {
-    while (p < end && is_ws(*p)) p++;
-    if (p >= end) return nullptr;
-    *tok = p;
-    while (p < end && !is_ws(*p)) p++;
-    *len = p - *tok;
-    return p;
-}
-long count_tokens(const char* p, const char* end) {
-    const char* tok;
-    long len, n = 0;
-    while ((p = next_token(p, end, &tok, &len)) != nullptr) n++;
-    return n;
-}
+// parallel_for, LineIndex, index_lines_buf, next_token, count_tokens: eagle_host.h (HIP-free, built under the CPU sanitizers)
+void index_lines(const MappedFile& m, int threads, LineIndex& ix) { index_lines_buf(m.p, m.size, threads, ix); }
 
 bool pwrite_all(int fd, const char* src, size_t bytes, off_t off, int threads) {
     std::atomic<bool> ok{true};
@@ -393,7 +335,7 @@ static int create_M_plink(eagle_ctx* ctx, const char* fname, const char* asciifn
     HIPCHK(ctx, hipMemsetAsync(image.p, 0, (size_t)img_rows * ld, ctx->stream));
     HIPCHK(ctx, alleles.alloc((size_t)2 * L));
     HIPCHK(ctx, hipMemsetAsync(alleles.p, 0, (size_t)2 * L, ctx->stream));
-    unsigned long long* flags = (unsigned long long*)((char*)eagle_ctx_scratch(ctx) + 512);   // [0] first third-allele, [1] first missing
+    unsigned long long* flags = (unsigned long long*)((char*)eagle_ctx_scratch(ctx) + EAGLE_SCR_INGEST);   // [0] first third-allele, [1] first missing
     HIPCHK(ctx, hipMemsetAsync(flags, 0xff, 2 * sizeof(unsigned long long), ctx->stream));
 
     SidecarWriter sc;

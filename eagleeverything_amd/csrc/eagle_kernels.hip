@@ -959,7 +959,7 @@ extern "C" int eagle_dev_scan_operands(eagle_ctx* ctx, const double* Sa, const d
     hipLaunchKernelGGL(k_colgemv_sum, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, s, tmp, n_pad, 8, v_out);
     LAUNCH_CHECK(ctx);
     // symmetric operands (every Eagle run): W = S V S is symmetric and only its upper 128-tiles are computed
-    int* sym = (int*)eagle_ctx_scratch(ctx);
+    int* sym = (int*)((char*)eagle_ctx_scratch(ctx) + EAGLE_SCR_SYM);
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, sym, 1);
     dim3 g32((unsigned)(n_pad / 32), (unsigned)(n_pad / 32));
     hipLaunchKernelGGL(k_sym_check, g32, dim3(256), 0, s, Sa, Va, n_pad, sym);
@@ -997,7 +997,7 @@ extern "C" int eagle_dev_scan_operands_rows(eagle_ctx* ctx, const double* Sa, co
 // In-place fold of a COMPLETE W image: Wu[j][k] = W[j][k] + W[k][j] (j<k), W[k][k], 0 below.
 extern "C" int eagle_dev_fold_upper(eagle_ctx* ctx, double* W, long n_pad, void* stream) {
     if (n_pad % 32) return eagle_fail(ctx, EAGLE_ERR_ARG, "fold_upper: bad padding");
-    int* sym = (int*)eagle_ctx_scratch(ctx);
+    int* sym = (int*)((char*)eagle_ctx_scratch(ctx) + EAGLE_SCR_SYM);
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, (hipStream_t)stream, sym, 0);
     dim3 g32((unsigned)(n_pad / 32), (unsigned)(n_pad / 32));
     hipLaunchKernelGGL(k_fold_upper, g32, dim3(256), 0, (hipStream_t)stream, W, n_pad, sym);
@@ -1499,7 +1499,7 @@ extern "C" int eagle_dev_transpose_f64(eagle_ctx* ctx, const double* in, double*
     return EAGLE_OK;
 }
 extern "C" int eagle_dev_dot_matrices(eagle_ctx* ctx, const double* A, long lda, const double* B, long ldb, long n, double* out, void* stream) {
-    double* part = (double*)((char*)eagle_ctx_scratch(ctx) + 1024);  // 256 partial sums in the ctx scratch page
+    double* part = (double*)((char*)eagle_ctx_scratch(ctx) + EAGLE_SCR_DOT_PARTIALS);  // 256 partial sums, their own region of the ctx scratch
     hipLaunchKernelGGL(k_dot_rows, dim3(256), dim3(256), 0, (hipStream_t)stream, A, lda, B, ldb, n, part);
     hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(1), 0, (hipStream_t)stream, part, 256, out);
     LAUNCH_CHECK(ctx);

@@ -102,7 +102,8 @@ static int dev_syevd(eagle_ctx* ctx, double* A, long n, double* w, bool vectors)
     DevBuf E, info;
     HIPCHK(ctx, E.alloc(sizeof(double) * n));
     HIPCHK(ctx, info.alloc(sizeof(rocblas_int)));
-    if (g_api.dsyevd(h, vectors ? rocblas_evect_original : rocblas_evect_none, rocblas_fill_upper, (rocblas_int)n, A, (rocblas_int)n, w, E.as<double>(),
+    // the LOWER triangle of the column-major matrix is read, like R's eigen(symmetric = TRUE) and LAPACK 'L' (numpy.linalg.eigh)
+    if (g_api.dsyevd(h, vectors ? rocblas_evect_original : rocblas_evect_none, rocblas_fill_lower, (rocblas_int)n, A, (rocblas_int)n, w, E.as<double>(),
                      info.as<rocblas_int>()) != rocblas_status_success)
         return eagle_fail(ctx, EAGLE_ERR_HIP, "rocsolver_dsyevd failed");
     int hinfo = 0;
@@ -125,6 +126,8 @@ static int dev_chol2inv(eagle_ctx* ctx, double* A, long n) {
     if (hinfo != 0) { failf(ctx, EAGLE_SOFT_SENTINEL, "the leading minor of order %d is not positive", hinfo); return EAGLE_SOFT_SENTINEL; }
     if (g_api.dpotri(h, rocblas_fill_upper, (rocblas_int)n, A, (rocblas_int)n, info.as<rocblas_int>()) != rocblas_status_success)
         return eagle_fail(ctx, EAGLE_ERR_HIP, "rocsolver_dpotri failed");
+    if ((rc = info_of(ctx, info.as<rocblas_int>(), &hinfo))) return rc;
+    if (hinfo != 0) return failf(ctx, EAGLE_ERR_ARG, "dpotri: element (%d, %d) of the Cholesky factor is zero, the inverse could not be computed", hinfo, hinfo);
     return eagle_dev_symmetrize(ctx, A, n, n, ctx->stream);  // column-major "upper" = row-major lower: mirror it
 }
 
@@ -249,7 +252,7 @@ extern "C" int eagle_mmt_sqrt_and_sqrtinv(eagle_ctx* ctx, const double* MMt, lon
     if ((rc = dev_chol2inv(ctx, dU.as<double>(), n))) return rc;
     HIPCHK(ctx, hipMemcpyAsync(invsqrt_out, dU.p, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost, ctx->stream));
     if (trace_out) {  // tr(sqrt invsqrt) = sum_ij sqrt_ij invsqrt_ij (both symmetric), fixed-order reduction
-        double* d_tr = (double*)((char*)ctx->d_scratch + 512);
+        double* d_tr = (double*)((char*)ctx->d_scratch + EAGLE_SCR_INGEST);
         if ((rc = eagle_dev_dot_matrices(ctx, dS.as<double>(), N, dU.as<double>(), n, n, d_tr, ctx->stream))) return rc;
         HIPCHK(ctx, hipMemcpyAsync(trace_out, d_tr, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     }

@@ -268,6 +268,21 @@ def last_stream_stats(device=0):
     return d
 
 
+class _ScanTiming(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("call_wall_s", "device_wall_s", "host_setup_s", "upload_ms", "w_ms", "load_wait_ms", "prepare_ms",
+                                          "vara_ms", "certify_ms", "d2h_ms")] + [("blocks", C.c_long), ("markers", C.c_long)]
+
+
+def last_scan_timing(device=0, device_index=0):
+    """Phase clock of the last calculate_a_and_vara_rcpp / scan_with_W call on one device of the context (include/eagle_hip.h,
+    eagle_last_scan_timing)."""
+    L = _lib.load()
+    ctx = context(device)
+    st = _ScanTiming()
+    _check(ctx, L.eagle_last_scan_timing(ctx, int(device_index), C.byref(st)))
+    return {k: getattr(st, k) for k, _ in _ScanTiming._fields_}
+
+
 def scan_operand_cache_stats(device=0):
     """(hits, misses) of the device copy of S = inv_MMt_sqrt kept between calculate_a_and_vara_rcpp calls (include/eagle_hip.h)."""
     L = _lib.load()
@@ -321,7 +336,10 @@ def createMt_ASCII_rcpp(f_name, f_name_ascii, type, max_memory_in_Gbytes, dims, 
 def _square_any_order(A):
     """(buffer, transposed): a float64 n x n array usable as a column-major matrix without a copy when it is contiguous in
     either order -- a C-ordered buffer read column-major is the transpose, which the callers below undo for free
-    (symmetric input, or inv(A^T) = inv(A)^T).  A 200 MB layout change on one host core costs more than the device call."""
+    (symmetric input, or inv(A^T) = inv(A)^T).  A 200 MB layout change on one host core costs more than the device call.
+    Triangles: eagle_sym_eig reads the LOWER and eagle_chol2inv the UPPER triangle of the column-major matrix (as R's eigen() and
+    chol() do); a C-ordered array goes over as its transpose, so the OTHER triangle is read -- identical for an exactly symmetric
+    matrix, different at rounding level for one that is symmetric only to rounding (pass np.asfortranarray(A) to pin R's triangle)."""
     A = np.asarray(A, dtype=np.float64)
     if A.ndim != 2 or A.shape[0] != A.shape[1]:
         raise ValueError("square matrix expected")

@@ -189,10 +189,15 @@ int eagle_create_Mt_ascii(eagle_ctx* ctx, const char* f_name, const char* f_name
  *     factorisations are rocSOLVER library calls (dlopen()ed on first use), the products this library's fp64 MFMA GEMM.
  * ------------------------------------------------------------------------------------------- */
 /* eigen(A, symmetric = TRUE): values in DEcreasing order as R returns them, the matching eigenvectors in the columns of
- * vectors_out (NULL: only.values = TRUE).  Used by E/R/emma_eigen_L_wo_Z.R:3, emma_eigen_R_wo_Z.R:17, calculateMMt_sqrt_and_sqrtinv.R:25. */
+ * vectors_out (NULL: only.values = TRUE).  Used by E/R/emma_eigen_L_wo_Z.R:3, emma_eigen_R_wo_Z.R:17, calculateMMt_sqrt_and_sqrtinv.R:25.
+ * Only the LOWER triangle of the column-major matrix is read (as R's eigen(symmetric = TRUE) and LAPACK uplo 'L' do): for an input
+ * that is symmetric only to rounding, a row-major buffer handed over as its transpose has its UPPER triangle read instead and the
+ * result differs at rounding level.  Must not run under `rocprofv3 --pmc` (rocSOLVER aborts under counter collection,
+ * profiles/r02_eigh_under_pmc.log). */
 int eagle_sym_eig(eagle_ctx* ctx, const double* A, long n, double* values_out, double* vectors_out);
 /* chol2inv(chol(A)) (calculateMMt_sqrt_and_sqrtinv.R:30, calculateP.R:27, calculate_reduced_vara.R:27).  Returns
- * EAGLE_SOFT_SENTINEL when A is not positive definite (R's chol() error text in eagle_last_error). */
+ * EAGLE_SOFT_SENTINEL when A is not positive definite (R's chol() error text in eagle_last_error).  Only the UPPER triangle of
+ * the column-major matrix is read (as R's chol() does); a row-major buffer handed over as its transpose has its lower triangle read. */
 int eagle_chol2inv(eagle_ctx* ctx, const double* A, long n, double* Ainv_out);
 /* solve(A) (calculate_reduced_vara.R:31-33, calculateP.R:28).  EAGLE_SOFT_SENTINEL for a singular matrix. */
 int eagle_inverse(eagle_ctx* ctx, const double* A, long n, double* Ainv_out);
@@ -380,6 +385,26 @@ typedef struct eagle_stream_stats {
     double starved_s;    /* device seconds the compute stream sat idle between chunks because the next one was not loaded yet */
 } eagle_stream_stats;
 int eagle_last_stream_stats(eagle_ctx* ctx, eagle_stream_stats* out);
+/* Where the LAST eagle_calculate_a_and_vara / eagle_scan_with_W call spent its time on device `device_index` of the context
+ * (0 = the lead, which works on the calling thread): the accounting between the device-resident step bench.py times and what
+ * the .Call-shaped entry point costs (E/R/calculate_a_and_vara.R:20-31 is the caller).  The *_ms fields are HIP-event intervals
+ * on that device's compute stream, summed over the marker blocks of a streamed file. */
+typedef struct eagle_scan_timing {
+    double call_wall_s;   /* the whole call on the calling thread (argument checks, all devices, joins) */
+    double device_wall_s; /* this device's worker: resident lookup / file load, uploads, kernels, results back */
+    double host_setup_s;  /* of it: host seconds until the operand uploads were enqueued (resident lookup or file load, arena,
+                             staging of V, a_hat -- and S when it is not the cached one -- out of pageable memory) */
+    double upload_ms;     /* stream time from the first upload to the last (V, a_hat, S on a cache miss) */
+    double w_ms;          /* v = S a_hat, W = S (V S): symmetry check, two products, fold (+ all-gather of W's rows) */
+    double load_wait_ms;  /* streamed files: compute stream waiting for a marker block to be loaded */
+    double prepare_ms;    /* digits of W, rho, ONE genotype pass (a = Mt v, diagonal term of vara) */
+    double vara_ms;       /* the vara kernel (int8 digit slices + finish, or the fp64 kernel) */
+    double certify_ms;    /* error bounds, candidate selection, fp64 re-evaluation */
+    double d2h_ms;        /* row masking + a, vara back into the caller's arrays */
+    long blocks;          /* marker blocks (1 = resident) */
+    long markers;         /* markers of this device's shard */
+} eagle_scan_timing;
+int eagle_last_scan_timing(eagle_ctx* ctx, int device_index, eagle_scan_timing* out);
 /* eagle_calculate_a_and_vara keeps the last call's S = inv_MMt_sqrt on the device (MMt^-1/2 is the same matrix in every find_qtl
  * call of an AM() run; n_pad <= 16,384, 2 x 8 n_pad^2 bytes): the next call starts its n^3 products on that copy and meanwhile
  * uploads the caller's matrix and compares the two bit for bit; a difference starts the products over with the new matrix, so the

@@ -71,6 +71,8 @@ typedef double v4d __attribute__((vector_size(32), aligned(8)));
 #define EO_MC 96
 #define EO_NC 2048
 
+/* aligned_alloc wants a size that is a multiple of the alignment (C11 7.22.3.1; found by the ASan build) */
+static size_t eo_round64(size_t b) { return (b + 63) / 64 * 64; }
 static void eo_pack_b(long kc, long nc, const double* B, long rsb, long csb, double* Bp) {
     /* Bp: panels of EO_NR columns, each panel kc x EO_NR row-major, zero padded */
     for (long j0 = 0; j0 < nc; j0 += EO_NR) {
@@ -126,12 +128,12 @@ static int eo_dgemm(long M, long N, long K, const double* A, long rsa, long csa,
         long ncp = (nc + EO_NR - 1) / EO_NR * EO_NR;
         for (long pc = 0; pc < K; pc += EO_KC) {
             long kc = K - pc < EO_KC ? K - pc : EO_KC;
-            double* Bp = (double*)aligned_alloc(64, sizeof(double) * (size_t)(ncp * kc + 8));
+            double* Bp = (double*)aligned_alloc(64, eo_round64(sizeof(double) * (size_t)(ncp * kc + 8)));
             if (!Bp) return eo_fail(EO_ERR_NOMEM, "out of memory in dgemm%s", NULL);
             eo_pack_b(kc, nc, B + pc * rsb + jc * csb, rsb, csb, Bp);
 #pragma omp parallel
             {
-                double* Ap = (double*)aligned_alloc(64, sizeof(double) * (size_t)((EO_MC + EO_MR) * kc + 8));
+                double* Ap = (double*)aligned_alloc(64, eo_round64(sizeof(double) * (size_t)((EO_MC + EO_MR) * kc + 8)));
                 if (!Ap) {
 #pragma omp atomic write
                     failed = 1;

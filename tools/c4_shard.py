@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""BASELINE configs[3] at the size ONE of its eight GPUs holds: n = 50,000 individuals x 625,000 markers (5,000,000 / 8).
+
+  phase A  the shard resident in HBM (31 GB int8 + its re-centred image + 80 GB of fp64 operands), device-resident entry points:
+           MM^T partial (exact int32) + finish, and the calculate_a_and_vara pass (W = S V S, genotype pass, digit-slice vara
+           kernel, certification, arg-max), timed per phase with HIP events;
+  phase B  the same shard STREAMED from its 2-bit sidecar (7.8 GB) through the reference-shaped entry point
+           (calculate_a_and_vara_rcpp.cpp:117-234 is the reference's blocked branch), with EAGLE_HIP_MAX_RESIDENT_GB forcing
+           >= 100 chunks; eagle_last_stream_stats says how much of the loads the kernels hid.
+
+Operands have low-rank structure (S = s I + P P^T, V = D + U U^T) so that a and vara have O(n r) closed forms in numpy; the
+library receives dense 50,000 x 50,000 matrices and does the full n^3 products.  The text file the sidecar belongs to is a
+sparse placeholder of the right size (31 GB of '0' holes that are never read: a valid sidecar is all a load needs).
+Usage: tools/c4_shard.py [n] [L] [chunks]      (defaults 50000 625000 100; a small shape makes a quick self-test)
+"""
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+I8_PEAK, F64_PEAK, F4_PEAK = 5000.0, 78.6, 10000.0
+
+
+def log(msg):
+    print("[c4_shard %7.1fs] %s" % (time.time() - T0, msg), file=sys.stderr, flush=True)
+
+
+def drop_page_cache(path):
+    """Ask the kernel to forget the file's (clean) pages, so that the next read comes from the device under the file system."""
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        os.fsync(fd)
+        os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+    finally:
+        os.close(fd)
+
+
+def fs_of(path):
+    best = ("", "?", "?")
+    for line in open("/proc/mounts"):
+        dev, mnt, typ = line.split()[:3]
+        if os.path.abspath(path).startswith(mnt.rstrip("/") + "/") or mnt == "/":
+            if len(mnt) >= len(best[0]):
+                best = (mnt, typ, dev)
+    return {"mount": best[0], "fstype": best[1], "device": best[2]}
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
+    L = int(sys.argv[2]) if len(sys.argv) > 2 else 625000
+    chunks = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+    import torch
+    from eagleeverything_amd import rcpp_api, synth
+    from eagleeverything_amd.sharded import DeviceShard
+    out = {"n": n, "L": L, "what": "BASELINE configs[3] (50,000 x 5,000,000 over 8 GPUs): the shard of ONE GPU on one MI355X"}
+    sh = DeviceShard(n, L)
+    lib = sh.L
+    np_, Lp = sh.np_, sh.Lp
+    t = time.time()
+    sh.fill_synthetic(seed=4)
+    torch.cuda.synchronize()
+    out["genotypes_s"] = time.time() - t
+    log("genotypes drawn: %d x %d (%.1f GB int8)" % (L, n, Lp * np_ / 1e9))
+    tmpdir = tempfile.mkdtemp(dir=os.environ.get("TMPDIR", "/tmp"))
+    path_text = os.path.join(tmpdir, "Mt.ascii")
+    t = time.time()
+    out["sidecar_bytes"] = synth.write_sidecar_from_device(lib, sh.ctx, sh.Mt8, L, n, path_text)
+    out["sidecar_write_s"] = time.time() - t
+    out["filesystem"] = fs_of(path_text)
+    log("sidecar written: %.2f GB in %.1f s on %s" % (out["sidecar_bytes"] / 1e9, out["sidecar_write_s"], out["filesystem"]))
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    # ---- phase A1: MM^T of the shard (calculateMMt_rcpp.cpp:95 as a k-split partial) ---------------------------------
+    t = time.time()
+    e0, e1, e2, e3 = ev(), ev(), ev(), ev()
+    e0.record()
+    sh.individual_major_fp4()
+    e1.record()
+    sh.M8 = None
+    c32 = torch.empty((np_, np_), dtype=torch.int32, device=sh.dev)
+    sh.mmt_partial(out=c32)   # first call: tile lists, attributes
+    torch.cuda.synchronize()
+    e2.record()
+    sh.mmt_partial(out=c32)
+    e3.record()
+    torch.cuda.synchronize()
+    syrk_s = e2.elapsed_time(e3) / 1e3
+    e4, e5 = ev(), ev()
+    e4.record()
+    MMt, mx = sh.mmt_finish(c32, normalise=False)
+    e5.record()
+    torch.cuda.synchronize()
+    del c32
+    mm = {"operand_images_s (transpose + fp4 pack)": e0.elapsed_time(e1) / 1e3, "syrk_s": syrk_s, "finish_s": e4.elapsed_time(e5) / 1e3,
+          "syrk_frac_of_fp4_peak": (np_ * (np_ + 256.0)) * Lp / syrk_s / 1e12 / F4_PEAK}
+    # exact integer properties on the full shard
+    cols = torch.tensor([0, 1, 255, 256, n // 2, n - 1], device=sh.dev)
+    diag_ref = torch.zeros(n, dtype=torch.float64, device=sh.dev)
+    cols_ref = torch.zeros((n, cols.numel()), dtype=torch.float64, device=sh.dev)
+    for r0 in range(0, L, 32768):
+        blk = sh.Mt8[r0:min(L, r0 + 32768), :n]
+        diag_ref += (blk.to(torch.int16) ** 2).sum(dim=0, dtype=torch.int64).double()
+        cols_ref += blk.double().T @ blk[:, cols].double()
+    mm["diag_exact"] = bool(torch.equal(torch.diagonal(MMt), diag_ref))
+    mm["columns_exact"] = bool(torch.equal(MMt[:, cols], cols_ref))
+    mm["symmetric_blocks"] = bool(all(torch.equal(MMt[b0:b0 + 1000, 20000 % n:20000 % n + 1000], MMt[20000 % n:20000 % n + 1000, b0:b0 + 1000].T)
+                                      for b0 in (0, n // 4, n - 1000)))
+    mm["max_equals"] = bool(float(mx) == float(MMt.max()))
+    out["mmt"] = mm
+    log("MM^T: %s" % json.dumps(mm))
+    del MMt, diag_ref, cols_ref
+    sh.M4 = None
+    torch.cuda.empty_cache()
+
+    # ---- operands with closed forms ------------------------------------------------------------------------------------
+    rng = np.random.default_rng(50)
+    r1, r2 = 6, 5
+    P = rng.standard_normal((n, r1)) / np.sqrt(n) * 0.5
+    U = rng.standard_normal((n, r2)) / np.sqrt(n) * 0.7
+    s, d = 0.8, rng.uniform(0.5, 1.5, size=n)
+    ahat = rng.standard_normal(n)
+    Pd, Ud = torch.as_tensor(P, device=sh.dev), torch.as_tensor(U, device=sh.dev)
+    S = Pd @ Pd.T
+    S.diagonal().add_(s)
+    V = Ud @ Ud.T
+    V.diagonal().add_(torch.as_tensor(d, device=sh.dev))
+    S_host = S.cpu().numpy()   # symmetric: row-major == column-major
+    V_host = V.cpu().numpy()
+    sh.set_operands(S, V, ahat)
+    del S, V
+    torch.cuda.empty_cache()
+    sh.mode = 1
+
+    # ---- phase A2: the resident scan ------------------------------------------------------------------------------------
+    names = ("W = S V S", "prepare", "vara kernel", "certify")
+    reps = []
+    for rep in range(2):
+        es = [ev() for _ in range(5)]
+        tw = time.perf_counter()
+        es[0].record(); sh.scan_operands(None)
+        es[1].record(); sh.vara_prepare()
+        es[2].record(); sh.vara_kernel()
+        es[3].record(); sh.certify()
+        es[4].record(); sh.argmax()
+        tsqmax, gidx, near = sh.best()
+        wall = time.perf_counter() - tw
+        reps.append(dict({k: es[i].elapsed_time(es[i + 1]) / 1e3 for i, k in enumerate(names)}, step_s=wall))
+        log("resident scan rep %d: %s" % (rep, json.dumps(reps[-1])))
+    r = reps[-1]
+    S_used = sh.vara_i8_info()[0]
+    nct8 = np_ // 256
+    ops = sum(2.0 * Lp * 256 * min((ct + 1) * 256, np_) for ct in range(nct8)) * S_used
+    res = {"phases_s": r, "markers_per_s": L / r["step_s"], "slices": S_used,
+           "vara_kernel_frac_of_int8_peak": ops / r["vara kernel"] / 1e12 / I8_PEAK,
+           "W_frac_of_fp64_peak": 3.0 * np_ ** 3 / r["W = S V S"] / 1e12 / F64_PEAK, "certificate": sh.certificate()}
+    a_res, v_res = sh.a[:L].cpu().numpy(), sh.vara[:L].cpu().numpy()
+    rows = np.r_[0:64, L // 2:L // 2 + 64, L - 64:L]
+    M = sh.Mt8[torch.as_tensor(rows, device=sh.dev)][:, :n].cpu().numpy().astype(np.float64)
+    Z = s * M + (M @ P) @ P.T
+    a_ref = Z @ ahat
+    v_ref = (Z * Z) @ d + ((Z @ U) ** 2).sum(axis=1)
+    res["a_max_rel_vs_closed_form"] = float(np.max(np.abs(a_res[rows] - a_ref)) / np.max(np.abs(a_ref)))
+    res["vara_max_rel_vs_closed_form"] = float(np.max(np.abs(v_res[rows] - v_ref) / np.abs(v_ref)))
+    with np.errstate(all="ignore"):
+        tsq = a_res ** 2 / v_res
+    res["argmax_equals_full_tsq"] = bool(gidx == int(np.nanargmax(tsq)) and tsqmax == float(np.nanmax(tsq)))
+    res["selected_marker"] = gidx + 1
+    out["resident_scan"] = res
+    log("resident: %s" % json.dumps(res))
+    # free everything the device-resident leg held
+    sh.release_operands()
+    sh.Mt8 = sh.Mt8s = sh.cshift = sh.l1 = sh.cert_ws = sh.a = sh.vara = None
+    del sh
+    torch.cuda.empty_cache()
+
+    # ---- phase B: the shard streamed from its 2-bit sidecar through the reference-shaped entry point ------------------------------
+    rows_per_chunk = max(256, (Lp // chunks) // 256 * 256)
+    budget_gb = 2.0 * rows_per_chunk * np_ / 1e9
+    os.environ["EAGLE_HIP_MAX_RESIDENT_GB"] = "%.6f" % budget_gb
+    msgs = []
+    for leg in ("from_disk_after_fadvise_dontneed", "from_page_cache"):
+        if leg.startswith("from_disk"):
+            drop_page_cache(path_text + ".e2b")
+        t = time.perf_counter()
+        r1_ = rcpp_api.calculate_a_and_vara_rcpp(path_text, np.nan, S_host, V_host, 1000.0, (L, n), ahat, quiet=False, message=msgs.append)
+        wall = time.perf_counter() - t
+        st = rcpp_api.last_stream_stats()
+        idx, tmax, _ = rcpp_api.last_scan_argmax()
+        a1, v1 = np.asarray(r1_["a"]).ravel(), np.asarray(r1_["vara"]).ravel()
+        st.update({"call_wall_s": wall, "markers_per_s": L / wall, "markers_per_s_excluding_operands (kernels+starved)": L / max(1e-9, st["kernel_s"] + st["starved_s"]),
+                   "chunk_budget_GB": budget_gb, "rows_per_chunk": rows_per_chunk,
+                   "a_equal_resident": bool(np.array_equal(a1, a_res)), "vara_max_rel_vs_resident": float(np.max(np.abs(v1 - v_res) / np.abs(v_res))),
+                   "vara_values_differing_from_resident": int(np.sum(v1 != v_res)), "selected_marker_equal": bool(idx == gidx + 1)})
+        out["streamed_" + leg] = st
+        log("streamed (%s): %s" % (leg, json.dumps(st)))
+    out["streamed_message"] = [m for m in msgs if "streamed" in m][:1]
+    os.environ.pop("EAGLE_HIP_MAX_RESIDENT_GB")
+    for f in (path_text, path_text + ".e2b"):
+        os.unlink(f)
+    os.rmdir(tmpdir)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    T0 = time.time()
+    main()

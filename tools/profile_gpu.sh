@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): rocprofv3 kernel stats + separate PMC passes of bench.py (headline shape, 10k x 1M).
 # PMC passes reload the operands the stats pass computed: torch.linalg.eigh (rocSOLVER) segfaults under rocprofv3
-# counter collection (log: profiles/r02_eigh_under_pmc.log, made by tools/eigh_under_pmc.sh), and the workload must be the
+# counter collection (log: profiles/r02_eigh_under_pmc.log, made by tools/eigh_under_pmc.py), and the workload must be the
 # same in every pass.
 # Usage: tools/profile_gpu.sh <tag> [bench args...]      outputs under gpurun_out/prof_<tag>/
 set -o pipefail
