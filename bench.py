@@ -79,8 +79,6 @@ class Run:
         self.sh = sh = DeviceShard(n, m1 - m0, first_marker=m0, device=local_rank)
         sh.nslices = args.slices
         sh.fill_synthetic()
-        sh.individual_major()
-        sh.individual_major_fp4()  # operand image of the MM^T kernel (made once per shard, like the int8 images)
         torch.cuda.synchronize(self.dev)
         self.t_gen = time.time() - t0
         self.S = self.V = self.ahat = None
@@ -105,16 +103,19 @@ class Run:
     def mmt_build(self, reps):
         torch, sh = self.torch, self.sh
         c32 = torch.empty((sh.np_, sh.np_), dtype=torch.int32, device=self.dev)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        times, syrk = [], []
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        times, syrk, image = [], [], []
         MMt = None
         for rep in range(reps + 1):
+            sh.M4 = None   # the fp4 operand image exists for MM^T only: making it is part of the build
             self.barrier()
             t1 = time.perf_counter()
-            c32.zero_()
-            ev0.record()
-            sh.mmt_partial(out=c32)
-            ev1.record()
+            ev[0].record()
+            sh.individual_major_fp4()   # k_transpose_pack_fp4: marker-major int8 -> individual-major fp4, one pass
+            ev[1].record()
+            ev[2].record()
+            sh.mmt_partial(out=c32)     # zeroes c32, then the SYRK
+            ev[3].record()
             self.coll.sum_partial_mmt(c32, dst=0)   # the process that talks to R needs the sum; the others only contribute
             if self.rank == 0:
                 MMt, mx = sh.mmt_finish(c32, normalise=True)
@@ -122,8 +123,10 @@ class Run:
             dt = self.max_over_ranks(time.perf_counter() - t1)
             if rep > 0:
                 times.append(dt)
-                syrk.append(ev0.elapsed_time(ev1))
+                syrk.append(ev[2].elapsed_time(ev[3]))
+                image.append(ev[0].elapsed_time(ev[1]))
         del c32
+        self.mmt_image_s = float(np.mean(image)) / 1e3
         return MMt, float(np.mean(times)), float(np.mean(syrk)) / 1e3
 
     # ---- scan operands from the model algebra on the actual MM^T (untimed input manufacturing) ------
@@ -519,16 +522,20 @@ def main():
     t_gen = run.t_gen
     sh.mode = 0 if args.mode == "f64" else 1
     MMt, mmt_build_s, syrk_s = run.mmt_build(args.mmt_reps)
+    mmt_image_s = run.mmt_image_s
     t_ops = run.make_operands(MMt)
     del MMt
     w_choice = run.choose_w_sharing()
     sh_share_w = bool(sh.share_w)
     sel, elapsed, parts = run.timed(args.steps, args.warmup)
+    a_step, vara_step = sh.a[:sh.Lloc].clone(), sh.vara[:sh.Lloc].clone()   # what the last timed step returned
     ms_per_step = elapsed / args.steps * 1e3
     value = Ltot * args.steps / elapsed
     kern_s = parts["kern"]
     cert = sh.certificate() if sh.mode == 1 else None
 
+    if world > 1:
+        del a_step, vara_step
     # the HBM-bound kernel of the scan on its own (a = Mt v: L*n genotype bytes, read once), outside the timed steps
     gp = []
     for _ in range(4):
@@ -634,11 +641,12 @@ def main():
         tmpd = tempfile.mkdtemp(dir=os.environ.get("TMPDIR", "/tmp"))
         try:
             geno = synth.write_geno_pair_sidecars(tmpd, sh)
+            sh.M8 = None   # the individual-major int8 image was only needed to write M.ascii's sidecar
             S_h, V_h, a_h = np.asfortranarray(run.S.cpu().numpy()), np.asfortranarray(run.V.cpu().numpy()), run.ahat.cpu().numpy()
             leg, _ = abi_leg(args, torch, geno, n, Ltot, S_h, V_h, a_h, local_rank, 3, 1)
             a_e, v_e = leg.pop("results")
-            leg["a_bitwise_equal_to_device_resident_step"] = bool(np.array_equal(a_e, sh.a[:Ltot].cpu().numpy()))
-            leg["vara_bitwise_equal_to_device_resident_step"] = bool(np.array_equal(v_e, sh.vara[:Ltot].cpu().numpy()))
+            leg["a_bitwise_equal_to_device_resident_step"] = bool(np.array_equal(a_e, a_step.cpu().numpy()))
+            leg["vara_bitwise_equal_to_device_resident_step"] = bool(np.array_equal(v_e, vara_step.cpu().numpy()))
             leg["selected_marker_equal"] = bool(leg["selected_marker"] == sel_i8[0])
             leg["device_resident_step_ms"] = ms_per_step
             leg["gap_ms (call - device-resident step)"] = leg["ms_per_call"] - ms_per_step
@@ -779,7 +787,12 @@ def main():
             "launcher": "self-spawned child torch.distributed.run" if os.environ.get("EAGLE_BENCH_SPAWNED") else ("external launcher" if world > 1 else "single process"),
             "markers_per_rank": [shard_range(Ltot, r, world)[1] - shard_range(Ltot, r, world)[0] for r in range(world)],
             "w_sharing": ("rows 1/%d per rank + one all-gather" % world if world > 1 and sh_share_w else ("replicated on every rank" if world > 1 else "n/a (one rank)")),
-            "mmt_build_s": mmt_build_s, "selected_marker": int(sel[0]), "tsqmax": sel[1],
+            "mmt_build_s": mmt_build_s,
+            "mmt_build_breakdown_s": {"fp4 operand image from the marker-major genotypes (k_transpose_pack_fp4)": mmt_image_s,
+                                      "partial SYRK (zero + k_syrk_f4w)": syrk_s,
+                                      "sum over ranks + mirror / int32 -> fp64 / max + normalise": max(0.0, mmt_build_s - mmt_image_s - syrk_s),
+                                      "note": "mmt_build_s is all-in: every pass that exists only for MM^T is inside the timed region"},
+            "selected_marker": int(sel[0]), "tsqmax": sel[1],
             "roofline": roof, "roofline_secondary": secondary, "cpu_baseline": cpu, "parity": parity,
             "device": info, "kernel_sha16": sha, "setup_s": {"genotypes": t_gen, "operands": t_ops},
         }

@@ -97,6 +97,7 @@ SIGNATURES = {
                                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     "eagle_vara_f6_workspace_bytes": (C.c_int64, [C.c_long, C.c_long, C.c_int]),
     "eagle_dev_pack_fp4": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p]),
+    "eagle_dev_transpose_pack_fp4": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_void_p]),
     "eagle_dev_vara_f6_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_int,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "eagle_dev_vara_f6_mfma": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_int, C.c_void_p,

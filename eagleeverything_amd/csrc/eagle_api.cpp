@@ -231,7 +231,7 @@ template <class F> static int run_on_devices(eagle_ctx* ctx, F fn) {
 // this device's resident genotype copies only (safe from a per-device worker thread)
 static void drop_cache_local(eagle_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
-    for (auto& g : ctx->cache) { if (g.dev) (void)hipFree(g.dev); if (g.dev_s) (void)hipFree(g.dev_s); if (g.cshift) (void)hipFree(g.cshift); if (g.l1) (void)hipFree(g.l1); }
+    for (auto& g : ctx->cache) { if (g.dev) (void)hipFree(g.dev); if (g.dev_s) (void)hipFree(g.dev_s); if (g.cshift) (void)hipFree(g.cshift); if (g.l1) (void)hipFree(g.l1); if (g.dev_f4) (void)hipFree(g.dev_f4); }
     ctx->cache.clear();
     if (ctx->f4_buf) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->f4_buf); ctx->f4_buf = nullptr; ctx->f4_cap = 0; }
 }
@@ -260,6 +260,7 @@ extern "C" void eagle_close(eagle_ctx* ctx) {
     if (ctx->d_mmt_max) (void)hipFree(ctx->d_mmt_max);
     if (ctx->d_a) (void)hipFree(ctx->d_a);
     if (ctx->d_vara) (void)hipFree(ctx->d_vara);
+    if (ctx->d_bound) (void)hipFree(ctx->d_bound);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_Scache) (void)hipFree(ctx->d_Scache);
     if (ctx->d_Sscr) (void)hipFree(ctx->d_Sscr);
@@ -638,7 +639,8 @@ static void free_entry(GenoEntry& g) {
     if (g.dev_s) (void)hipFree(g.dev_s);
     if (g.cshift) (void)hipFree(g.cshift);
     if (g.l1) (void)hipFree(g.l1);
-    g.dev = g.dev_s = g.cshift = nullptr; g.l1 = nullptr;
+    if (g.dev_f4) (void)hipFree(g.dev_f4);
+    g.dev = g.dev_s = g.cshift = nullptr; g.l1 = nullptr; g.dev_f4 = nullptr;
 }
 // Whole-file resident copy (rows lines x cols characters from the origin), current size and mtime.
 const GenoEntry* eagle_cache_find(eagle_ctx* ctx, const char* path, long rows, long cols) {
@@ -906,7 +908,16 @@ static int mmt_range(eagle_ctx* ctx, const char* path, long n, long L, long c0, 
     for (long c : sel) if (c >= c0 && c < c1) in_range.push_back(c - c0);
     DevBuf dsel, win;
     if (rc == EAGLE_OK) {
-        rc = eagle_dev_mmt_accumulate(ctx, g->dev, np, eagle_pad(Lw_all), g->ld, ctx->d_c32, ctx->stream);
+        // the fp4 operand image stays with the resident file: a later calculateMMt on it (SummaryAM re-calls .calcMMt,
+        // E/R/summary_am.R:140) is the SYRK + finish only
+        const long Lwp = eagle_pad(Lw_all);
+        if (!g->dev_f4) {
+            hipError_t e = hipMalloc(&g->dev_f4, (size_t)np * (size_t)(Lwp / 2));
+            if (e != hipSuccess) { g->dev_f4 = nullptr; (void)hipGetLastError(); }
+            else if ((rc = eagle_dev_pack_fp4(ctx, g->dev, np, Lwp, g->ld, g->dev_f4, ctx->stream))) { (void)hipFree(g->dev_f4); g->dev_f4 = nullptr; return rc; }
+        }
+        rc = g->dev_f4 ? eagle_dev_mmt_accumulate_f4(ctx, g->dev_f4, np, Lwp, Lwp / 2, ctx->d_c32, ctx->stream)
+                       : eagle_dev_mmt_accumulate(ctx, g->dev, np, Lwp, g->ld, ctx->d_c32, ctx->stream);  // no room: pack into the ctx buffer per call
         if (rc) return rc;
         if (!in_range.empty()) {
             HIPCHK(ctx, dsel.alloc(sizeof(long) * in_range.size()));
@@ -1043,9 +1054,11 @@ static int ensure_scan_out(eagle_ctx* ctx, long L_pad) {
     if (ctx->scan_cap >= L_pad) return EAGLE_OK;
     if (ctx->d_a) { (void)hipFree(ctx->d_a); ctx->d_a = nullptr; }
     if (ctx->d_vara) { (void)hipFree(ctx->d_vara); ctx->d_vara = nullptr; }
+    if (ctx->d_bound) { (void)hipFree(ctx->d_bound); ctx->d_bound = nullptr; }
     ctx->scan_cap = 0;
     HIPCHK(ctx, hipMalloc((void**)&ctx->d_a, sizeof(double) * (size_t)L_pad));
     HIPCHK(ctx, hipMalloc((void**)&ctx->d_vara, sizeof(double) * (size_t)L_pad));
+    HIPCHK(ctx, hipMalloc((void**)&ctx->d_bound, sizeof(double) * (size_t)L_pad));
     ctx->scan_cap = L_pad;
     return EAGLE_OK;
 }
@@ -1082,8 +1095,10 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
         streamed = (r == EAGLE_STREAM);
     }
     EAGLE_ARRIVE(streamed ? 1.0 : 0.0);
-    // certification against the maximum over ALL devices' shards needs every shard resident (one block per device)
-    const bool global_cert = rv && use_i8 && rv->vmax < 0.5;
+    // A scan that does not see all its markers at once -- a file streamed in marker blocks, the shards of several devices -- is
+    // certified against ONE lower bound of the maximum over every block of every device, so that the candidates, and with them every
+    // returned bit, are those of the one-block scan of the whole file (the per-marker bounds of all blocks stay: 8 bytes per marker).
+    const bool bounds_flow = use_i8 && (streamed || rv);
     const long Lc = streamed ? stream_chunk_rows(np, Lp) : Lp;  // marker rows per pass
     DevBuf dsel;
     const size_t wsb = use_i8 ? (size_t)eagle_vara_i8_workspace_bytes(np, Lc, nslices) : 0;
@@ -1239,12 +1254,11 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
             if (rc) break;
             ph.mark(ctx->stream, PH_VARA);
             // a-posteriori certificate: markers the digit bounds cannot settle are re-evaluated by the fp64 kernel, so that
-            // which(tsq == max(tsq))[1] on the returned arrays is the marker the fp64 scan selects (find_qtl.R:71-83).  A
-            // streamed file is certified block by block against the block's own maximum (a superset of the global candidates);
-            // resident shards of a multi-device scan exchange their lower bounds first (below), so that the candidates -- and
-            // with them every returned bit -- are those of the single-device scan.
-            if (global_cert) {
-                rc = eagle_dev_scan_certify_lb(ctx, nr, nrp, np, cv, l1, nslices, ws, ctx->d_a + r0, ctx->d_vara + r0, cert, ctx->stream);
+            // which(tsq == max(tsq))[1] on the returned arrays is the marker the fp64 scan selects (find_qtl.R:71-83).  One resident
+            // block on one device: bound, selection and re-evaluation right here.  Marker blocks / device shards: only the
+            // per-marker bounds now; selection against the global lower bound after the last block (below).
+            if (bounds_flow) {
+                rc = eagle_dev_cert_bounds(ctx, nr, nrp, np, cv, l1, nslices, ws, ctx->d_vara + r0, ctx->d_bound + r0, ctx->stream);
             } else {
                 rc = eagle_dev_scan_certify(ctx, Mt8, nr, nrp, np, ldm, cv, l1, nslices, ws, Wu, ctx->d_a + r0, ctx->d_vara + r0, cert, ctx->stream);
                 if (!rc) rc = eagle_dev_cert_accumulate(ctx, cert, cert_totals, ctx->stream);
@@ -1261,17 +1275,61 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
         if (streamed && (rc = ring.computed(ctx))) break;
     }
     if (streamed && !rc) ring.finish(ctx);
-    if (global_cert) {
+    if (bounds_flow) {
         double lb = 0.0;  // this shard's lower bound of the maximum tsq (0 for an empty shard)
         if (!rc && Lr > 0) {
-            e = hipMemcpyAsync(&lb, cert, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            if (e != hipSuccess) rc = eagle_fail_hip(ctx, e, "lower bound of the shard's maximum");
+            rc = eagle_dev_cert_lb_b(ctx, Lr, ctx->d_a, ctx->d_vara, ctx->d_bound, cert, ctx->stream);
+            if (!rc) {
+                e = hipMemcpyAsync(&lb, cert, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                if (e != hipSuccess) rc = eagle_fail_hip(ctx, e, "lower bound of the shard's maximum");
+            }
         }
         EAGLE_ARRIVE(lb);
+        const double glb = rv ? rv->vmax : lb;
         if (Lr > 0) {
-            rc = eagle_dev_scan_certify_apply(ctx, g->dev, Lr, Lp, np, g->ld, g->cshift, g->l1, nslices, ws, Wu, ctx->d_a, ctx->d_vara, cert,
-                                              rv->vmax, ctx->stream);
+            eagle_cert_info hd;
+            rc = eagle_dev_cert_select_b(ctx, Lr, ctx->d_a, ctx->d_vara, ctx->d_bound, cert, glb, ctx->stream);
+            if (!rc) {
+                e = hipMemcpyAsync(&hd, cert, sizeof hd, hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                if (e != hipSuccess) rc = eagle_fail_hip(ctx, e, "candidate count");
+            }
+            if (!rc && hd.overflow) {
+                // more candidates than the re-evaluation buffer holds (degenerate operands): all of the shard in fp64
+                if (!streamed) {
+                    rc = eagle_dev_vara_f64(ctx, g->dev, Lp, np, g->ld, Wu, ctx->d_vara, ctx->stream);
+                } else {
+                    ChunkRing again;
+                    if (!(rc = again.init(ctx))) {
+                        again.buf[0] = ring.buf[0]; again.buf[1] = ring.buf[1];
+                        for (long r0 = 0; r0 < Lr && !rc; r0 += Lc) {
+                            const long nr = std::min(Lc, Lr - r0), nrp = eagle_pad(nr);
+                            int8_t* tile = nullptr;
+                            rc = again.load(ctx, f_name_ascii, m0 + r0, nr, 0, n, np, (size_t)nrp * np, max_memory_in_Gbytes, host_threads(), &tile);
+                            if (!rc) rc = eagle_dev_vara_f64(ctx, tile, nrp, np, np, Wu, ctx->d_vara + r0, ctx->stream);
+                            if (!rc) rc = again.computed(ctx);
+                        }
+                        if (!rc) again.finish(ctx);
+                    }
+                }
+            } else if (!rc && hd.reevaluated > 0) {
+                if (!streamed) {
+                    rc = eagle_dev_cert_reevaluate(ctx, g->dev, g->ld, np, Wu, ctx->d_vara, cert, ctx->stream);
+                } else {
+                    // only the candidates' rows are read back from the file (its 2-bit sidecar when there is one): typically one or two
+                    const long cnt = hd.reevaluated;
+                    std::vector<long> idx((size_t)cnt);
+                    int8_t* rows = eagle_cert_rows(cert);
+                    e = hipMemcpyAsync(idx.data(), eagle_cert_indices(cert), sizeof(long) * (size_t)cnt, hipMemcpyDeviceToHost, ctx->stream);
+                    if (e == hipSuccess) e = hipMemsetAsync(rows, 0, (size_t)((cnt + 127) / 128 * 128) * (size_t)np, ctx->stream);
+                    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                    if (e != hipSuccess) rc = eagle_fail_hip(ctx, e, "candidate list");
+                    for (long c = 0; c < cnt && !rc; c++)
+                        rc = eagle_dev_load_ascii(ctx, f_name_ascii, m0 + idx[(size_t)c], 1, 0, n, rows + c * np, np, max_memory_in_Gbytes, 1);
+                    if (!rc) rc = eagle_dev_cert_reevaluate(ctx, nullptr, np, np, Wu, ctx->d_vara, cert, ctx->stream);
+                }
+            }
             if (!rc) rc = eagle_dev_cert_accumulate(ctx, cert, cert_totals, ctx->stream);
             if (!rc) ph.mark(ctx->stream, PH_CERT);
         }

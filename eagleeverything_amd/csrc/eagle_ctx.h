@@ -30,6 +30,7 @@ struct GenoEntry {
     int8_t* dev_s = nullptr;    // re-centred image m - c_i (eagle_dev_marker_shift), made on the first digit-slice scan of the file
     int8_t* cshift = nullptr;   // c_i per row
     int32_t* l1 = nullptr;      // {sum_j |m_ij - c_i|, sum_j (m_ij - c_i)^2} per row (error bounds of the digit-slice scan)
+    void* dev_f4 = nullptr;     // fp4 image of `dev` (two genotypes per byte): operand of the MM^T kernel, made by the first calculateMMt on the file
 };
 
 struct eagle_ctx {
@@ -56,6 +57,7 @@ struct eagle_ctx {
     // results of the last calls, kept in HBM
     double* d_mmt = nullptr; long mmt_n = 0; double* d_mmt_max = nullptr;
     double* d_a = nullptr; double* d_vara = nullptr; long scan_L = 0; long scan_cap = 0;
+    double* d_bound = nullptr;  // a-posteriori error bound of every vara_i of the last digit-slice scan that ran in marker blocks / device shards
     long cert_reevaluated = 0, cert_flagged = 0; int cert_fell_back = 0;  // certification counters of the last digit-slice scan
     double scan_phase_ms[8] = {0}; long scan_blocks = 0;                  // phase clock of the last scan on this device (eagle_last_scan_timing)
     double scan_host_setup_s = 0, scan_range_wall_s = 0, scan_call_wall_s = 0;

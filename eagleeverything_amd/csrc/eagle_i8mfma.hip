@@ -1374,6 +1374,119 @@ extern "C" int eagle_dev_scan_certify(eagle_ctx* ctx, const int8_t* Mt8, long L,
                                         __builtin_nan(""), stream);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same certification for a scan that does not see all its markers at once (a file streamed through HBM in marker blocks, the
+// shards of a multi-device context): ONE lower bound over every block of every device, so that the returned bits do not depend
+// on how the markers were cut up (a block-by-block certificate re-evaluated a superset of candidates, and up
+// to 64 vara values differed at 1e-9 between a streamed and a resident scan of the same file).
+//   per block, right after the vara kernel:  bound[i] = b_i                      (eagle_dev_cert_bounds; 8 bytes per marker stay)
+//   after the last block:                    LB = max_i a_i^2 / (vara_i + b_i)   (eagle_dev_cert_lb_b; devices exchange theirs)
+//                                            idx[] = markers with b_i > 1e-7 |vara_i| or a_i^2 / (vara_i - b_i) >= LB (1 - 1e-9)
+//                                                                                 (eagle_dev_cert_select_b)
+//   the caller gathers those rows (from the resident image, or by re-reading just them from the file) and runs
+//   eagle_dev_vara_f64_split on them: bitwise the values, and so the selected marker, of the one-block scan.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cert_bounds(const double* __restrict__ vara, long L, const int32_t* __restrict__ l1,
+                                                     const int8_t* __restrict__ cshift, const double* __restrict__ vdiag,
+                                                     const double* __restrict__ mrho, const VaraHdr* __restrict__ hdr, double* __restrict__ bound) {
+    const CertCtx cc = cert_ctx(hdr);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L; i += (long)gridDim.x * 256)
+        bound[i] = cert_bound(cc, l1, i, cshift[i], vdiag[i], mrho[i], vara[i]);
+}
+__global__ __launch_bounds__(256) void k_cert_lb_b(const double* __restrict__ a, const double* __restrict__ vara, const double* __restrict__ bound,
+                                                   long L, CertHdr* __restrict__ ch) {
+    double best = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L; i += (long)gridDim.x * 256) {
+        const double x = a[i], v = vara[i];
+        if (!(isfinite(x) && isfinite(v))) continue;
+        const double up = v + bound[i];
+        if (!(up > 0.0)) continue;
+        const double lb = (x * x) / up;
+        best = lb > best ? lb : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_down(best, o); best = y > best ? y : best; }
+    if ((threadIdx.x & 63) == 0 && best > 0.0 && isfinite(best)) atomicMax(&ch->lb_bits, (unsigned long long)__double_as_longlong(best));
+}
+__global__ __launch_bounds__(256) void k_cert_select_b(const double* __restrict__ a, const double* __restrict__ vara, const double* __restrict__ bound,
+                                                       long L, CertHdr* __restrict__ ch, long* __restrict__ idx, double lb) {
+    const double thr = lb * (1.0 - 1e-9);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L; i += (long)gridDim.x * 256) {
+        const double x = a[i], v = vara[i];
+        if (!(isfinite(x) && isfinite(v))) continue;
+        const double b = bound[i];
+        const bool flagged = b > 1e-7 * fabs(v);
+        const double den = v - b;
+        const bool cand = !(den > 0.0) || (x * x) / den >= thr;
+        if (flagged) atomicAdd(&ch->flagged, 1);
+        if (flagged || cand) {
+            const int k = atomicAdd(&ch->count, 1);
+            if (k < CERT_CAP) idx[k] = i; else ch->overflow = 1;
+        }
+    }
+}
+// bound[0..L) of one marker block (vara_ws: the block's workspace as passed to prepare + mfma; vara: the block's values)
+extern "C" int eagle_dev_cert_bounds(eagle_ctx* ctx, long L, long L_pad, long n_pad, const int8_t* cshift, const int32_t* l1norm, int nslices,
+                                     const void* vara_ws, const double* vara, double* bound, void* stream) {
+    if (n_pad % T8 || L_pad % T8 || L < 0 || L > L_pad || !cshift || !l1norm || !bound)
+        return eagle_fail(ctx, EAGLE_ERR_ARG, "cert_bounds: layout contract violated");
+    if (L == 0) return EAGLE_OK;
+    const int smax = ws_smax(nslices);
+    const VaraHdr* hdr = (const VaraHdr*)vara_ws;
+    const double* vdiag = (const double*)((const char*)vara_ws + ws_vd_off(n_pad, L_pad, smax));
+    const double* mrho = (const double*)((const char*)vara_ws + ws_mr_off(n_pad, L_pad, smax));
+    unsigned blocks = (unsigned)((L + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_cert_bounds, dim3(blocks), dim3(256), 0, (hipStream_t)stream, vara, L, l1norm, cshift, vdiag, mrho, hdr, bound);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "k_cert_bounds");
+    return EAGLE_OK;
+}
+// head of cert_ws zeroed, then eagle_cert_info.lower_bound = max_i a_i^2 / (vara_i + bound_i) over the L markers (0: none positive)
+extern "C" int eagle_dev_cert_lb_b(eagle_ctx* ctx, long L, const double* a, const double* vara, const double* bound, void* cert_ws, void* stream) {
+    if (L < 0 || !cert_ws) return eagle_fail(ctx, EAGLE_ERR_ARG, "cert_lb_b: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(cert_ws, 0, 256, s);
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "cert_lb_b memset");
+    if (L == 0) return EAGLE_OK;
+    unsigned blocks = (unsigned)((L + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_cert_lb_b, dim3(blocks), dim3(256), 0, s, a, vara, bound, L, (CertHdr*)cert_ws);
+    e = hipGetLastError();
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "k_cert_lb_b");
+    return EAGLE_OK;
+}
+// candidates against `lb` into the index list of cert_ws (count / flagged / overflow in its head, which eagle_dev_cert_lb_b zeroed)
+extern "C" int eagle_dev_cert_select_b(eagle_ctx* ctx, long L, const double* a, const double* vara, const double* bound, void* cert_ws, double lb,
+                                       void* stream) {
+    if (L < 0 || !cert_ws) return eagle_fail(ctx, EAGLE_ERR_ARG, "cert_select_b: bad arguments");
+    if (L == 0) return EAGLE_OK;
+    unsigned blocks = (unsigned)((L + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_cert_select_b, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, vara, bound, L, (CertHdr*)cert_ws,
+                       (long*)((char*)cert_ws + cert_idx_off()), lb);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "k_cert_select_b");
+    return EAGLE_OK;
+}
+// Re-evaluation of the selected markers in fp64 once their genotype rows sit in cert_ws (eagle_cert_rows): rows of the resident
+// image are gathered here (Mt8 != NULL); rows of a streamed file were put there by the caller (Mt8 == NULL).  vara[idx[k]] is
+// overwritten with bitwise the value eagle_dev_vara_f64 gives that marker.
+extern "C" int8_t* eagle_cert_rows(void* cert_ws) { return (int8_t*)cert_ws + cert_rows_off(); }
+extern "C" long* eagle_cert_indices(void* cert_ws) { return (long*)((char*)cert_ws + cert_idx_off()); }
+extern "C" int eagle_dev_cert_reevaluate(eagle_ctx* ctx, const int8_t* Mt8, long ld, long n_pad, const double* Wu, double* vara, void* cert_ws, void* stream) {
+    CertHdr* ch = (CertHdr*)cert_ws;
+    long* idx = (long*)((char*)cert_ws + cert_idx_off());
+    int8_t* rows = (int8_t*)cert_ws + cert_rows_off();
+    double* partial = (double*)((char*)cert_ws + cert_part_off(n_pad));
+    if (Mt8) {
+        hipLaunchKernelGGL(k_cert_gather, dim3(CERT_CAP), dim3(256), 0, (hipStream_t)stream, Mt8, ld, n_pad, ch, idx, rows);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return eagle_fail_hip(ctx, e, "k_cert_gather");
+    }
+    return eagle_dev_vara_f64_split(ctx, rows, CERT_CAP, n_pad, n_pad, Wu, &ch->count, idx, partial, vara, stream);
+}
+
 __global__ void k_vara_i8_bound(const VaraHdr* __restrict__ hdr, double* __restrict__ out, int* __restrict__ slices_out) {
     *out = hdr->bound;
     if (slices_out) *slices_out = hdr->S;
@@ -1567,6 +1680,48 @@ extern "C" int eagle_dev_pack_fp4(eagle_ctx* ctx, const int8_t* Mt8, long L_pad,
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "k_pack_fp4");
+    return EAGLE_OK;
+}
+
+// The operand image of the MM^T kernel straight from the marker-major genotypes: M4[individual][marker / 2] (fp4, two per byte,
+// the even marker in the low nibble) from Mt8[marker][individual] in ONE pass -- a 256-marker x 64-individual tile goes through LDS,
+// wave `part` gathers 64 markers of its lane's individual (all lanes of a wave read one LDS row: 64 consecutive bytes, conflict
+// free) and writes their 32 bytes.  Replaces k_transpose_i8 + k_pack_fp4 (read 2 + write 1.5 bytes per genotype, and a second
+// int8 image of the shard) by read 1 + write 0.5.  Same bytes as the two-pass form (tests/test_gpu_parity.py).
+__global__ __launch_bounds__(256) void k_transpose_pack_fp4(const int8_t* __restrict__ in, long ld_in, uint8_t* __restrict__ out, long ld4) {
+    __shared__ __attribute__((aligned(16))) int8_t tile[256][64];
+    const long r0 = (long)blockIdx.x * 256, c0 = (long)blockIdx.y * 64;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int row = (t >> 2) + 64 * i, ch = (t & 3) * 16;
+        *(i32x4*)(&tile[row][ch]) = *(const i32x4*)(in + (r0 + row) * ld_in + c0 + ch);
+    }
+    __syncthreads();
+    const int c = t & 63, part = t >> 6;
+    unsigned o[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        unsigned v = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const unsigned m = (unsigned)(int)tile[part * 64 + w * 8 + q][c];
+            v |= (((m & 1u) << 1) | ((m & 0x80u) >> 4)) << (4 * q);
+        }
+        o[w] = v;
+    }
+    uint8_t* dst = out + (c0 + c) * ld4 + (r0 + part * 64) / 2;
+    *(i32x4*)dst = i32x4{(int)o[0], (int)o[1], (int)o[2], (int)o[3]};
+    *(i32x4*)(dst + 16) = i32x4{(int)o[4], (int)o[5], (int)o[6], (int)o[7]};
+}
+extern "C" int eagle_dev_transpose_pack_fp4(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, void* M4, long ld4, void* stream) {
+    if (L_pad % 256 || n_pad % 64 || ld % 16 || n_pad > ld || ld4 % 16 || ld4 < L_pad / 2 || n_pad / 64 > 65535)
+        return eagle_fail(ctx, EAGLE_ERR_ARG, "transpose_pack_fp4: layout contract violated (L_pad % 256, n_pad % 64, ld % 16, ld4 % 16)");
+    if (L_pad <= 0 || n_pad <= 0) return EAGLE_OK;
+    hipLaunchKernelGGL(k_transpose_pack_fp4, dim3((unsigned)(L_pad / 256), (unsigned)(n_pad / 64)), dim3(256), 0, (hipStream_t)stream, Mt8, ld,
+                       (uint8_t*)M4, ld4);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "k_transpose_pack_fp4");
     return EAGLE_OK;
 }
 

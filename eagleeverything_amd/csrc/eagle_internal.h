@@ -31,6 +31,14 @@ long eagle_upper_tiles_count(long n_pad);  // int32 elements of the packed upper
 int eagle_dev_tiles_pack(eagle_ctx* ctx, int32_t* C32, long n_pad, int32_t* packed, int unpack, void* stream);
 int eagle_dev_add_i32(eagle_ctx* ctx, int32_t* dst, const int32_t* src, long count, void* stream);
 int eagle_dev_cert_accumulate(eagle_ctx* ctx, const void* cert_ws, long* totals_dev, void* stream);
+// certification of a scan cut into marker blocks / device shards against ONE lower bound (eagle_i8mfma.hip, "The same certification ...")
+int eagle_dev_cert_bounds(eagle_ctx* ctx, long L, long L_pad, long n_pad, const int8_t* cshift, const int32_t* l1norm, int nslices,
+                          const void* vara_ws, const double* vara, double* bound, void* stream);
+int eagle_dev_cert_lb_b(eagle_ctx* ctx, long L, const double* a, const double* vara, const double* bound, void* cert_ws, void* stream);
+int eagle_dev_cert_select_b(eagle_ctx* ctx, long L, const double* a, const double* vara, const double* bound, void* cert_ws, double lb, void* stream);
+int8_t* eagle_cert_rows(void* cert_ws);
+long* eagle_cert_indices(void* cert_ws);
+int eagle_dev_cert_reevaluate(eagle_ctx* ctx, const int8_t* Mt8, long ld, long n_pad, const double* Wu, double* vara, void* cert_ws, void* stream);
 int eagle_dev_symmetrize(eagle_ctx* ctx, double* A, long n, long ld, void* stream);
 int eagle_dev_symmetrize_mean(eagle_ctx* ctx, double* A, long n, long ld, void* stream);
 int eagle_dev_scale_rows_pow(eagle_ctx* ctx, double* R, long n, long ld, const double* w, double p, void* stream);

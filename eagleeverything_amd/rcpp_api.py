@@ -268,6 +268,16 @@ def last_stream_stats(device=0):
     return d
 
 
+def last_scan_certificate(device=0):
+    """(markers re-evaluated in fp64, of which flagged by their own error bound, whether a block fell back to fp64 entirely) of the
+    last digit-slice calculate_a_and_vara_rcpp call (include/eagle_hip.h, eagle_last_scan_certificate)."""
+    L = _lib.load()
+    ctx = context(device)
+    nre, nfl, fell = C.c_long(), C.c_long(), C.c_int()
+    _check(ctx, L.eagle_last_scan_certificate(ctx, C.byref(nre), C.byref(nfl), C.byref(fell)))
+    return nre.value, nfl.value, bool(fell.value)
+
+
 class _ScanTiming(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("call_wall_s", "device_wall_s", "host_setup_s", "upload_ms", "w_ms", "load_wait_ms", "prepare_ms",
                                           "vara_ms", "certify_ms", "d2h_ms")] + [("blocks", C.c_long), ("markers", C.c_long)]

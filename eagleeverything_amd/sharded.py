@@ -204,10 +204,13 @@ class DeviceShard:
     def individual_major_fp4(self):
         """M4: the individual-major genotypes as fp4 (two per byte), the operand image of the MM^T kernel."""
         if self.M4 is None:
-            M8 = self.individual_major()
             self.M4 = self.torch.empty((self.np_, self.Lp // 2), dtype=self.torch.uint8, device=self.dev)
-            self._check(self.L.eagle_dev_pack_fp4(self.ctx, M8.data_ptr(), self.np_, self.Lp, self.Lp, self.M4.data_ptr(),
-                                                  self._stream()))
+            if self.M8 is not None:   # a column window of M.ascii was loaded: pack it
+                self._check(self.L.eagle_dev_pack_fp4(self.ctx, self.M8.data_ptr(), self.np_, self.Lp, self.Lp, self.M4.data_ptr(),
+                                                      self._stream()))
+            else:                     # straight from the marker-major image, one pass, no individual-major int8 image
+                self._check(self.L.eagle_dev_transpose_pack_fp4(self.ctx, self.Mt8.data_ptr(), self.Lp, self.np_, self.np_,
+                                                                self.M4.data_ptr(), self.Lp // 2, self._stream()))
         return self.M4
 
     # ---- MM^T -----------------------------------------------------------------------------------

@@ -130,8 +130,8 @@ def test_spectral_scan_over_two_contexts(api, tmp_path):
 
 
 def test_multi_device_streamed_shards(api, oracle, tmp_path, monkeypatch):
-    """Shards that may not stay resident are streamed per device; MM^T stays exact, a identical, vara identical except where a
-    block's own certification re-evaluated a few more markers in fp64, the selected marker identical."""
+    """Shards that may not stay resident are streamed per device; MM^T, a, vara and the selected marker come back bit for bit as
+    from one device holding the file (the blocks' certification uses one lower bound over all blocks of all devices)."""
     n, L = 520, 9000
     rng = np.random.default_rng(8)
     Mt8 = synth.genotypes_marker_major(n, L, seed=33)
@@ -152,10 +152,8 @@ def test_multi_device_streamed_shards(api, oracle, tmp_path, monkeypatch):
     monkeypatch.delenv("EAGLE_HIP_MAX_RESIDENT_GB")
     np.testing.assert_array_equal(mmt_one, mmt_many)
     np.testing.assert_array_equal(one["a"], many["a"])
-    differ = np.flatnonzero(one["vara"].ravel() != many["vara"].ravel())
-    assert differ.size <= 64
-    np.testing.assert_allclose(many["vara"].ravel()[differ], one["vara"].ravel()[differ], rtol=1e-9)
-    assert best_one[0] == best_many[0]
+    np.testing.assert_array_equal(one["vara"], many["vara"])   # one lower bound over every block of every device
+    assert best_one[0] == best_many[0] and best_one[1] == best_many[1]
     api.drop_cache(device=dev)
 
 

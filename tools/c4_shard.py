@@ -129,8 +129,8 @@ def main():
     S.diagonal().add_(s)
     V = Ud @ Ud.T
     V.diagonal().add_(torch.as_tensor(d, device=sh.dev))
-    S_host = S.cpu().numpy()   # symmetric: row-major == column-major
-    V_host = V.cpu().numpy()
+    S_host = S.cpu().numpy().T   # symmetric: the transposed view of the row-major copy IS the column-major matrix R would hand over
+    V_host = V.cpu().numpy().T   # (no 20 GB layout change on one host core inside the timed call)
     sh.set_operands(S, V, ahat)
     del S, V
     torch.cuda.empty_cache()
@@ -190,6 +190,8 @@ def main():
         r1_ = rcpp_api.calculate_a_and_vara_rcpp(path_text, np.nan, S_host, V_host, 1000.0, (L, n), ahat, quiet=False, message=msgs.append)
         wall = time.perf_counter() - t
         st = rcpp_api.last_stream_stats()
+        st["phases"] = rcpp_api.last_scan_timing()
+        st["certificate (re-evaluated, flagged, fell back)"] = list(rcpp_api.last_scan_certificate())
         idx, tmax, _ = rcpp_api.last_scan_argmax()
         a1, v1 = np.asarray(r1_["a"]).ravel(), np.asarray(r1_["vara"]).ravel()
         st.update({"call_wall_s": wall, "markers_per_s": L / wall, "markers_per_s_excluding_operands (kernels+starved)": L / max(1e-9, st["kernel_s"] + st["starved_s"]),
