@@ -1162,7 +1162,9 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
                 Sa = ctx->d_Scache;
             } else if ((r = upload_square(ctx, inv_MMt_sqrt, n, np, Sa))) return r;
         }
-        if ((r = ensure_scan_out(ctx, Lp))) return r;
+        // streamed: every block is worked as a full chunk of Lc rows (one workspace layout for all of them; the rows beyond a short
+        // last block are zero and land in the slack behind the shard's results)
+        if ((r = ensure_scan_out(ctx, streamed ? (Lr + Lc - 1) / Lc * Lc : Lp))) return r;
         HIPCHK(ctx, hipMemsetAsync(cert_totals, 0, 3 * sizeof(long), ctx->stream));
         ph.mark(ctx->stream, PH_UPLOAD);
         return EAGLE_OK;
@@ -1209,7 +1211,7 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
     if (!rc && streamed && !quiet) say(ctx, " Mt.ascii streamed through HBM in blocks of %ld markers", Lc);
     // one pass per marker block: the whole shard when it is resident, else chunks read back from the file
     for (long r0 = 0; r0 < Lr && !rc; r0 += Lc) {
-        const long nr = std::min(Lc, Lr - r0), nrp = eagle_pad(nr);
+        const long nr = std::min(Lc, Lr - r0), nrp = streamed ? Lc : eagle_pad(nr);
         const int8_t* Mt8 = streamed ? nullptr : g->dev;
         const long ldm = streamed ? np : g->ld;
         if (streamed) {
@@ -1247,7 +1249,8 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
                 Ms = g->dev_s; cv = g->cshift; l1 = g->l1;
             }
             // one pass over the genotypes gives a = Mt v and the diagonal term of vara; then the int8 MFMA kernel
-            rc = eagle_dev_vara_i8_prepare(ctx, Mt8, nrp, np, ldm, Wu, nslices, ws, v, ctx->d_a + r0, ctx->stream);
+            // (the W-dependent part -- digits of W, rho -- once per scan; per block of a streamed file only the genotype pass)
+            rc = eagle_dev_vara_i8_prepare_part(ctx, Mt8, nrp, np, ldm, Wu, nslices, ws, v, ctx->d_a + r0, ctx->stream, !streamed ? 0 : (r0 == 0 ? 0 : 2));
             if (rc) break;
             ph.mark(ctx->stream, PH_PREPARE);
             rc = eagle_dev_vara_i8_mfma_shifted(ctx, Ms, cv, nrp, np, ldm, nslices, ws, ctx->d_vara + r0, nullptr, ctx->stream);

@@ -1527,8 +1527,11 @@ static int vara_i8_check(eagle_ctx* ctx, long L_pad, long n_pad, long ld, int ns
 // 9 = the compiler-scheduled 384 x 256 form).
 static bool vara_piped(const eagle_ctx* ctx, long n_pad) { return ctx->tune != 8 && ctx->tune != 9 && n_pad < 65536; }
 
-extern "C" int eagle_dev_vara_i8_prepare(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu,
-                                         int nslices, void* ws, const double* v, double* a_out, void* stream) {
+// part 0: everything (one block = the whole scan).  A scan that walks several marker blocks of the SAME L_pad through one workspace
+// (a streamed file) does the W-dependent work once -- part 1: header, digits of W, rho; 4 n_pad^2 S bytes written -- and per block
+// only part 2: q zeroed, ONE pass over the block's genotypes (a = Mt8 v, the diagonal term, m^T rho).
+extern "C" int eagle_dev_vara_i8_prepare_part(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu,
+                                              int nslices, void* ws, const double* v, double* a_out, void* stream, int part) {
     int rc = vara_i8_check(ctx, L_pad, n_pad, ld, nslices);
     if (rc) return rc;
     if (L_pad == 0) return EAGLE_OK;
@@ -1538,25 +1541,36 @@ extern "C" int eagle_dev_vara_i8_prepare(eagle_ctx* ctx, const int8_t* Mt8, long
     double* dW = (double*)((char*)ws + ws_dw_off(L_pad, smax));
     double* vdiag = (double*)((char*)ws + ws_vd_off(n_pad, L_pad, smax));
     int8_t* Bs = (int8_t*)((char*)ws + ws_bs_off(n_pad, L_pad, smax));
-    hipError_t e = hipMemsetAsync(ws, 0, ws_dw_off(L_pad, smax), s);  // header and q
-    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "vara_i8 memset");
-    hipLaunchKernelGGL(k_absmax_offdiag, dim3(1024), dim3(256), 0, s, Wu, n_pad, (unsigned long long*)&hdr->maxabs_off);
-    hipLaunchKernelGGL(k_vara_prep, dim3(1), dim3(256), 0, s, Wu, n_pad, nslices, hdr, dW);
-    // correction terms of the re-centred markers: rho and R from Wu, m^T rho from the genotype pass
-    double* mrho = (double*)((char*)ws + ws_mr_off(n_pad, L_pad, smax));
     double* rho = (double*)((char*)ws + ws_rho_off(n_pad, L_pad, smax));
-    double* colpart = (double*)((char*)ws + ws_cp_off(n_pad, L_pad, smax));
-    hipLaunchKernelGGL(k_rho_rows, dim3((unsigned)n_pad), dim3(256), 0, s, Wu, n_pad, rho);
-    hipLaunchKernelGGL(k_rho_cols, dim3((unsigned)(n_pad / 256), (unsigned)(n_pad / 256)), dim3(256), 0, s, Wu, n_pad, colpart);
-    hipLaunchKernelGGL(k_rho_final, dim3(1), dim3(1024), 0, s, colpart, n_pad, rho, hdr);
-    // ONE pass over the genotypes: a = Mt8 v (if asked for; a NULL a_out drops it), the diagonal term, and m^T rho
-    rc = eagle_dev_gemv3_i8(ctx, Mt8, L_pad, n_pad, ld, v ? v : dW, dW, rho, 1.0, v ? a_out : nullptr, vdiag, mrho, stream);
-    if (rc) return rc;
-    dim3 g2((unsigned)(n_pad / 32), (unsigned)(n_pad / 32));
-    hipLaunchKernelGGL(k_slice_w, g2, dim3(256), 0, s, Wu, n_pad, hdr, Bs, vara_piped(ctx, n_pad) ? 1 : 0);
+    hipError_t e = part == 2 ? hipMemsetAsync((char*)ws + ws_q_off(), 0, ws_dw_off(L_pad, smax) - ws_q_off(), s)   // q only
+                             : hipMemsetAsync(ws, 0, ws_dw_off(L_pad, smax), s);                                     // header and q
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "vara_i8 memset");
+    if (part != 2) {
+        hipLaunchKernelGGL(k_absmax_offdiag, dim3(1024), dim3(256), 0, s, Wu, n_pad, (unsigned long long*)&hdr->maxabs_off);
+        hipLaunchKernelGGL(k_vara_prep, dim3(1), dim3(256), 0, s, Wu, n_pad, nslices, hdr, dW);
+        // correction terms of the re-centred markers: rho and R from Wu, m^T rho from the genotype pass
+        double* colpart = (double*)((char*)ws + ws_cp_off(n_pad, L_pad, smax));
+        hipLaunchKernelGGL(k_rho_rows, dim3((unsigned)n_pad), dim3(256), 0, s, Wu, n_pad, rho);
+        hipLaunchKernelGGL(k_rho_cols, dim3((unsigned)(n_pad / 256), (unsigned)(n_pad / 256)), dim3(256), 0, s, Wu, n_pad, colpart);
+        hipLaunchKernelGGL(k_rho_final, dim3(1), dim3(1024), 0, s, colpart, n_pad, rho, hdr);
+    }
+    if (part != 1) {
+        // ONE pass over the genotypes: a = Mt8 v (if asked for; a NULL a_out drops it), the diagonal term, and m^T rho
+        double* mrho = (double*)((char*)ws + ws_mr_off(n_pad, L_pad, smax));
+        rc = eagle_dev_gemv3_i8(ctx, Mt8, L_pad, n_pad, ld, v ? v : dW, dW, rho, 1.0, v ? a_out : nullptr, vdiag, mrho, stream);
+        if (rc) return rc;
+    }
+    if (part != 2) {
+        dim3 g2((unsigned)(n_pad / 32), (unsigned)(n_pad / 32));
+        hipLaunchKernelGGL(k_slice_w, g2, dim3(256), 0, s, Wu, n_pad, hdr, Bs, vara_piped(ctx, n_pad) ? 1 : 0);
+    }
     e = hipGetLastError();
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "vara_i8_prepare");
     return EAGLE_OK;
+}
+extern "C" int eagle_dev_vara_i8_prepare(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu,
+                                         int nslices, void* ws, const double* v, double* a_out, void* stream) {
+    return eagle_dev_vara_i8_prepare_part(ctx, Mt8, L_pad, n_pad, ld, Wu, nslices, ws, v, a_out, stream, 0);
 }
 
 // Phase 2: the int8 MFMA kernel over all (marker tile, slice) workers + the S-term finish.

@@ -30,6 +30,9 @@ int eagle_dev_vara_f64_split(eagle_ctx* ctx, const int8_t* rows8, long rows_cap,
 long eagle_upper_tiles_count(long n_pad);  // int32 elements of the packed upper 256-tiles of an n_pad x n_pad matrix
 int eagle_dev_tiles_pack(eagle_ctx* ctx, int32_t* C32, long n_pad, int32_t* packed, int unpack, void* stream);
 int eagle_dev_add_i32(eagle_ctx* ctx, int32_t* dst, const int32_t* src, long count, void* stream);
+// eagle_dev_vara_i8_prepare in parts: 0 = all of it, 1 = the W-dependent part only (once per scan), 2 = the block part only
+int eagle_dev_vara_i8_prepare_part(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu, int nslices, void* ws,
+                                   const double* v, double* a_out, void* stream, int part);
 int eagle_dev_cert_accumulate(eagle_ctx* ctx, const void* cert_ws, long* totals_dev, void* stream);
 // certification of a scan cut into marker blocks / device shards against ONE lower bound (eagle_i8mfma.hip, "The same certification ...")
 int eagle_dev_cert_bounds(eagle_ctx* ctx, long L, long L_pad, long n_pad, const int8_t* cshift, const int32_t* l1norm, int nslices,

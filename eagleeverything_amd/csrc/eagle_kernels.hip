@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) void k_fold_upper(double* __restrict__ W, long
 __global__ __launch_bounds__(256) void k_sym_check(const double* __restrict__ A, const double* __restrict__ B, long np,
                                                    int* __restrict__ sym) {
     const long bj = (long)blockIdx.y * 32, bk = (long)blockIdx.x * 32;
-    if (bk <= bj) return;
+    if (bk < bj) return;  // (the diagonal 32-tiles too: round 3 found an asymmetry inside one of them going unnoticed)
     __shared__ double t2[2][32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int r = ty; r < 32; r += 8) {
@@ -843,6 +843,193 @@ __global__ __launch_bounds__(256) void k_gemm_f64_tail(const double* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_gemm_f64_dma (round 3; the W = S (V S) products at n_pad % 256 == 0): C = A * B on 256 x 128 output tiles,
+// operands global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no VGPR staging, no ds_write), XOR-swizzled unpadded tiles,
+// fragments software-pipelined by half K blocks, ONE barrier per K block placed inside a run of MFMAs.
+//   8 waves (4 x 2), wave tile 64 x 64 = 4 x 4 MFMA tiles (128 accumulator VGPRs), one workgroup per CU; a 256 x 128 tile streams
+//   (256 + 128) K doubles per 256 * 128 * K MACs: 3/4 of the panel bytes of the 128 x 128 form.
+//   K block = 16.  LDS stage = A [256 rows][128 B] (32 KiB) + B [16 k][1 KiB] (16 KiB); two stages = 96 KiB.
+//   A: 16-byte chunk c (k = 2c, 2c+1) of row r lives at chunk c ^ ((r >> 1) & 7); lane (i16, g) reads chunks g and 4 + g of its
+//      row with ds_read_b128 -- the four 16-lane groups of that instruction each cover all 16 granules of a 256-byte bank line
+//      (checked by tests/test_kernel_index_maps.py) -- so lane group g owns k in {2g, 2g+1, 8+2g, 9+2g} and MFMA step s of a
+//      K block multiplies k = 2g + (s & 1) + 8 (s >> 1), g = 0..3.  (The k order inside an fp64 sum is a free choice; this one
+//      is FIXED and is the definition of this kernel's result.  It differs from k_gemm_f64_list8's {s, 4+s, 8+s, 12+s}, so the two
+//      kernels agree to rounding, not bit for bit.)
+//   B: row k is 1 KiB; its 128-byte block nt (16 columns) lives at block nt ^ ((k >> 1) & 1), so the two lane groups a
+//      ds_read_b64 serves together (k and k + 2, same columns) sit in different halves of the bank line.
+//   DMA: a wave instruction writes 1 KiB of consecutive LDS bytes; the swizzles are applied to the per-lane SOURCE offset
+//      (two VGPRs for A: even / odd groups of 8 rows; one for B: the rows 2w, 2w+1 of wave w share (k >> 1) & 1).
+//   Pipeline of K block kb (stage buffer kb & 1; X = the fragments of k-half 0, Y = of k-half 1):
+//        read Y(kb)                     | 32 MFMAs on X(kb)
+//                                       | 16 MFMAs on Y(kb)
+//        barrier  -- every wave's DMA pieces of stage kb+1 have landed (issued a whole K block ago), all reads of stage kb are done
+//        DMA stage kb+2 -> buffer of stage kb ; read X(kb+1)   | 16 MFMAs on Y(kb)
+//   Tiles: (row128 << 16) | col128 -- a tile starts at any multiple of 128 rows and covers 256; rows at or beyond `row_end` are
+//   read as zero (buffer descriptor bounds) and not stored (the last tile of a row range whose length is an odd multiple of 128).
+//   TRANS: the tile is stored transposed, C[col][row] (the symmetric-operand pipeline of eagle_dev_scan_operands).
+// ------------------------------------------------------------------------------------------------
+#define G2_TM 256
+#define G2_TN 128
+#define G2_A_BYTES (G2_TM * GF_BK * 8)
+#define G2_B_BYTES (GF_BK * G2_TN * 8)
+#define G2_STAGE (G2_A_BYTES + G2_B_BYTES)
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <bool TRANS>
+__global__ __launch_bounds__(512, 2) void k_gemm_f64_dma(const double* __restrict__ A, long lda, const double* __restrict__ B, long ldb,
+                                                         double* __restrict__ C, long ldc, long K, long row_end, const int* __restrict__ tiles,
+                                                         int n_main, int split, double* __restrict__ scratch, const int* __restrict__ skip_if,
+                                                         int skip_val) {
+    __shared__ __attribute__((aligned(1024))) char lds[2][G2_STAGE];
+    if (skip_if && *skip_if == skip_val) return;
+    const int b = blockIdx.x;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = w >> 1, wc = w & 1;
+    const int i16 = lane & 15, g = lane >> 4;
+    const long nkb_all = K / GF_BK;
+    int tile;
+    long kb0 = 0, kb1 = nkb_all;
+    double* out;
+    long ldo;
+    if (b < n_main) {
+        tile = tiles[b];
+        out = nullptr; ldo = ldc;
+    } else {
+        const int u = b - n_main, tt = u / split, ks = u - tt * split;
+        tile = tiles[n_main + tt];
+        kb0 = nkb_all * ks / split;
+        kb1 = nkb_all * (ks + 1) / split;
+        out = scratch + (long)u * (G2_TM * G2_TN);
+        ldo = G2_TN;
+    }
+    const long row0 = (long)(tile >> 16) * 128, col0 = (long)(tile & 0xffff) * 128;
+    const long rows_here = row_end - row0 < G2_TM ? row_end - row0 : G2_TM;
+    const int lda8 = (int)(lda * 8), ldb8 = (int)(ldb * 8);
+    // A: rows of this tile, all K (256 * lda * 8 bytes < 2^32); B: re-based per K block (16 rows), columns of this tile
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(A + row0 * lda), 0, (int)(rows_here * lda8), 0x00020000);
+    const int voffAE = (lane >> 3) * lda8 + (((lane & 7) ^ (lane >> 4)) << 4), voffAO = voffAE ^ 64;
+    const int voffB = (((lane >> 3) ^ (w & 1)) << 7) + ((lane & 7) << 4);
+    auto dma = [&](long kb, char* st) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int grp = w * 4 + i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(st + grp * 1024), 16, (i & 1) ? voffAO : voffAE,
+                                                     grp * 8 * lda8 + (int)(kb * GF_BK * 8), 0, 0);
+        }
+        const __amdgpu_buffer_rsrc_t rsB =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(B + kb * GF_BK * ldb + col0), 0, GF_BK * ldb8, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int k = w * 2 + i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(st + G2_A_BYTES + k * 1024), 16, voffB, k * ldb8, 0, 0);
+        }
+    };
+    // fragment addresses: per-lane LDS pointers of both stages, made once -- inside the K loop every read is a base register + an
+    // immediate offset and the loop counters are scalar ints: a vector instruction between two fp64 MFMAs of a wave costs about 6
+    // of the matrix pipe's cycles even with a second wave on the SIMD (tools/ubench/f64_ceiling.hip: 0.99 of the peak with no VALU
+    // in the loop, 0.92 with one v_mov per MFMA), so the loop holds nothing but fragment reads, DMA issues and MFMAs
+    const int offA = (wr * 64 + i16) * 128 + ((g ^ (i16 >> 1)) << 4);  // chunk g of row wr*64 + m*16 + i16 (+ m * 2048); chunk 4+g: ^ 64
+    const int offB = G2_A_BYTES + (2 * g) * 1024 + i16 * 8;             // row k = 2g (+ 1024 for k+1, + 8192 for the second k-half)
+    const char* pAx[2] = {lds[0] + offA, lds[1] + offA};
+    const char* pAy[2] = {lds[0] + (offA ^ 64), lds[1] + (offA ^ 64)};
+    const char* pB[2][4];
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        const int blk = ((wc * 4 + n) ^ (g & 1)) << 7;
+        pB[0][n] = lds[0] + offB + blk;
+        pB[1][n] = lds[1] + offB + blk;
+    }
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < 4; n++) acc[m][n] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    f64x2 ax[4], ay[4];
+    double bx[4][2], by[4][2];
+#define G2_READ_X(ST)                                                              \
+    do {                                                                           \
+        _Pragma("unroll") for (int m = 0; m < 4; m++) ax[m] = *(const f64x2*)(pAx[ST] + m * 2048); \
+        _Pragma("unroll") for (int n = 0; n < 4; n++) {                            \
+            bx[n][0] = *(const double*)(pB[ST][n]);                                \
+            bx[n][1] = *(const double*)(pB[ST][n] + 1024);                         \
+        }                                                                          \
+    } while (0)
+#define G2_READ_Y(ST)                                                              \
+    do {                                                                           \
+        _Pragma("unroll") for (int m = 0; m < 4; m++) ay[m] = *(const f64x2*)(pAy[ST] + m * 2048); \
+        _Pragma("unroll") for (int n = 0; n < 4; n++) {                            \
+            by[n][0] = *(const double*)(pB[ST][n] + 8192);                         \
+            by[n][1] = *(const double*)(pB[ST][n] + 8192 + 1024);                  \
+        }                                                                          \
+    } while (0)
+#define G2_MFMA(A_, B_, M0, M1)                                                    \
+    do {                                                                           \
+        _Pragma("unroll") for (int e = 0; e < 2; e++)                              \
+            _Pragma("unroll") for (int m = M0; m < M1; m++)                        \
+                _Pragma("unroll") for (int n = 0; n < 4; n++)                      \
+                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(A_[m][e], B_[n][e], acc[m][n], 0, 0, 0); \
+    } while (0)
+    // one K block on stage buffer ST: `next` = there is a K block after this one, `next2` = and one after that
+#define G2_KBLOCK(ST, kb_, next, next2)                                            \
+    do {                                                                           \
+        G2_READ_Y(ST);                                                             \
+        G2_MFMA(ax, bx, 0, 4);                                                     \
+        G2_MFMA(ay, by, 0, 2);                                                     \
+        __syncthreads(); /* this wave's DMA of the next stage (vmcnt) and its reads of this one (lgkmcnt), then the barrier */ \
+        if (next2) dma((kb_) + 2, lds[ST]);                                        \
+        if (next) G2_READ_X((ST) ^ 1);                                             \
+        G2_MFMA(ay, by, 2, 4);                                                     \
+    } while (0)
+    const int nkb = (int)(kb1 - kb0);
+    dma(kb0, lds[0]);
+    __syncthreads();
+    G2_READ_X(0);
+    if (nkb > 1) dma(kb0 + 1, lds[1]);
+    int i = 0;
+    for (; i + 2 <= nkb; i += 2) {   // two K blocks per trip: the stage buffer of every read is a compile-time constant
+        G2_KBLOCK(0, kb0 + i, true, i + 2 < nkb);
+        G2_KBLOCK(1, kb0 + i + 1, i + 2 < nkb, i + 3 < nkb);
+    }
+    if (i < nkb) G2_KBLOCK(0, kb0 + i, false, false);
+#undef G2_KBLOCK
+#undef G2_MFMA
+#undef G2_READ_X
+#undef G2_READ_Y
+    // C/D map of v_mfma_f64_16x16x4: lane (i16, g), register q holds row g + 4 q, column i16 of the 16 x 16 tile
+    double* dst = out ? out : C;
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < 4; n++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const long rl = wr * 64 + m * 16 + g + 4 * q, cl = wc * 64 + n * 16 + i16;
+                if (rl >= rows_here) continue;
+                if (out) dst[rl * ldo + cl] = acc[m][n][q];
+                else if (TRANS) dst[(col0 + cl) * ldc + row0 + rl] = acc[m][n][q];
+                else dst[(row0 + rl) * ldc + col0 + cl] = acc[m][n][q];
+            }
+}
+// partial tiles of the split-K tail added in ascending K order (fixed: deterministic); 32 workgroups per tile, 8 rows each
+template <bool TRANS>
+__global__ __launch_bounds__(256) void k_gemm_f64_dma_tail(const double* __restrict__ scratch, const int* __restrict__ tail_tiles, int split,
+                                                           double* __restrict__ C, long ldc, long row_end, const int* __restrict__ skip_if, int skip_val) {
+    if (skip_if && *skip_if == skip_val) return;
+    const int tile = tail_tiles[blockIdx.x >> 5], part = blockIdx.x & 31;
+    const long row0 = (long)(tile >> 16) * 128, col0 = (long)(tile & 0xffff) * 128;
+    const double* src = scratch + (long)(blockIdx.x >> 5) * split * (G2_TM * G2_TN);
+    for (int e = part * 1024 + threadIdx.x; e < (part + 1) * 1024; e += 256) {
+        double s = src[e];
+        for (int k = 1; k < split; k++) s += src[(long)k * (G2_TM * G2_TN) + e];
+        const long rl = e >> 7, cl = e & 127;
+        if (row0 + rl >= row_end) continue;
+        if (TRANS) C[(col0 + cl) * ldc + row0 + rl] = s;
+        else C[(row0 + rl) * ldc + col0 + cl] = s;
+    }
+}
+
 // device tile lists, cached per (device, tiles per side, kind): 0 = all tiles, 1 = row tile <= column tile, 2 = row tile > column tile
 #include <map>
 #include <mutex>
@@ -883,9 +1070,88 @@ static int gemm_tile_list(eagle_ctx* ctx, int nt, int kind, int rt0, int rt1, co
     return EAGLE_OK;
 }
 
+// Tile list of k_gemm_f64_dma: 256-row tiles starting at 128-row tile rt0, rt0 + 2, ... (the last may be half inside [rt0, rt1)),
+// 128-column tiles; kind 0 = all, 1 = tiles holding an element on or above the diagonal (column tile >= first row tile),
+// 2 = the others.  Row tile outer: consecutive workgroups share an A row panel.
+static int gemm_dma_tile_list(eagle_ctx* ctx, int nt, int kind, int rt0, int rt1, const int** out, long* count) {
+    std::lock_guard<std::mutex> lock(g_gemm_lists_mutex);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    auto key = std::make_tuple(dev, nt, kind | 256, rt0, rt1);
+    auto it = g_gemm_lists.find(key);
+    if (it != g_gemm_lists.end()) { *out = it->second.first; *count = it->second.second; return EAGLE_OK; }
+    std::vector<int> h;
+    for (int i = rt0; i < rt1; i += 2)
+        for (int j = 0; j < nt; j++)
+            if (kind == 0 || (kind == 1 && j >= i) || (kind == 2 && j < i)) h.push_back((i << 16) | j);
+    int* d = nullptr;
+    if (!h.empty()) {
+        hipError_t e = hipMalloc((void**)&d, h.size() * sizeof(int));
+        if (e != hipSuccess) return eagle_fail_hip(ctx, e, "gemm tile list alloc");
+        e = hipMemcpy(d, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(d); return eagle_fail_hip(ctx, e, "gemm tile list copy"); }
+    }
+    g_gemm_lists[key] = std::make_pair(d, (long)h.size());
+    *out = d;
+    *count = (long)h.size();
+    return EAGLE_OK;
+}
+// C[rows rt0*128 .. rt1*128) = A * B on k_gemm_f64_dma (n_pad % 256 == 0); trans: C^T is written instead (C[col][row]).
+static int gemm_f64_dma_tiles(eagle_ctx* ctx, const double* A, const double* B, double* C, long np, int kind, const int* skip_if, int skip_val,
+                              void* stream, int rt0, int rt1, bool trans) {
+    const int* tiles = nullptr;
+    long count = 0;
+    int rc = gemm_dma_tile_list(ctx, (int)(np / 128), kind, rt0, rt1, &tiles, &count);
+    if (rc || count == 0) return rc;
+    const long slots = ctx->cu_count > 0 ? ctx->cu_count : 256;  // one workgroup per CU
+    const long n_main = count / slots * slots, tail = count - n_main;
+    const long nkb = np / GF_BK;
+    int split = 1;
+    if (tail > 0) {
+        double best = 1.0;
+        for (int sp = 2; sp <= 8; sp++) {
+            if (nkb / sp < 8 || (double)tail * sp * G2_TM * G2_TN * 8.0 > 256e6) break;
+            const double cost = (double)((tail * sp + slots - 1) / slots) / sp;
+            if (cost < best - 1e-9) { best = cost; split = sp; }
+        }
+    }
+    double* scratch = nullptr;
+    if (split > 1) {
+        const size_t need = (size_t)tail * split * G2_TM * G2_TN * sizeof(double);
+        if (need > ctx->gemm_scratch_cap) {
+            if (ctx->gemm_scratch) { (void)hipStreamSynchronize((hipStream_t)stream); (void)hipFree(ctx->gemm_scratch); ctx->gemm_scratch = nullptr; ctx->gemm_scratch_cap = 0; }
+            hipError_t e = hipMalloc(&ctx->gemm_scratch, need);
+            if (e != hipSuccess) return eagle_fail_hip(ctx, e, "gemm scratch");
+            ctx->gemm_scratch_cap = need;
+        }
+        scratch = (double*)ctx->gemm_scratch;
+    }
+    const long blocks = split > 1 ? n_main + tail * split : count;
+    const long row_end = (long)rt1 * 128;
+    const int nm = (int)(split > 1 ? n_main : count);
+    if (trans) {
+        hipLaunchKernelGGL((k_gemm_f64_dma<true>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, A, np, B, np, C, np, np, row_end, tiles, nm, split,
+                           scratch, skip_if, skip_val);
+        if (split > 1)
+            hipLaunchKernelGGL((k_gemm_f64_dma_tail<true>), dim3((unsigned)(tail * 32)), dim3(256), 0, (hipStream_t)stream, scratch, tiles + n_main, split, C, np,
+                               row_end, skip_if, skip_val);
+    } else {
+        hipLaunchKernelGGL((k_gemm_f64_dma<false>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, A, np, B, np, C, np, np, row_end, tiles, nm, split,
+                           scratch, skip_if, skip_val);
+        if (split > 1)
+            hipLaunchKernelGGL((k_gemm_f64_dma_tail<false>), dim3((unsigned)(tail * 32)), dim3(256), 0, (hipStream_t)stream, scratch, tiles + n_main, split, C, np,
+                               row_end, skip_if, skip_val);
+    }
+    LAUNCH_CHECK(ctx);
+    return EAGLE_OK;
+}
+
 static int gemm_f64_tiles(eagle_ctx* ctx, const double* A, const double* B, double* C, long np, int kind, const int* skip_if, int skip_val,
                           void* stream, int rt0 = 0, int rt1 = -1) {
     if (np % GF_T || np <= 0 || np / GF_T > 65535) return eagle_fail(ctx, EAGLE_ERR_ARG, "gemm_f64: size must be a multiple of 128");
+    // n_pad % 256 == 0 (every size eagle_pad produces): the 256 x 128 LDS-DMA kernel; tune 21..27 keep the 128 x 128 forms for A/B runs
+    if (np % 256 == 0 && 256 * np * 8 < 2147483648L && !(ctx->tune >= 21 && ctx->tune <= 27))
+        return gemm_f64_dma_tiles(ctx, A, B, C, np, kind, skip_if, skip_val, stream, rt0, rt1 < 0 ? (int)(np / GF_T) : rt1, false);
     const int* tiles = nullptr;
     long count = 0;
     if (rt1 < 0) rt1 = (int)(np / GF_T);
@@ -925,7 +1191,7 @@ static int gemm_f64_tiles(eagle_ctx* ctx, const double* A, const double* B, doub
         case 23: GEMM_LAUNCH(GF_LDA, 1); break;  // XCD-contiguous 8 x 8 super-tile order: neutral
         case 24: GEMM_LAUNCH(18, 1); break;
         case 26: GEMM_LAUNCH(GF_LDA, 0); break;  // four waves per tile, pitch 20 (shipped until the eight-wave form)
-        default:  // eight waves per tile: 50.4 -> 48.4 ms for W at n = 10,000 (66.6 TF incl. v, symmetry check, fold), same bits
+        default:  // (tune 25, and sizes that are not a multiple of 256) eight waves per tile: 50.4 -> 48.4 ms for W at n = 10,000 (66.6 TF incl. v, symmetry check, fold), same bits
             hipLaunchKernelGGL((k_gemm_f64_list8<GF_LDA>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, A, np, B, np, C, np, np, tiles,
                                (int)(split > 1 ? n_main : count), split, scratch, skip_if, skip_val);
     }

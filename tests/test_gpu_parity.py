@@ -788,14 +788,17 @@ def test_config_C3_shape_single_gpu(api, oracle):
     assert float(mx) == float(MMt.max())
 
 
-def test_dev_gemm_f64_layout(api):
-    """The fp64 MFMA fragment maps, checked with asymmetric integer-valued data (exact in fp64)."""
+@pytest.mark.parametrize("n", [256, 384, 768, 1280, 2816])
+def test_dev_gemm_f64_layout(api, n):
+    """The fp64 MFMA fragment maps, the LDS-DMA swizzles and the split-K tail of the GEMM kernels, checked with asymmetric
+    integer-valued data (exact in fp64, so any summation order must give the same bits): k_gemm_f64_dma (256 x 128 tiles) for
+    multiples of 256 -- 2816 is 242 tiles, all of them in the split-K tail; 1280 has whole tiles only -- and the 128 x 128 form
+    for 384."""
     import torch
     from eagleeverything_amd import _lib
     L = _lib.load()
     ctx = api.context(0)
-    n = 256
-    rng = np.random.default_rng(0)
+    rng = np.random.default_rng(n)
     A = rng.integers(-8, 9, size=(n, n)).astype(np.float64)
     B = rng.integers(-8, 9, size=(n, n)).astype(np.float64)
     dA = torch.from_numpy(A).cuda(); dB = torch.from_numpy(B).cuda(); dC = torch.zeros((n, n), dtype=torch.float64, device="cuda")
@@ -804,6 +807,44 @@ def test_dev_gemm_f64_layout(api):
     assert rc == 0
     torch.cuda.synchronize()
     np.testing.assert_array_equal(dC.cpu().numpy(), A @ B)
+
+
+@pytest.mark.parametrize("n", [500, 1400])
+def test_scan_operands_products_exact_on_integer_operands(api, n):
+    """W = S (V S) and v = S a_hat through eagle_dev_scan_operands (symmetric operands: upper tiles + fold), through the general
+    path (non-symmetric V: both triangles from memory) and through eagle_dev_scan_operands_rows (row blocks whose length is an odd
+    multiple of 128: the half tile at the end of a range) on small-integer matrices, where every product and sum is exact in fp64:
+    the folded image must equal numpy's bit for bit whatever the tile shape or summation order."""
+    import torch
+    from eagleeverything_amd.sharded import DeviceShard
+    sh = DeviceShard(n, 256)
+    np_ = sh.np_
+    rng = np.random.default_rng(n)
+    S = rng.integers(-3, 4, size=(n, n)).astype(np.float64); S = S + S.T
+    V = rng.integers(-3, 4, size=(n, n)).astype(np.float64); V = V + V.T
+    ahat = rng.integers(-4, 5, size=n).astype(np.float64)
+    for sym in (True, False):
+        Vx = V.copy()
+        if not sym:
+            Vx[1, 0] += 5.0
+        W = S @ Vx @ S
+        fold = np.triu(W, 1) + np.tril(W, -1).T + np.diag(np.diag(W))
+        sh.set_operands(S, Vx, ahat)
+        sh.scan_operands(None)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(sh.Wu[:n, :n].cpu().numpy(), fold)
+        assert float(sh.Wu[n:, :].abs().max()) == 0.0 and float(sh.Wu[:, n:].abs().max()) == 0.0
+        np.testing.assert_array_equal(sh.v[:n].cpu().numpy(), S @ ahat)
+        # rows of the W^T image in three ranges with odd 128-row counts
+        Wt = torch.zeros((np_, np_), dtype=torch.float64, device=sh.dev)
+        cuts = [0, 128, np_ - 384 if np_ >= 768 else 256, np_]
+        for r0, r1 in zip(cuts[:-1], cuts[1:]):
+            if r0 >= r1:
+                continue
+            sh._check(sh.L.eagle_dev_scan_operands_rows(sh.ctx, sh.Sa.data_ptr(), sh.Va.data_ptr(), sh.ahat.data_ptr(), n, np_, r0, r1,
+                                                        sh.v.data_ptr(), Wt.data_ptr(), sh.tmp.data_ptr(), sh._stream()))
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(Wt[:n, :n].cpu().numpy(), W.T)
 
 
 @pytest.mark.parametrize("n", [3001, 3100, 3500])

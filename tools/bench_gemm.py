@@ -9,7 +9,8 @@ from eagleeverything_amd import _lib
 from eagleeverything_amd.sharded import DeviceShard
 
 n = int(os.environ.get("N", 10000))
-variants = [int(v) for v in os.environ.get("VARIANTS", "0,26,21,22,23").split(",")]
+# 0 = shipped (k_gemm_f64_dma, 256 x 128 tiles, LDS-DMA, round 3); 25 = eight waves per 128 x 128 tile (shipped in round 2); 26 = four waves
+variants = [int(v) for v in os.environ.get("VARIANTS", "0,25,26").split(",")]
 lib = _lib.load()
 sh = DeviceShard(n, 256)
 gen = torch.Generator(device=sh.dev); gen.manual_seed(1)
@@ -18,6 +19,7 @@ Sm = torch.eye(n, dtype=torch.float64, device=sh.dev) * 0.4 + A @ A.T
 V = 0.5 * torch.eye(n, dtype=torch.float64, device=sh.dev) - 0.01 * (A[:, :8] @ A[:, :8].T)
 sh.set_operands(Sm, V, torch.randn(n, generator=gen, device=sh.dev, dtype=torch.float64))
 ref = None
+refs = {}
 res = {v: [] for v in variants}
 for rnd in range(5):
     for v in variants:
@@ -26,9 +28,10 @@ for rnd in range(5):
         e0.record(); sh.scan_operands(); e1.record()
         torch.cuda.synchronize()
         if ref is None: ref = sh.Wu.clone()
-        elif v in (23, 24):  # another tile order puts other tiles into the split-K tail: same sums, another rounding
-            assert torch.allclose(ref, sh.Wu, rtol=1e-12, atol=1e-13), "variant %d differs" % v
-        else: assert torch.equal(ref, sh.Wu), "variant %d differs" % v
+        if v not in refs: refs[v] = sh.Wu.clone()
+        assert torch.equal(refs[v], sh.Wu), "variant %d is not reproducible" % v      # every variant: the same bits on every run
+        # different kernels / tile orders sum in different (fixed) orders: agreement to rounding
+        assert torch.allclose(ref, sh.Wu, rtol=1e-12, atol=1e-13 * float(ref.abs().max())), "variant %d differs" % v
         if rnd: res[v].append(e0.elapsed_time(e1))
 lib.eagle_dev_set_tune(sh.ctx, 0)
 flops = 3.0 * sh.np_ ** 3
