@@ -415,6 +415,7 @@ def parse_args(argv=None):
     ap.add_argument("--mmt-reps", type=int, default=2)
     ap.add_argument("--cpu-sample", type=int, default=32768, help="markers in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary entries (C2, fp64 mode, 7 digits)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the reference-shaped (host files -> host results) secondary leg")
     ap.add_argument("--simple-operands", action="store_true", help="seeded random SPD S / V instead of the model algebra")
     ap.add_argument("--save-operands", default=None, help="write S, V, a_hat (torch.save) after computing them")
     ap.add_argument("--load-operands", default=None, help="read S, V, a_hat written by --save-operands (used by the PMC passes of\n                    tools/profile_gpu.sh: rocSOLVER's eigh crashes under rocprofv3 counter collection)")
@@ -577,7 +578,7 @@ def main():
     secondary = {
         "step_breakdown_ms": {"W=S*V*S (+all-gather)": parts["w"] * 1e3, "prepare (slice W, genotype pass)": parts["prep"] * 1e3,
                               "vara kernel": parts["kern"] * 1e3, "certify": parts["cert"] * 1e3},
-        "w_product": {"bound": "mfma", "kernel": "k_gemm_f64_list (v_mfma_f64_16x16x4_f64), S*(V*S), upper tiles of the 2nd product",
+        "w_product": {"bound": "mfma", "kernel": "k_gemm_f64_dma (v_mfma_f64_16x16x4_f64, 256 x 128 tiles, LDS-DMA): X = V*S in 1024-row blocks, then the tiles of S*X on or below the diagonal, transposed",
                       "achieved": w_flops / parts["w"] / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                       "frac": w_flops / parts["w"] / 1e12 / FP64_MFMA_PEAK_TFLOPS, "ms": parts["w"] * 1e3,
                       "note": "includes v = S a_hat, the symmetry check, the fold and (N > 1) the all-gather of W's rows"},
@@ -596,13 +597,20 @@ def main():
     cpu = None
     parity = None
     if rank == 0 and world == 1 and args.cpu_sample > 0:
-        # the box gives one GPU a 16-core share of the host: keep the baseline inside it
+        # the C port of the reference's in-memory branch on ALL host cores of the GPU box (count read here and stated), with the
+        # 16-thread figure (the share of the host one GPU of the box gets) kept beside it, and -- BASELINE.md section 3 --
+        # numpy's @ on its bundled OpenBLAS as the secondary baseline.  Bounded marker samples: ~10 + 5 + 10 s of CPU work.
         from oracle import oracle_c  # checker / baseline only
         oracle_c.build()
-        oracle_c.set_num_threads(int(os.environ.get("OMP_NUM_THREADS", min(16, os.cpu_count() or 1))))
+        host_cores = os.cpu_count() or 1
+        try:
+            usable = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            usable = host_cores
         ns = min(args.cpu_sample, Lloc)
         Mt_s = sh.Mt8[:ns, :n].cpu().numpy()
         Sh, Vh, ah = run.S.cpu().numpy(), run.V.cpu().numpy(), run.ahat.cpu().numpy()
+        oracle_c.set_num_threads(int(os.environ.get("OMP_NUM_THREADS", host_cores)))
         v_h, W_h = oracle_c.scan_operands(Sh, Vh, ah)          # n^3 part, done once per call in the reference too
         tc = time.perf_counter()
         a_ref, vara_ref = oracle_c.scan_from_i8_with_W(Mt_s, v_h, W_h)
@@ -611,7 +619,32 @@ def main():
         cpu = {"value": ns / cpu_s, "unit": "markers/s", "cores": cores, "kind": "port",
                "sample": "first %d markers of the %dx%d problem, reference in-memory branch order (GEMV, T=Mt*W, row-dot; "
                          "calculate_a_and_vara_rcpp.cpp:91-112), W=S*V*S precomputed and excluded" % (ns, n, Ltot),
-               "seconds": cpu_s}
+               "seconds": cpu_s, "host_cores": host_cores, "cores_this_process_may_use": usable}
+        if cores != 16 and host_cores >= 16:
+            n16 = max(1024, ns // 2)
+            oracle_c.set_num_threads(16)
+            tc = time.perf_counter()
+            oracle_c.scan_from_i8_with_W(Mt_s[:n16], v_h, W_h)
+            cpu["value_16_threads"] = n16 / (time.perf_counter() - tc)
+            cpu["sample_16_threads"] = "first %d markers" % n16
+            oracle_c.set_num_threads(cores)
+        # numpy @ (OpenBLAS dgemm / dgemv) on the same sample: T = Mt W, vara_i = T_i . m_i, a = Mt v
+        try:
+            from threadpoolctl import threadpool_info
+            blas = [(i.get("internal_api"), i.get("num_threads")) for i in threadpool_info() if i.get("user_api") == "blas"]
+        except Exception:
+            blas = None
+        nb = min(ns, 16384)
+        tc = time.perf_counter()
+        Mf = Mt_s[:nb].astype(np.float64)
+        a_np = Mf @ v_h
+        T_np = Mf @ W_h
+        vara_np = np.einsum("ij,ij->i", T_np, Mf)
+        np_s = time.perf_counter() - tc
+        cpu["numpy_openblas"] = {"value": nb / np_s, "unit": "markers/s", "blas_threads": blas, "sample": "first %d markers, int8 -> float64 conversion included" % nb,
+                                 "a_max_rel_vs_port": float(np.max(np.abs(a_np - a_ref[:nb])) / np.max(np.abs(a_ref[:nb]))),
+                                 "vara_max_rel_vs_port": float(np.max(np.abs(vara_np - vara_ref[:nb]) / np.abs(vara_ref[:nb])))}
+        del Mf, T_np
         a_g = sh.a[:ns].cpu().numpy()
         v_g = sh.vara[:ns].cpu().numpy()
         rel = lambda x, r: float(np.max(np.abs(x - r)) / np.max(np.abs(r)))
@@ -634,32 +667,6 @@ def main():
     # ---- secondary entries (N = 1): fp64-mode and 7-digit scans of the headline shape, and BASELINE configs[1] --------
     if world == 1 and not args.no_secondary and sh.mode == 1:
         sel_i8 = sel
-        # the same step through the REFERENCE-SHAPED entry points (host files -> host results; what R's .Call sees), PCIe included,
-        # with the phase clock of the library: every ms between the device-resident step above and the .Call-shaped time
-        import tempfile
-        from eagleeverything_amd import synth
-        tmpd = tempfile.mkdtemp(dir=os.environ.get("TMPDIR", "/tmp"))
-        try:
-            geno = synth.write_geno_pair_sidecars(tmpd, sh)
-            sh.M8 = None   # the individual-major int8 image was only needed to write M.ascii's sidecar
-            S_h, V_h, a_h = np.asfortranarray(run.S.cpu().numpy()), np.asfortranarray(run.V.cpu().numpy()), run.ahat.cpu().numpy()
-            leg, _ = abi_leg(args, torch, geno, n, Ltot, S_h, V_h, a_h, local_rank, 3, 1)
-            a_e, v_e = leg.pop("results")
-            leg["a_bitwise_equal_to_device_resident_step"] = bool(np.array_equal(a_e, a_step.cpu().numpy()))
-            leg["vara_bitwise_equal_to_device_resident_step"] = bool(np.array_equal(v_e, vara_step.cpu().numpy()))
-            leg["selected_marker_equal"] = bool(leg["selected_marker"] == sel_i8[0])
-            leg["device_resident_step_ms"] = ms_per_step
-            leg["gap_ms (call - device-resident step)"] = leg["ms_per_call"] - ms_per_step
-            leg["note"] = ("PCIe-inclusive and never `value`: per call V (8 n^2 bytes) up, S up and compared with the device copy of the last call "
-                           "under the n^3 products, a_hat up, a and vara (16 bytes per marker) down; genotypes resident after the cold call "
-                           "(loaded from the 2-bit sidecars beside sparse text placeholders)")
-            secondary["e2e_reference_shaped"] = leg
-            del S_h, V_h, a_e, v_e
-        finally:
-            for f in os.listdir(tmpd):
-                os.unlink(os.path.join(tmpd, f))
-            os.rmdir(tmpd)
-            rcpp_api.drop_cache(local_rank)
         sh.mode = 0
         s64, el64, p64 = run.timed(1, 1)
         secondary["scan_fp64_mode"] = {"value": Ltot / el64, "unit": "markers/s", "ms_per_step": el64 * 1e3,
@@ -750,6 +757,38 @@ def main():
                                           "note": "opt-in entry points (include/eagle_hip.h 1d): needs U, lambda of the normalised MM^T and an R-side "
                                                   "change; K is fixed during an AM() run, so Z = Mt U is built once and each scan is one pass over Z"}
             del Z, lin, quad
+        # (after the other secondary entries: the 35 GB this leg allocates and frees outside torch's allocator leave the card's memory
+        # fragmented, and an 82 GB buffer allocated after it made the HBM-bound spectral pass 50 % slower -- 21 against 14 ms)
+        # the same step through the REFERENCE-SHAPED entry points (host files -> host results; what R's .Call sees), PCIe included,
+        # with the phase clock of the library: every ms between the device-resident step above and the .Call-shaped time
+        import tempfile
+        from eagleeverything_amd import synth
+        tmpd = tempfile.mkdtemp(dir=os.environ.get("TMPDIR", "/tmp"))
+        try:
+            if args.no_e2e:
+                raise StopIteration
+            geno = synth.write_geno_pair_sidecars(tmpd, sh)
+            sh.M8 = None   # the individual-major int8 image was only needed to write M.ascii's sidecar
+            S_h, V_h, a_h = np.asfortranarray(run.S.cpu().numpy()), np.asfortranarray(run.V.cpu().numpy()), run.ahat.cpu().numpy()
+            leg, _ = abi_leg(args, torch, geno, n, Ltot, S_h, V_h, a_h, local_rank, 3, 1)
+            a_e, v_e = leg.pop("results")
+            leg["a_bitwise_equal_to_device_resident_step"] = bool(np.array_equal(a_e, a_step.cpu().numpy()))
+            leg["vara_bitwise_equal_to_device_resident_step"] = bool(np.array_equal(v_e, vara_step.cpu().numpy()))
+            leg["selected_marker_equal"] = bool(leg["selected_marker"] == sel_i8[0])
+            leg["device_resident_step_ms"] = ms_per_step
+            leg["gap_ms (call - device-resident step)"] = leg["ms_per_call"] - ms_per_step
+            leg["note"] = ("PCIe-inclusive and never `value`: per call V (8 n^2 bytes) up, S up and compared with the device copy of the last call "
+                           "under the n^3 products, a_hat up, a and vara (16 bytes per marker) down; genotypes resident after the cold call "
+                           "(loaded from the 2-bit sidecars beside sparse text placeholders)")
+            secondary["e2e_reference_shaped"] = leg
+            del S_h, V_h, a_e, v_e
+        except StopIteration:
+            pass
+        finally:
+            for f in os.listdir(tmpd):
+                os.unlink(os.path.join(tmpd, f))
+            os.rmdir(tmpd)
+            rcpp_api.drop_cache(local_rank)
         # BASELINE configs[1]: 5,000 x 500,000 on one card
         del run, sh
         torch.cuda.empty_cache()

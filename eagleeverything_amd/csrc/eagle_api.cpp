@@ -1141,11 +1141,13 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
             if ((r = upload_square(ctx, inv_MMt_sqrt, n, np, Wu))) return r;
             if ((r = upload_vec(ctx, a, n, np, v))) return r;
         } else {
-            // V and a_hat first: the first product needs all of V.  S = inv_MMt_sqrt is MMt^-1/2, the same matrix in every call of an
-            // AM() run, but R builds it anew each time (no pointer identity, and hashing 800 MB costs what copying them costs): the
-            // copy of the last call stays on the device, this call computes on it at once, and the caller's matrix is uploaded on
-            // the loader stream and compared bit for bit while the n^3 product runs; a difference starts the product over (below).
-            if ((r = upload_square(ctx, dim_reduced_vara, n, np, Va))) return r;
+            // S = inv_MMt_sqrt is MMt^-1/2, the same matrix in every call of an AM() run, but R builds it anew each time (no pointer
+            // identity, and hashing 800 MB costs what copying them costs): the copy of the last call stays on the device, this call
+            // computes on it at once, and the caller's matrix is uploaded on the loader stream and compared bit for bit while the
+            // n^3 products run; a difference starts the products over (below).  V changes with every call; it arrives in row
+            // blocks on the loader stream UNDER the first product, which works on the rows that have landed (below) -- unless the
+            // rows of W are shared between devices (share_w: the row-block product there needs all of V at once).
+            if (share_w && (r = upload_square(ctx, dim_reduced_vara, n, np, Va))) return r;
             if ((r = upload_vec(ctx, a, n, np, ah))) return r;
             const bool cacheable = !share_w && np <= 16384 && !getenv("EAGLE_HIP_NO_SCACHE");
             if (cacheable && ctx->scache_np != np) {
@@ -1184,7 +1186,33 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
         if (nr != ncclSuccess) rc = failf(ctx, EAGLE_ERR_HIP, "ncclAllGather: %s", rccl->GetErrorString(nr));
         if (!rc) rc = eagle_dev_fold_upper(ctx, Wu, np, ctx->stream);
     } else if (!rc) {
-        rc = w_direct ? eagle_dev_fold_upper(ctx, Wu, np, ctx->stream) : eagle_dev_scan_operands(ctx, Sa, Va, ah, n, np, v, Wu, tmp, ctx->stream);
+        if (w_direct) rc = eagle_dev_fold_upper(ctx, Wu, np, ctx->stream);
+        else {
+            // v = S a_hat at once; then V in blocks of 1024 rows of its image: copy on the loader stream, event, the rows X = V S of
+            // that block on the compute stream.  PCIe (57 GB/s) delivers a block in half the time its product takes, so all of
+            // V's upload but the first block hides under the first n^3 product.
+            rc = eagle_dev_scan_operands_begin(ctx, Sa, ah, n, np, v, tmp, ctx->stream);
+            if (!rc && (e = hipMemsetAsync(Va, 0, sq, ctx->load_stream)) != hipSuccess) rc = eagle_fail_hip(ctx, e, "V memset");
+            std::vector<hipEvent_t> landed;
+            for (long b0 = 0; b0 < np && !rc; b0 += EAGLE_VROWS_BLOCK) {
+                const long b1 = std::min(np, b0 + EAGLE_VROWS_BLOCK), hr = std::min(n, b1) - b0;  // rows of the image = columns of the R matrix
+                if (hr > 0) {
+                    e = hipMemcpy2DAsync(Va + b0 * np, sizeof(double) * np, dim_reduced_vara + b0 * n, sizeof(double) * n, sizeof(double) * n, (size_t)hr,
+                                         hipMemcpyHostToDevice, ctx->load_stream);
+                    if (e != hipSuccess) { rc = eagle_fail_hip(ctx, e, "upload of a row block of V"); break; }
+                }
+                hipEvent_t ev = nullptr;
+                if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) { rc = eagle_fail_hip(ctx, e, "hipEventCreate"); break; }
+                landed.push_back(ev);
+                if ((e = hipEventRecord(ev, ctx->load_stream)) != hipSuccess || (e = hipStreamWaitEvent(ctx->stream, ev, 0)) != hipSuccess) {
+                    rc = eagle_fail_hip(ctx, e, "row block event"); break;
+                }
+                rc = eagle_dev_scan_operands_vrows(ctx, Sa, Va, np, b0, b1, tmp, ctx->stream);
+            }
+            if (!rc) rc = eagle_dev_scan_operands_finish(ctx, Sa, Va, np, Wu, tmp, ctx->stream);
+            if (rc) (void)hipStreamSynchronize(ctx->load_stream);  // nothing of the caller's V may still be in flight when we return
+            for (hipEvent_t ev : landed) (void)hipEventDestroy(ev);
+        }
         if (!rc && s_from_cache) {
             // under the product: the caller's S to the scratch copy (loader stream), compared with the cached one
             int* flag = (int*)((char*)ctx->d_scratch + EAGLE_SCR_SCACHE_FLAG);

@@ -12,6 +12,11 @@ int eagle_fail(eagle_ctx* ctx, int code, const char* msg);
 int eagle_fail_hip(eagle_ctx* ctx, hipError_t e, const char* where);
 // C = A * B, all row-major np x np fp64, np % 128 == 0
 int eagle_dev_gemm_f64(eagle_ctx* ctx, const double* A, const double* B, double* C, long np, void* stream);
+// eagle_dev_scan_operands in three steps (eagle_kernels.hip): the caller may upload V in row blocks under the first product
+#define EAGLE_VROWS_BLOCK 1024  /* rows of V's image per upload + product step (a multiple of 256) */
+int eagle_dev_scan_operands_begin(eagle_ctx* ctx, const double* Sa, const double* ahat, long n, long n_pad, double* v_out, double* tmp, void* stream);
+int eagle_dev_scan_operands_vrows(eagle_ctx* ctx, const double* Sa, const double* Va, long n_pad, long row0, long row1, double* tmp, void* stream);
+int eagle_dev_scan_operands_finish(eagle_ctx* ctx, const double* Sa, const double* Va, long n_pad, double* Wu_out, double* tmp, void* stream);
 // out = A x where At is the row-major image of A^T (i.e. the column-major R matrix), n_pad % 64 == 0
 int eagle_dev_colgemv(eagle_ctx* ctx, const double* At, long n, long n_pad, const double* x, double* out, void* stream);
 // 4 KiB of ctx-owned device scratch (flags, small reductions); stream-ordered use only

@@ -971,29 +971,38 @@ __global__ __launch_bounds__(512, 2) void k_gemm_f64_dma(const double* __restric
                 _Pragma("unroll") for (int n = 0; n < 4; n++)                      \
                     acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(A_[m][e], B_[n][e], acc[m][n], 0, 0, 0); \
     } while (0)
-    // one K block on stage buffer ST: `next` = there is a K block after this one, `next2` = and one after that
-#define G2_KBLOCK(ST, kb_, next, next2)                                            \
+    // One REGION = the code between two barriers, on stage buffer ST holding K block kb_ (visible since the barrier before it):
+    //   DMA of K block kb_+1 into the other buffer (all its readers passed that barrier) | fragment reads X(kb_) | the last 16 MFMAs
+    //   of K block kb_-1 (on its Y fragments) | fragment reads Y(kb_) | 48 MFMAs of K block kb_ | barrier.
+    // The sched_group_barriers spell that order out for hipcc (it otherwise parks fragment reads behind the MFMAs and then waits for
+    // them in front of the barrier); the sched_barrier keeps the barrier behind the MFMAs, so a wave arrives with matrix work in flight.
+#define G2_REGION(ST, kb_, first, more)                                            \
     do {                                                                           \
+        if (more) dma((kb_) + 1, lds[(ST) ^ 1]);                                   \
+        G2_READ_X(ST);                                                             \
+        if (!(first)) G2_MFMA(ay, by, 2, 4);                                       \
         G2_READ_Y(ST);                                                             \
         G2_MFMA(ax, bx, 0, 4);                                                     \
         G2_MFMA(ay, by, 0, 2);                                                     \
-        __syncthreads(); /* this wave's DMA of the next stage (vmcnt) and its reads of this one (lgkmcnt), then the barrier */ \
-        if (next2) dma((kb_) + 2, lds[ST]);                                        \
-        if (next) G2_READ_X((ST) ^ 1);                                             \
-        G2_MFMA(ay, by, 2, 4);                                                     \
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                         \
+        if (!(first)) __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);          \
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                         \
+        __builtin_amdgcn_sched_group_barrier(0x008, 48, 0);                        \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+        __syncthreads(); /* this wave's DMA of K block kb_+1 (vmcnt) and its reads of this stage (lgkmcnt), then the barrier */ \
     } while (0)
     const int nkb = (int)(kb1 - kb0);
     dma(kb0, lds[0]);
     __syncthreads();
-    G2_READ_X(0);
-    if (nkb > 1) dma(kb0 + 1, lds[1]);
-    int i = 0;
+    G2_REGION(0, kb0, true, nkb > 1);
+    int i = 1;
     for (; i + 2 <= nkb; i += 2) {   // two K blocks per trip: the stage buffer of every read is a compile-time constant
-        G2_KBLOCK(0, kb0 + i, true, i + 2 < nkb);
-        G2_KBLOCK(1, kb0 + i + 1, i + 2 < nkb, i + 3 < nkb);
+        G2_REGION(1, kb0 + i, false, true);
+        G2_REGION(0, kb0 + i + 1, false, i + 2 < nkb);
     }
-    if (i < nkb) G2_KBLOCK(0, kb0 + i, false, false);
-#undef G2_KBLOCK
+    if (i < nkb) G2_REGION(1, kb0 + i, false, false);
+    G2_MFMA(ay, by, 2, 4);   // the tail of the last K block
+#undef G2_REGION
 #undef G2_MFMA
 #undef G2_READ_X
 #undef G2_READ_Y
@@ -1072,7 +1081,8 @@ static int gemm_tile_list(eagle_ctx* ctx, int nt, int kind, int rt0, int rt1, co
 
 // Tile list of k_gemm_f64_dma: 256-row tiles starting at 128-row tile rt0, rt0 + 2, ... (the last may be half inside [rt0, rt1)),
 // 128-column tiles; kind 0 = all, 1 = tiles holding an element on or above the diagonal (column tile >= first row tile),
-// 2 = the others.  Row tile outer: consecutive workgroups share an A row panel.
+// 2 = the others, 3 = tiles holding an element on or below the diagonal (column tile <= last 128-row tile of the tile).
+// Row tile outer: consecutive workgroups share an A row panel.
 static int gemm_dma_tile_list(eagle_ctx* ctx, int nt, int kind, int rt0, int rt1, const int** out, long* count) {
     std::lock_guard<std::mutex> lock(g_gemm_lists_mutex);
     int dev = 0;
@@ -1083,7 +1093,7 @@ static int gemm_dma_tile_list(eagle_ctx* ctx, int nt, int kind, int rt0, int rt1
     std::vector<int> h;
     for (int i = rt0; i < rt1; i += 2)
         for (int j = 0; j < nt; j++)
-            if (kind == 0 || (kind == 1 && j >= i) || (kind == 2 && j < i)) h.push_back((i << 16) | j);
+            if (kind == 0 || (kind == 1 && j >= i) || (kind == 2 && j < i) || (kind == 3 && j <= i + 1)) h.push_back((i << 16) | j);
     int* d = nullptr;
     if (!h.empty()) {
         hipError_t e = hipMalloc((void**)&d, h.size() * sizeof(int));
@@ -1213,8 +1223,21 @@ static int gemm_f64_upper(eagle_ctx* ctx, const double* A, const double* B, doub
     return gemm_f64_tiles(ctx, A, B, C, np, 2, sym, 1, stream);
 }
 
-extern "C" int eagle_dev_scan_operands(eagle_ctx* ctx, const double* Sa, const double* Va, const double* ahat, long n,
-                                       long n_pad, double* v_out, double* Wu_out, double* tmp, void* stream) {
+// W = S (V S) in three steps, so that the caller can overlap the PCIe upload of V with the first product
+// (eagle_api.cpp scan_range: V arrives in row blocks on the loader stream; the device copy of S is already there):
+//   _begin   v = S a_hat (needs Sa, a_hat only).
+//   _vrows   X[r0, r1) = Va[r0, r1) * Sa for one block of rows of Va's image (r0, r1 multiples of 128) into tmp -- needs only
+//            those rows of Va.  For SYMMETRIC operands (every Eagle run: MMt^-1/2 and a variance matrix) X = V S.
+//   _finish  symmetry check of Sa, Va; if symmetric: the 256 x 128 tiles of W' = Sa * X that hold an element on or below the
+//            diagonal, stored TRANSPOSED into Wu (W is symmetric: only one triangle is needed, the fold doubles it);
+//            if not: the general products Xt = Sa * Va, Wt = Xt * Sa (both triangles) replace everything -- launched always,
+//            dropped on the device by the flag the check left, so there is no host round trip either way; then the fold.
+// For exactly symmetric images the symmetric pipeline forms, tile for tile, the very sums of the general products (the same
+// products in the same k order, a * b = b * a); for images symmetric only to rounding the two differ at rounding level, as the
+// "upper tiles doubled" shortcut always did.  eagle_dev_scan_operands = the three steps on resident operands, so a device-resident
+// step (bench.py) and the reference-shaped call (upload pipelined) return the same bits.
+extern "C" int eagle_dev_scan_operands_begin(eagle_ctx* ctx, const double* Sa, const double* ahat, long n, long n_pad, double* v_out, double* tmp,
+                                             void* stream) {
     if (n_pad % GF_T || n > n_pad) return eagle_fail(ctx, EAGLE_ERR_ARG, "scan_operands: bad padding");
     hipStream_t s = (hipStream_t)stream;
     // v = S a_hat ; Sa is the row-major image of S^T, so v_i = sum_j Sa[j][i] a_hat[j]
@@ -1224,20 +1247,57 @@ extern "C" int eagle_dev_scan_operands(eagle_ctx* ctx, const double* Sa, const d
     hipLaunchKernelGGL(k_colgemv_part, dim3((unsigned)(n_pad / 64), 8), dim3(256), 0, s, Sa, n, n_pad, ahat, tmp);
     hipLaunchKernelGGL(k_colgemv_sum, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, s, tmp, n_pad, 8, v_out);
     LAUNCH_CHECK(ctx);
-    // symmetric operands (every Eagle run): W = S V S is symmetric and only its upper 128-tiles are computed
+    return EAGLE_OK;
+}
+static bool scan_operands_pipelined(const eagle_ctx* ctx, long n_pad) {
+    return n_pad % 256 == 0 && 256 * n_pad * 8 < 2147483648L && !(ctx->tune >= 21 && ctx->tune <= 27);
+}
+extern "C" int eagle_dev_scan_operands_vrows(eagle_ctx* ctx, const double* Sa, const double* Va, long n_pad, long row0, long row1, double* tmp,
+                                             void* stream) {
+    if (n_pad % GF_T || row0 % GF_T || row1 % GF_T || row0 < 0 || row1 > n_pad || row0 >= row1)
+        return eagle_fail(ctx, EAGLE_ERR_ARG, "scan_operands_vrows: bad padding or row block");
+    if (!scan_operands_pipelined(ctx, n_pad)) return EAGLE_OK;  // (the 128 x 128 kernels of the A/B runs: all of it in _finish)
+    return gemm_f64_dma_tiles(ctx, Va, Sa, tmp, n_pad, 0, nullptr, 0, stream, (int)(row0 / GF_T), (int)(row1 / GF_T), false);
+}
+extern "C" int eagle_dev_scan_operands_finish(eagle_ctx* ctx, const double* Sa, const double* Va, long n_pad, double* Wu_out, double* tmp, void* stream) {
+    if (n_pad % GF_T) return eagle_fail(ctx, EAGLE_ERR_ARG, "scan_operands: bad padding");
+    hipStream_t s = (hipStream_t)stream;
     int* sym = (int*)((char*)eagle_ctx_scratch(ctx) + EAGLE_SCR_SYM);
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, sym, 1);
     dim3 g32((unsigned)(n_pad / 32), (unsigned)(n_pad / 32));
     hipLaunchKernelGGL(k_sym_check, g32, dim3(256), 0, s, Sa, Va, n_pad, sym);
     LAUNCH_CHECK(ctx);
-    // Xt = (V S)^T = S^T V^T = Sa * Va ; Wt = (S X)^T = X^T S^T = Xt * Sa        (row-major images)
-    int rc = eagle_dev_gemm_f64(ctx, Sa, Va, tmp, n_pad, stream);
-    if (rc) return rc;
-    rc = gemm_f64_upper(ctx, tmp, Sa, Wu_out, n_pad, sym, stream);
-    if (rc) return rc;
+    int rc;
+    const int nt = (int)(n_pad / GF_T);
+    if (scan_operands_pipelined(ctx, n_pad)) {
+        // symmetric: W' = Sa * X on the tiles with column tile <= last row tile ... i.e. NOT strictly above the diagonal, transposed
+        // into the upper tiles of Wu (skipped when the check failed)
+        rc = gemm_f64_dma_tiles(ctx, Sa, tmp, Wu_out, n_pad, 3, sym, 0, stream, 0, nt, true);
+        if (rc) return rc;
+        // not symmetric: the general products (skipped when the check passed)
+        rc = gemm_f64_dma_tiles(ctx, Sa, Va, tmp, n_pad, 0, sym, 1, stream, 0, nt, false);
+        if (!rc) rc = gemm_f64_dma_tiles(ctx, tmp, Sa, Wu_out, n_pad, 0, sym, 1, stream, 0, nt, false);
+        if (rc) return rc;
+    } else {
+        // Xt = (V S)^T = S^T V^T = Sa * Va ; Wt = (S X)^T = X^T S^T = Xt * Sa        (row-major images)
+        rc = eagle_dev_gemm_f64(ctx, Sa, Va, tmp, n_pad, stream);
+        if (rc) return rc;
+        rc = gemm_f64_upper(ctx, tmp, Sa, Wu_out, n_pad, sym, stream);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(k_fold_upper, g32, dim3(256), 0, s, Wu_out, n_pad, sym);
     LAUNCH_CHECK(ctx);
     return EAGLE_OK;
+}
+extern "C" int eagle_dev_scan_operands(eagle_ctx* ctx, const double* Sa, const double* Va, const double* ahat, long n,
+                                       long n_pad, double* v_out, double* Wu_out, double* tmp, void* stream) {
+    int rc = eagle_dev_scan_operands_begin(ctx, Sa, ahat, n, n_pad, v_out, tmp, stream);
+    // the same 1024-row blocks the reference-shaped call uses while V arrives: each launch cuts its own split-K tail, so only
+    // the same blocking gives the same sums
+    for (long b0 = 0; b0 < n_pad && !rc; b0 += EAGLE_VROWS_BLOCK)
+        rc = eagle_dev_scan_operands_vrows(ctx, Sa, Va, n_pad, b0, b0 + EAGLE_VROWS_BLOCK < n_pad ? b0 + EAGLE_VROWS_BLOCK : n_pad, tmp, stream);
+    if (!rc) rc = eagle_dev_scan_operands_finish(ctx, Sa, Va, n_pad, Wu_out, tmp, stream);
+    return rc;
 }
 
 // The same operands with the n^3 work shared between ranks (marker-sharded multi-GPU run): this call computes v = S a_hat

@@ -8,7 +8,7 @@ from collections import defaultdict
 
 out = sys.argv[1]
 OURS = ("k_vara_i8p", "k_vara_i8w", "k_syrk_f4w", "k_syrk_f4p", "k_vara_i8", "k_vara_f64", "k_cert_lb", "k_cert_select", "k_cert_gather", "k_tiles_pack", "k_syrk_f4", "k_pack_fp4", "k_marker_shift", "k_rho_rows", "k_rho_cols", "k_rho_final", "k_syrk_i8", "k_gemm_f64", "k_gemv_mfma", "k_slice_vec", "k_sym_check", "k_vara_prep", "k_absmax_offdiag", "k_slice_w", "k_fold_upper", "k_colgemv", "k_tsq", "k_absmax",
-        "k_transpose_i8", "k_mmt_finish", "k_mmt_normalise", "k_decode_ascii", "k_vara_i8_finish")
+        "k_transpose_pack_fp4", "k_transpose_i8", "k_spectral", "k_zbuild", "k_cert_bounds", "k_cert_lb_b", "k_cert_select_b", "k_mmt_finish", "k_mmt_normalise", "k_decode_ascii", "k_vara_i8_finish")
 
 
 def find(pattern):
@@ -19,6 +19,10 @@ def find(pattern):
 def short(name):
     for k in OURS:
         if k in name:
+            if "k_gemm_f64_dma_tail" in name:
+                return "k_gemm_f64_dma_tail"
+            if "k_gemm_f64_dma" in name:
+                return "k_gemm_f64_dma"
             if "k_gemm_f64_list" in name:
                 return "k_gemm_f64_list"
             if "k_gemm_f64_tail" in name:
