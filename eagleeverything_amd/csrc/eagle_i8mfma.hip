@@ -1698,41 +1698,62 @@ extern "C" int eagle_dev_pack_fp4(eagle_ctx* ctx, const int8_t* Mt8, long L_pad,
 }
 
 // The operand image of the MM^T kernel straight from the marker-major genotypes: M4[individual][marker / 2] (fp4, two per byte,
-// the even marker in the low nibble) from Mt8[marker][individual] in ONE pass -- a 256-marker x 64-individual tile goes through LDS,
-// wave `part` gathers 64 markers of its lane's individual (all lanes of a wave read one LDS row: 64 consecutive bytes, conflict
-// free) and writes their 32 bytes.  Replaces k_transpose_i8 + k_pack_fp4 (read 2 + write 1.5 bytes per genotype, and a second
+// the even marker in the low nibble) from Mt8[marker][individual] in ONE pass -- a 256-marker x 128-individual tile goes through LDS,
+// each thread gathers 128 markers of its individual (all lanes of a wave read one LDS row: 64 consecutive bytes, conflict
+// free) and writes their 64 bytes.  Replaces k_transpose_i8 + k_pack_fp4 (read 2 + write 1.5 bytes per genotype, and a second
 // int8 image of the shard) by read 1 + write 0.5.  Same bytes as the two-pass form (tests/test_gpu_parity.py).
 __global__ __launch_bounds__(256) void k_transpose_pack_fp4(const int8_t* __restrict__ in, long ld_in, uint8_t* __restrict__ out, long ld4) {
-    __shared__ __attribute__((aligned(16))) int8_t tile[256][64];
-    const long r0 = (long)blockIdx.x * 256, c0 = (long)blockIdx.y * 64;
+    // 256 markers x 128 individuals per block: whole 128-byte lines on both sides (with 64-individual tiles every input line was
+    // fetched by two blocks far apart in the grid: 25 GB of traffic for 15 GB of data at 10,000 x 1,000,000)
+    __shared__ __attribute__((aligned(16))) int8_t tile[256][128];
+    const long r0 = (long)blockIdx.x * 256, c0 = (long)blockIdx.y * 128;
     const int t = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int row = (t >> 2) + 64 * i, ch = (t & 3) * 16;
+    for (int i = 0; i < 8; i++) {
+        const int row = (t >> 3) + 32 * i, ch = (t & 7) * 16;
         *(i32x4*)(&tile[row][ch]) = *(const i32x4*)(in + (r0 + row) * ld_in + c0 + ch);
     }
     __syncthreads();
-    const int c = t & 63, part = t >> 6;
-    unsigned o[8];
+    const int c = t & 127, part = t >> 7;   // a wave reads 64 consecutive bytes of one LDS row per instruction: conflict free
+    const uint8_t* col = (const uint8_t*)&tile[part * 128][c];
+    i32x4 ov[4];
 #pragma unroll
-    for (int w = 0; w < 8; w++) {
-        unsigned v = 0;
+    for (int v4 = 0; v4 < 4; v4++) {
+        unsigned o[4];
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const unsigned m = (unsigned)(int)tile[part * 64 + w * 8 + q][c];
-            v |= (((m & 1u) << 1) | ((m & 0x80u) >> 4)) << (4 * q);
+        for (int w = 0; w < 4; w++) {
+            unsigned hw[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                // four genotypes of this individual into one dword, then k_pack_fp4's dword-wide code fold
+                const uint8_t* b = col + ((v4 * 4 + w) * 8 + hh * 4) * 128;
+                const unsigned x = (unsigned)b[0] | ((unsigned)b[128] << 8) | ((unsigned)b[256] << 16) | ((unsigned)b[384] << 24);
+                const unsigned cc = ((x & 0x01010101u) << 1) | ((x & 0x80808080u) >> 4);
+                const unsigned tt = cc | (cc >> 4);
+                hw[hh] = (tt & 0xffu) | ((tt >> 8) & 0xff00u);
+            }
+            o[w] = hw[0] | (hw[1] << 16);
         }
-        o[w] = v;
+        ov[v4] = i32x4{(int)o[0], (int)o[1], (int)o[2], (int)o[3]};
     }
-    uint8_t* dst = out + (c0 + c) * ld4 + (r0 + part * 64) / 2;
-    *(i32x4*)dst = i32x4{(int)o[0], (int)o[1], (int)o[2], (int)o[3]};
-    *(i32x4*)(dst + 16) = i32x4{(int)o[4], (int)o[5], (int)o[6], (int)o[7]};
+    // the 128 output rows (128 bytes each) go out as whole lines: staged in LDS (the input tile is dead; pitch 144 bytes keeps the
+    // 16-byte writes of 8 neighbouring rows on different banks), then 8 rows x 128 contiguous bytes per wave instruction
+    __syncthreads();
+    uint8_t* stage = (uint8_t*)&tile[0][0];
+#pragma unroll
+    for (int v4 = 0; v4 < 4; v4++) *(i32x4*)(stage + c * 144 + part * 64 + 16 * v4) = ov[v4];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int chunk = t + 256 * i, row = chunk >> 3, piece = chunk & 7;
+        *(i32x4*)(out + (c0 + row) * ld4 + r0 / 2 + piece * 16) = *(const i32x4*)(stage + row * 144 + piece * 16);
+    }
 }
 extern "C" int eagle_dev_transpose_pack_fp4(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, void* M4, long ld4, void* stream) {
-    if (L_pad % 256 || n_pad % 64 || ld % 16 || n_pad > ld || ld4 % 16 || ld4 < L_pad / 2 || n_pad / 64 > 65535)
-        return eagle_fail(ctx, EAGLE_ERR_ARG, "transpose_pack_fp4: layout contract violated (L_pad % 256, n_pad % 64, ld % 16, ld4 % 16)");
+    if (L_pad % 256 || n_pad % 128 || ld % 16 || n_pad > ld || ld4 % 16 || ld4 < L_pad / 2 || n_pad / 128 > 65535)
+        return eagle_fail(ctx, EAGLE_ERR_ARG, "transpose_pack_fp4: layout contract violated (L_pad % 256, n_pad % 128, ld % 16, ld4 % 16)");
     if (L_pad <= 0 || n_pad <= 0) return EAGLE_OK;
-    hipLaunchKernelGGL(k_transpose_pack_fp4, dim3((unsigned)(L_pad / 256), (unsigned)(n_pad / 64)), dim3(256), 0, (hipStream_t)stream, Mt8, ld,
+    hipLaunchKernelGGL(k_transpose_pack_fp4, dim3((unsigned)(L_pad / 256), (unsigned)(n_pad / 128)), dim3(256), 0, (hipStream_t)stream, Mt8, ld,
                        (uint8_t*)M4, ld4);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "k_transpose_pack_fp4");

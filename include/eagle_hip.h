@@ -421,7 +421,7 @@ int eagle_dev_pack_fp4(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad
 /* The operand image of eagle_dev_mmt_accumulate_f4 straight from the MARKER-major genotypes, in one pass: M4[n_pad][ld4 bytes],
  * byte b of row j = markers 2b (low nibble) and 2b+1 (high nibble) of individual j as e2m1 codes, from Mt8[L_pad][ld].  The same
  * bytes as eagle_dev_transpose_i8 followed by eagle_dev_pack_fp4, without the individual-major int8 image in between.
- * L_pad % 256 == 0, n_pad % 64 == 0, ld % 16 == 0, ld4 % 16 == 0, ld4 >= L_pad / 2. */
+ * L_pad % 256 == 0, n_pad % 128 == 0, ld % 16 == 0, ld4 % 16 == 0, ld4 >= L_pad / 2. */
 int eagle_dev_transpose_pack_fp4(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, void* M4, long ld4, void* stream);
 int eagle_dev_vara_f6_prepare(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu,
                               int nslices, void* ws, const double* v, double* a_out, void* stream);
