@@ -261,6 +261,7 @@ extern "C" void eagle_close(eagle_ctx* ctx) {
     if (ctx->d_a) (void)hipFree(ctx->d_a);
     if (ctx->d_vara) (void)hipFree(ctx->d_vara);
     if (ctx->d_bound) (void)hipFree(ctx->d_bound);
+    if (ctx->argmax_ws) (void)hipFree(ctx->argmax_ws);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_Scache) (void)hipFree(ctx->d_Scache);
     if (ctx->d_Sscr) (void)hipFree(ctx->d_Sscr);
@@ -1579,13 +1580,14 @@ static int local_scan_argmax(eagle_ctx* ctx, eagle_best* h) {
     h->tsqmax = 0.0; h->index0 = -1; h->near_ties = 0;
     if (!ctx->d_a || ctx->scan_L <= 0) return EAGLE_OK;  // an empty shard
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    DevBuf scratch, best;
-    HIPCHK(ctx, scratch.alloc(sizeof(double) * 3 * 1024));
-    HIPCHK(ctx, best.alloc(sizeof(eagle_best)));
-    int rc = eagle_dev_tsq_argmax(ctx, ctx->d_a, ctx->d_vara, ctx->scan_L, nullptr, best.as<eagle_best>(), scratch.as<double>(),
-                                  ctx->stream);
+    // ctx-owned workspace: a hipMalloc / hipFree pair per call costs milliseconds in a process that has 100+ GB mapped (measured:
+    // 13 ms per find_qtl-shaped call inside bench.py), and hipFree synchronises the device
+    if (!ctx->argmax_ws) HIPCHK(ctx, hipMalloc(&ctx->argmax_ws, sizeof(double) * 3 * 1024 + 256));
+    double* scratch = (double*)ctx->argmax_ws;
+    eagle_best* best = (eagle_best*)((char*)ctx->argmax_ws + sizeof(double) * 3 * 1024);
+    int rc = eagle_dev_tsq_argmax(ctx, ctx->d_a, ctx->d_vara, ctx->scan_L, nullptr, best, scratch, ctx->stream);
     if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(h, best.p, sizeof *h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h, best, sizeof *h, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (h->index0 >= 0) h->index0 += ctx->scan_first;  // global marker index
     return EAGLE_OK;

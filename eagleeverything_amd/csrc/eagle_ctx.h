@@ -68,6 +68,7 @@ struct eagle_ctx {
     long st_chunks = 0, st_file_bytes = 0;
     double st_pread_s = 0, st_load_wall_s = 0, st_wait_s = 0, st_compute_s = 0, st_total_s = 0, st_starved_s = 0, st_load_first_s = 0;
     void* d_scratch = nullptr;
+    void* argmax_ws = nullptr;   // block partials + result of eagle_last_scan_argmax (ctx-owned: no allocation per call)
     void* arena = nullptr; size_t arena_cap = 0, arena_off = 0;  // grow-only device workspace reused across calls
     void* f4_buf = nullptr; size_t f4_cap = 0;  // fp4 image of the tile eagle_dev_mmt_accumulate is working on
     void* gemm_scratch = nullptr; size_t gemm_scratch_cap = 0;  // split-K partial tiles of the fp64 GEMM's last wave

@@ -652,6 +652,51 @@ def test_certified_candidates_are_bitwise_fp64_device_api(api, oracle):
     sh.nslices = 0
 
 
+def test_overflow_fallback_through_the_reference_shaped_call_resident_streamed_and_sharded(api, tmp_path, monkeypatch):
+    """More candidates than the re-evaluation buffer holds (one digit slice forced: nearly every marker's bound exceeds 1e-7 of
+    its vara) must end in the fp64 scan's values for the whole file -- in the one-block flow (device-side gate), in the flow of
+    a streamed file (per-block bounds, ONE selection after the last block, the file streamed a second time through the fp64
+    kernel) and with the markers on two sub-contexts of the card.  Expected: bit for bit the arrays of scan mode 0."""
+    n, L = 600, 9000
+    rng = np.random.default_rng(17)
+    Mt8 = synth.genotypes_marker_major(n, L, seed=23)
+    geno = synth.write_geno_pair(str(tmp_path), Mt8)
+    A = rng.standard_normal((n, 40)) / 8.0
+    S = np.eye(n) + A @ A.T
+    V = 0.6 * np.eye(n) - 0.02 * (A[:, :4] @ A[:, :4].T)
+    ahat = rng.standard_normal(n)
+    call = lambda dev: api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat, device=dev)
+    api.set_scan_mode(0)
+    ref = call(0)
+    best_ref = api.last_scan_argmax()
+    api.set_scan_mode(1)
+    try:
+        api.set_scan_slices(1)
+        res = call(0)
+        assert api.last_scan_certificate()[2] is True                       # fell back
+        np.testing.assert_array_equal(res["vara"], ref["vara"])
+        np.testing.assert_array_equal(res["a"], ref["a"])
+        assert api.last_scan_argmax()[:2] == best_ref[:2]
+        monkeypatch.setenv("EAGLE_HIP_MAX_RESIDENT_GB", "0.0012")           # 768-byte rows: chunks of 768 markers, 12 blocks
+        api.drop_cache()
+        res = call(0)
+        assert api.last_stream_stats()["chunks"] >= 4 and api.last_scan_certificate()[2] is True
+        np.testing.assert_array_equal(res["vara"], ref["vara"])
+        np.testing.assert_array_equal(res["a"], ref["a"])
+        assert api.last_scan_argmax()[:2] == best_ref[:2]
+        monkeypatch.delenv("EAGLE_HIP_MAX_RESIDENT_GB")
+        dev = (0, 0)
+        api.set_scan_slices(1, device=dev)
+        res = call(dev)
+        np.testing.assert_array_equal(res["vara"], ref["vara"])
+        assert api.last_scan_argmax(device=dev)[:2] == best_ref[:2]
+        api.set_scan_slices(0, device=dev)
+        api.drop_cache(device=dev)
+    finally:
+        api.set_scan_slices(0)
+        api.drop_cache()
+
+
 def test_stochastic_rounding_option(api, oracle):
     """eagle_set_scan_rounding(1) / EAGLE_SLICES_STOCHASTIC (opt-in): the digits of W rounded at random (unbiased, keyed by
     position).  One digit fewer than round-to-nearest at n = 5000; every error inside the Hoeffding radius

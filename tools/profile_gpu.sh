@@ -11,11 +11,14 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 OPS=/tmp/eagle_bench_operands.pt
-ARGS="$ROOT/bench.py --cpu-sample 0 --no-secondary --steps 3 --warmup 1 --load-operands $OPS $@"
-KF="--kernel-include-regex k_vara_i8|k_vara_f64|k_syrk_f4|k_gemm_f64|k_gemv|k_mmt_finish|k_slice_w|k_pack_fp4|k_cert"
+# SECONDARY=1: the stats pass and the FETCH_SIZE / SQ / GRBM passes also run bench.py's secondary entries (fp64-mode scan, spectral
+# scan, Z builds), so that k_vara_f64, k_spectral_scan and k_zbuild_i8 appear in the summary
+if [ -n "$SECONDARY" ]; then NOSEC="--no-e2e"; else NOSEC="--no-secondary"; fi
+ARGS="$ROOT/bench.py --cpu-sample 0 $NOSEC --steps 3 --warmup 1 --load-operands $OPS $@"
+KF="--kernel-include-regex k_vara_i8|k_vara_f64|k_syrk_f4|k_gemm_f64|k_gemv|k_mmt_finish|k_slice_w|k_pack_fp4|k_transpose_pack_fp4|k_cert|k_spectral|k_zbuild"
 echo "== stats pass";
 # the stats pass profiles the bench command itself (model-algebra operands; the CPU sample and the secondary entries are skipped)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $ROOT/bench.py --cpu-sample 0 --no-secondary --save-operands $OPS "$@" > $OUT/stats.log 2>&1 || { tail -5 $OUT/stats.log; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $ROOT/bench.py --cpu-sample 0 $NOSEC --save-operands $OPS "$@" > $OUT/stats.log 2>&1 || { tail -5 $OUT/stats.log; exit 1; }
 echo "== pmc FETCH_SIZE"
 rocprofv3 $KF --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1 || { tail -5 $OUT/pmc_fetch.log; exit 1; }
 echo "== pmc WRITE_SIZE"

@@ -8,7 +8,7 @@ from collections import defaultdict
 
 out = sys.argv[1]
 OURS = ("k_vara_i8p", "k_vara_i8w", "k_syrk_f4w", "k_syrk_f4p", "k_vara_i8", "k_vara_f64", "k_cert_lb", "k_cert_select", "k_cert_gather", "k_tiles_pack", "k_syrk_f4", "k_pack_fp4", "k_marker_shift", "k_rho_rows", "k_rho_cols", "k_rho_final", "k_syrk_i8", "k_gemm_f64", "k_gemv_mfma", "k_slice_vec", "k_sym_check", "k_vara_prep", "k_absmax_offdiag", "k_slice_w", "k_fold_upper", "k_colgemv", "k_tsq", "k_absmax",
-        "k_transpose_pack_fp4", "k_transpose_i8", "k_spectral", "k_zbuild", "k_cert_bounds", "k_cert_lb_b", "k_cert_select_b", "k_mmt_finish", "k_mmt_normalise", "k_decode_ascii", "k_vara_i8_finish")
+        "k_transpose_pack_fp4", "k_transpose_i8", "k_spectral_scan", "k_spectral_finish", "k_zbuild_i8", "k_zbuild", "k_slice_u", "k_cert_bounds", "k_cert_lb_b", "k_cert_select_b", "k_mmt_finish", "k_mmt_normalise", "k_decode_ascii", "k_vara_i8_finish")
 
 
 def find(pattern):
@@ -43,12 +43,13 @@ print("# rocprofv3 summary of", os.path.basename(out))
 f = find("stats/**/*kernel_stats.csv")
 if f:
     print("\n## kernel stats (rocprofv3 --kernel-trace --stats), this repo's kernels")
-    print("%-28s %8s %14s %14s %8s" % ("kernel", "calls", "total_ms", "avg_ms", "pct"))
+    print("%-28s %8s %14s %14s %8s %12s %12s" % ("kernel", "calls", "total_ms", "avg_ms", "pct", "min_ms", "max_ms"))
     for r in csv.DictReader(open(f)):
         s = short(r["Name"])
         if s:
-            print("%-28s %8s %14.3f %14.4f %8s" % (s, r["Calls"], float(r["TotalDurationNs"]) / 1e6,
-                                                   float(r["AverageNs"]) / 1e6, r["Percentage"]))
+            print("%-28s %8s %14.3f %14.4f %8s %12.4f %12.4f" % (s, r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                                 float(r["AverageNs"]) / 1e6, r["Percentage"], float(r.get("MinNs", 0)) / 1e6,
+                                                                 float(r.get("MaxNs", 0)) / 1e6))
 for tag in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcc", "pmc_grbm"):
     f = find(tag + "/**/*counter_collection.csv")
     if not f:
