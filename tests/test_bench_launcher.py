@@ -57,16 +57,23 @@ def test_more_gpus_than_the_node_has_fails_fast():
 
 
 @pytest.mark.gpu
-def test_two_rank_rehearsal_through_the_self_spawn_path(tmp_path):
-    """Two ranks sharing the one card (gloo: collectives through the host), started by bench.py itself, select the marker one rank
-    selects, with the same tsq; the JSON says how many ranks RCCL saw (0 here: no RCCL transfer has run on this box)."""
-    common = ["--individuals", "3200", "--markers", "150001", "--steps", "2", "--warmup", "1", "--no-secondary", "--cpu-sample", "0"]
+@pytest.mark.parametrize("ranks,n", [(2, 3200), (4, 3000)])
+def test_rank_rehearsal_through_the_self_spawn_path(tmp_path, ranks, n):
+    """Two / four ranks sharing the one card (gloo: collectives through the host), started by bench.py itself, select the marker one
+    rank selects, with the same tsq; the JSON says how many ranks RCCL saw (0 here: no RCCL transfer has run on this box).  n = 3,000
+    pads to 24 row tiles of 128, so four ranks SHARE the rows of W (one all-gather) when that is the faster form; 3,200 pads to 26."""
+    common = ["--individuals", str(n), "--markers", "150001", "--steps", "2", "--warmup", "1", "--no-secondary", "--cpu-sample", "0"]
     one = json.loads(_run(common, timeout=900).stdout.strip().splitlines()[-1])
-    two_p = _run(["--gpus", "2"] + common, env={"EAGLE_BENCH_BACKEND": "gloo"}, timeout=900)
-    assert two_p.returncode == 0, two_p.stderr[-2000:]
-    two = json.loads(two_p.stdout.strip().splitlines()[-1])
-    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
-    assert two["launcher"].startswith("self-spawned") and two["rccl_ranks"] == 0 and "gloo" in two["collective_backend"]
-    assert two["markers_per_rank"] == [75001, 75000]
-    assert two["selected_marker"] == one["selected_marker"] and two["tsqmax"] == one["tsqmax"]
+    many_p = _run(["--gpus", str(ranks)] + common, env={"EAGLE_BENCH_BACKEND": "gloo"}, timeout=900)
+    assert many_p.returncode == 0, many_p.stderr[-2000:]
+    many = json.loads(many_p.stdout.strip().splitlines()[-1])
+    assert one["n_gpus"] == 1 and many["n_gpus"] == ranks
+    assert many["launcher"].startswith("self-spawned") and many["rccl_ranks"] == 0 and "gloo" in many["collective_backend"]
+    assert sum(many["markers_per_rank"]) == 150001 and len(many["markers_per_rank"]) == ranks
+    assert max(many["markers_per_rank"]) - min(many["markers_per_rank"]) <= 1
+    assert many["selected_marker"] == one["selected_marker"]
+    # the rows of W come from the row-block product when they are shared between ranks: same sums in another order
+    assert abs(many["tsqmax"] - one["tsqmax"]) <= 1e-9 * abs(one["tsqmax"])
+    if "replicated" in many["w_sharing"]:
+        assert many["tsqmax"] == one["tsqmax"]
     assert one["rccl_ranks"] == 0 and one["launcher"] == "single process"
