@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """PCIe- and file-inclusive timing of the reference-shaped entry points (host files -> host results) on the GPU box.
-Not the bench metric (bench.py times with genotypes resident); reported in DESIGN.md section 5."""
+Not the bench metric (bench.py times with genotypes resident).
+Operands here are the SIMPLE seeded S, V (no model algebra): the library picks 5-6 digit slices for them instead of the 4 of the
+bench's operands, so scan times are not comparable with bench.py's step (that was round 2's unexplained '100 ms gap'); bench.py's
+e2e_reference_shaped leg and --form abi time the same path on the bench's own operands."""
 import json
 import os
 import sys
