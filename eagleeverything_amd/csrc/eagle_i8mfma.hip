@@ -919,8 +919,14 @@ __device__ __forceinline__ void tx_klast(TxAcc& c, i32x4 (&a)[3], i32x4 (&an)[3]
     asm volatile(X_KLAST : X_ACC_RW(0), X_ACC_RW(1), X_ACC_RW(2), X_FRAGS, X_DMA_OUT(a, da) : [pa] "v"(pa), [pb] "v"(pb), X_DMA_IN(a, da) : "memory", "scc");
 }
 // (the tile row-dot of a lane sums 64 products in int32: |sum| <= 32768 K for a K-deep tile, i.e. n_pad < 65536)
+// PACE (experiment of round 3, tools/bench_vara.py tune 14): the 32 workers an XCD runs at a time meet at a soft
+// barrier before every column-tile pair -- one agent-scope counter per (XCD, round, pair), bounded spin (a worker that is not
+// co-resident with its round only costs the others the spin limit, never a hang) -- so that they stream the shared genotype and
+// W-digit stages in step and the L2 serves them once.  Same integer sums: bit-identical q.
+template <bool PACE>
 __global__ __launch_bounds__(512, 2) void k_vara_i8p(const int8_t* __restrict__ Mt8, long ld, int ntm, const int8_t* __restrict__ Bs,
-                                                     long np, const VaraHdr* __restrict__ hdr, long long* __restrict__ q, long Lp, int cut_last_round) {
+                                                     long np, const VaraHdr* __restrict__ hdr, long long* __restrict__ q, long Lp, int cut_last_round,
+                                                     int* __restrict__ pace) {
     extern __shared__ __attribute__((aligned(1024))) int8_t ldsv[];  // [2][A 48 KiB | B 32 KiB]
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
@@ -950,6 +956,13 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8p(const int8_t* __restrict__ 
     cur.p = pair0; cur.half = 0; vit_set_tile(cur, nct, pair1);
     if (!cur.valid) return;
     nxt = cur;
+    int pace_expected = 0;
+    int* pace_row = nullptr;
+    if (PACE && slot < full) {  // whole workers only; the cut last round runs unpaced
+        const int round = slot >> 5;
+        for (int u = 0; u < 32; u++) pace_expected += (((round * 32 + u) / nslices) * 8 + xcd) < ntm;
+        pace_row = pace + ((long)xcd * ((wx + 31) >> 5) + round) * npair;
+    }
     long long keep[3] = {0, 0, 0};
     const int r = lane & 31, h = lane >> 5, swz = (r >> 1) & 7;
     constexpr int STG = TW_ABYTES + TILE_BYTES;
@@ -996,6 +1009,15 @@ __global__ __launch_bounds__(512, 2) void k_vara_i8p(const int8_t* __restrict__ 
     };
     while (cur.valid) {
         const int done_ct = cur.ct, nk = cur.nk;  // nk >= 2
+        if (PACE && pace_row && cur.half == 0) {
+            if (t == 0) {
+                int* cnt = pace_row + cur.p;
+                (void)__hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int it = 0; it < 2000 && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pace_expected; it++)
+                    __builtin_amdgcn_s_sleep(8);
+            }
+            __syncthreads();
+        }
         tx_kstep<true, 1>(c, fa[0], fa[1], fb, offA + buf * STG + ch[1], offB + buf * STG + ch[1], dA, dB);
         stage_rest();
         for (int kt = 1; kt < nk; kt++) {
@@ -1601,8 +1623,9 @@ extern "C" int eagle_dev_vara_i8_mfma_shifted(eagle_ctx* ctx, const int8_t* Mt8s
     // form (k_vara_i8w), 7 = whole workers in the last round.
     if (vara_piped(ctx, n_pad) || (ctx->tune == 9 && n_pad < 32768)) {
         const bool piped = vara_piped(ctx, n_pad);
-        const void* kfn = !piped ? (const void*)k_vara_i8w : (const void*)k_vara_i8p;
-        bool& attr = !piped ? ctx->attr_vara_i8w : ctx->attr_vara_i8p;
+        const bool pace = piped && ctx->tune == 14;
+        const void* kfn = !piped ? (const void*)k_vara_i8w : (pace ? (const void*)k_vara_i8p<true> : (const void*)k_vara_i8p<false>);
+        bool& attr = !piped ? ctx->attr_vara_i8w : (pace ? ctx->attr_vara_i8pp : ctx->attr_vara_i8p);
         if (!attr) {
             hipError_t ea = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TW_ABYTES + TILE_BYTES));
             if (ea != hipSuccess) return eagle_fail_hip(ctx, ea, "hipFuncSetAttribute(k_vara_i8p/w)");
@@ -1613,7 +1636,20 @@ extern "C" int eagle_dev_vara_i8_mfma_shifted(eagle_ctx* ctx, const int8_t* Mt8s
         const dim3 gridw((unsigned)(8 * (gw * smax + 31 * VARA_TAIL_PMAX)));
         const int cut = ctx->tune == 7 ? 0 : 1;
         if (!piped) hipLaunchKernelGGL(k_vara_i8w, gridw, dim3(512), 2 * (TW_ABYTES + TILE_BYTES), s, Mt8s, ld, ntw, Bs, n_pad, hdr, q, L_pad, cut);
-        else hipLaunchKernelGGL(k_vara_i8p, gridw, dim3(512), 2 * (TW_ABYTES + TILE_BYTES), s, Mt8s, ld, ntw, Bs, n_pad, hdr, q, L_pad, cut);
+        else if (!pace) hipLaunchKernelGGL(k_vara_i8p<false>, gridw, dim3(512), 2 * (TW_ABYTES + TILE_BYTES), s, Mt8s, ld, ntw, Bs, n_pad, hdr, q, L_pad, cut, (int*)nullptr);
+        else {
+            // counters [8 XCDs][rounds][pairs], zeroed per launch, in the ctx's GEMM scratch (free during the scan)
+            const size_t need = sizeof(int) * 8 * (size_t)((gw * smax + 31) / 32 + 1) * (size_t)((n_pad / T8 + 1) / 2);
+            if (need > ctx->gemm_scratch_cap) {
+                if (ctx->gemm_scratch) { (void)hipStreamSynchronize(s); (void)hipFree(ctx->gemm_scratch); ctx->gemm_scratch = nullptr; ctx->gemm_scratch_cap = 0; }
+                hipError_t ea = hipMalloc(&ctx->gemm_scratch, need);
+                if (ea != hipSuccess) return eagle_fail_hip(ctx, ea, "pace counters");
+                ctx->gemm_scratch_cap = need;
+            }
+            hipError_t ea = hipMemsetAsync(ctx->gemm_scratch, 0, need, s);
+            if (ea != hipSuccess) return eagle_fail_hip(ctx, ea, "pace counters memset");
+            hipLaunchKernelGGL(k_vara_i8p<true>, gridw, dim3(512), 2 * (TW_ABYTES + TILE_BYTES), s, Mt8s, ld, ntw, Bs, n_pad, hdr, q, L_pad, cut, (int*)ctx->gemm_scratch);
+        }
     } else
     hipLaunchKernelGGL(k_vara_i8, dim3((unsigned)(groups * 8 * smax)), dim3(512), 5 * TILE_BYTES, s, Mt8s, ld, ntm, Bs, n_pad, hdr, q, L_pad);
     hipLaunchKernelGGL(k_vara_i8_finish, dim3((unsigned)((L_pad + 255) / 256)), dim3(256), 0, s, q, L_pad, hdr, vdiag, cshift, mrho, vara_out);

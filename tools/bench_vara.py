@@ -10,7 +10,7 @@ from eagleeverything_amd.sharded import DeviceShard
 
 n, L = int(os.environ.get("N", 5000)), int(os.environ.get("LM", 131072))
 S = int(os.environ.get("SLICES", 5))
-variants = [int(v) for v in os.environ.get("VARIANTS", "0,9,8").split(",")]  # 0 = shipped (384 x 256 tile, asm-pipelined k-step), 9 = the same tile scheduled by hipcc, 8 = the 256 x 256 tile form, 7 = no cut of the last round
+variants = [int(v) for v in os.environ.get("VARIANTS", "0,9,8").split(",")]  # 0 = shipped (384 x 256 tile, asm-pipelined k-step), 9 = the same tile scheduled by hipcc, 8 = the 256 x 256 tile form, 7 = no cut of the last round, 14 = the XCD's workers paced by a soft barrier per column-tile pair (k_vara_i8p<true>, round-3 experiment)
 lib = _lib.load()
 sh = DeviceShard(n, L)
 sh.fill_synthetic()

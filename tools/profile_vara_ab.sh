@@ -11,13 +11,14 @@ KF="--kernel-include-regex k_vara_i8"
 rocprofv3 $KF --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq -o pmc -- python3 $ROOT/tools/bench_vara.py > $OUT/pmc_sq.log 2>&1 || { tail -5 $OUT/pmc_sq.log; exit 1; }
 rocprofv3 $KF --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_grbm -o pmc -- python3 $ROOT/tools/bench_vara.py > $OUT/pmc_grbm.log 2>&1 || { tail -5 $OUT/pmc_grbm.log; exit 1; }
 rocprofv3 $KF --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python3 $ROOT/tools/bench_vara.py > $OUT/pmc_fetch.log 2>&1 || { tail -5 $OUT/pmc_fetch.log; exit 1; }
+rocprofv3 $KF --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT/pmc_tcc -o pmc -- python3 $ROOT/tools/bench_vara.py > $OUT/pmc_tcc.log 2>&1 || { tail -5 $OUT/pmc_tcc.log; exit 1; }
 cd $ROOT && python3 - $OUT > $OUT/summary.txt <<'PY'
 import csv, glob, os, sys
 from collections import defaultdict
 out = sys.argv[1]
 acc = defaultdict(lambda: defaultdict(list))
 dur = defaultdict(list)
-for tag in ("pmc_sq", "pmc_grbm", "pmc_fetch"):
+for tag in ("pmc_sq", "pmc_grbm", "pmc_fetch", "pmc_tcc"):
     for f in glob.glob(os.path.join(out, tag, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0]
@@ -41,6 +42,8 @@ for k in sorted(acc):
     if "GRBM_GUI_ACTIVE" in c and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
         print("  MFMA busy fraction of GPU cycles %.3f (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 128))" % (c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] * 128)))
     if "SQ_WAIT_INST_ANY" in c and "SQ_WAVE_CYCLES" in c: print("  wait-inst / wave cycles %.3f" % (c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]))
+    if "TCC_REQ_sum" in c: print("  L2 hit rate %.3f" % (c["TCC_HIT_sum"] / c["TCC_REQ_sum"]))
+    if "FETCH_SIZE" in c: print("  fabric-side read bytes 2 x FETCH_SIZE x 1024 = %.1f GB per launch" % (2 * c["FETCH_SIZE"] * 1024 / 1e9))
 PY
 cat $OUT/summary.txt
 find $OUT -name "*.db" -delete
