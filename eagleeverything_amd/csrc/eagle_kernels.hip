@@ -19,6 +19,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
 
 #define WAVE 64
 
@@ -1039,6 +1040,204 @@ __global__ __launch_bounds__(256) void k_gemm_f64_dma_tail(const double* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_vara_f64d (round 3): the fp64 vara kernel -- scan mode 0, the re-evaluation engine of the certification, the overflow fallback --
+// rebuilt on the lessons of k_gemm_f64_dma: every vector instruction between two fp64 MFMAs of a wave costs ~6 of the matrix pipe's
+// cycles (tools/ubench/f64_ceiling.hip), and k_vara_f64 converted its int8 A fragments to doubles inside the K loop (12 VALU per
+// 16 MFMAs, every element converted by both column waves) on top of register-staged B tiles.  Here
+//   * the genotype bytes of a K block are converted ONCE by the staging threads (8 per thread) and written to LDS as an fp64 tile
+//     [128 rows][128 B] with k_gemm_f64_dma's chunk swizzle; the fragments come back with two ds_read_b128 per 16-row tile;
+//   * Wu's K block arrives by LDS-DMA ([16 k][1 KiB], 128-byte block swizzle), no VGPR staging;
+//   * same lane-group ownership of k as k_gemm_f64_dma ({2g, 2g+1, 8+2g, 9+2g}), same barrier-to-barrier regions;
+//   * 4 waves 2 x 2, wave tile 64 x 64, two workgroups per CU (64 KiB of LDS each): two waves per SIMD.
+// Everything that DEFINES the result is as in k_vara_f64 except the k order inside a K block: per (row, column tile, 2048-deep K
+// chunk, 64-column half) the MFMA chain over the chunk, a 4-term chain + 16-lane butterfly, the partial row-dots added tiles
+// ascending, chunks ascending, the two halves last.  SPLIT = true puts every (tile, chunk) on its own workgroup and k_vara_f64_sum
+// forms the same chain: bitwise the same value for a row whichever form computed it.  (tune 28: the round-2 kernel, for A/B runs.)
+// ------------------------------------------------------------------------------------------------
+#define V2_A_BYTES (GF_T * GF_BK * 8)
+#define V2_B_BYTES (GF_BK * GF_T * 8)
+#define V2_STAGE (V2_A_BYTES + V2_B_BYTES)
+template <bool SPLIT>
+__global__ __launch_bounds__(256, 2) void k_vara_f64d(const int8_t* __restrict__ A8, long lda, const double* __restrict__ B, long ldb,
+                                                      double* __restrict__ out, int n_coltiles, long K, const int* __restrict__ gate,
+                                                      double* __restrict__ partial) {
+    __shared__ __attribute__((aligned(1024))) char lds[2][V2_STAGE];
+    __shared__ double Psum[2][GF_T];  // the running row-dots P_wc(row) of the non-SPLIT form (in LDS: 32 VGPRs the K loop needs)
+    if (gate) {
+        if (!SPLIT && *gate == 0) return;
+        if (SPLIT && (long)blockIdx.x * GF_T >= (long)*gate) return;
+    }
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = w >> 1, wc = w & 1;
+    const int i16 = lane & 15, g = lane >> 4;
+    const long row0 = (long)blockIdx.x * GF_T;
+    const int8_t* Ablk = A8 + row0 * lda;
+    int mlim = 4;  // SPLIT with a row count: 16-row tiles entirely beyond the count are not computed (wave-uniform)
+    if (SPLIT && gate) {
+        const long left = (long)*gate - row0 - wr * 64;
+        mlim = left <= 0 ? 0 : (left >= 64 ? 4 : (int)((left + 15) >> 4));
+        mlim = __builtin_amdgcn_readfirstlane(mlim);
+    }
+    const int nchunk_max = (int)((K + GF_KC - 1) / GF_KC);
+    // staging of A: thread t converts the 8 bytes k0 + 8 ah .. of row ar and writes chunks 4 ah + j (k = 8 ah + 2j, 2j+1), swizzled
+    const int ar = t >> 1, ah = t & 1;
+    const int8_t* Arow = Ablk + (long)ar * lda + 8 * ah;
+    int wrA[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) wrA[j] = ar * 128 + (((4 * ah + j) ^ ((ar >> 1) & 7)) << 4);
+    // DMA of B: wave w issues rows 4w .. 4w+3 of the K block; rows 4w, 4w+1 have (k >> 1) & 1 = 0, rows 4w+2, 4w+3 have 1
+    const int ldb8 = (int)(ldb * 8);
+    const int voffB0 = ((lane >> 3) << 7) + ((lane & 7) << 4), voffB1 = voffB0 ^ 128;
+    const int offA = (wr * 64 + i16) * 128 + ((g ^ (i16 >> 1)) << 4);
+    const int offB = V2_A_BYTES + (2 * g) * 1024 + i16 * 8;
+    const char* pAx[2] = {lds[0] + offA, lds[1] + offA};
+    const char* pAy[2] = {lds[0] + (offA ^ 64), lds[1] + (offA ^ 64)};
+    const char* pB[2][4];
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        const int blk = ((wc * 4 + n) ^ (g & 1)) << 7;
+        pB[0][n] = lds[0] + offB + blk;
+        pB[1][n] = lds[1] + offB + blk;
+    }
+    if (!SPLIT) { Psum[t >> 7][t & 127] = 0.0; }   // (made visible by the barriers of the first chunk)
+    const int ct0 = SPLIT ? (int)blockIdx.y : 0;
+    const int ct1 = SPLIT ? (int)blockIdx.y + 1 : n_coltiles;
+    for (int ct = ct0; ct < ct1; ct++) {
+        const double* Bblk = B + (long)ct * GF_T;
+        const long kend = (long)(ct + 1) * GF_T < K ? (long)(ct + 1) * GF_T : K;
+        const int c0 = SPLIT ? (int)blockIdx.z : 0;
+        const int c1 = SPLIT ? (int)blockIdx.z + 1 : nchunk_max;
+        for (int c = c0; c < c1; c++) {
+            const long kc0 = (long)c * GF_KC;
+            if (kc0 >= kend) break;
+            const long kc1 = kc0 + GF_KC < kend ? kc0 + GF_KC : kend;
+            const int nkb = (int)((kc1 - kc0) / GF_BK);
+            f64x4 acc[4][4];
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int n = 0; n < 4; n++) acc[m][n] = (f64x4){0.0, 0.0, 0.0, 0.0};
+            i32x2 a8;   // the 8 genotype bytes this thread stages next
+            auto a_load = [&](int kb) { a8 = *(const i32x2*)(Arow + kc0 + (long)kb * GF_BK); };
+            auto a_store = [&](char* st) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int d = a8[j >> 1], sh = (j & 1) * 16;
+                    f64x2 v;
+                    v[0] = (double)((d << (24 - sh)) >> 24);
+                    v[1] = (double)((d << (16 - sh)) >> 24);
+                    *(f64x2*)(st + wrA[j]) = v;
+                }
+            };
+            auto b_dma = [&](int kb, char* st) {
+                const __amdgpu_buffer_rsrc_t rsB =
+                    __builtin_amdgcn_make_buffer_rsrc((void*)(Bblk + (kc0 + (long)kb * GF_BK) * ldb), 0, GF_BK * ldb8, 0x00020000);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int k = w * 4 + i;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(st + V2_A_BYTES + k * 1024), 16, (i & 2) ? voffB1 : voffB0, k * ldb8, 0, 0);
+                }
+            };
+            f64x2 ax[4], ay[4];
+            double bx[4][2], by[4][2];
+#define V2_READ_X(ST)                                                              \
+    do {                                                                           \
+        _Pragma("unroll") for (int m = 0; m < 4; m++) ax[m] = *(const f64x2*)(pAx[ST] + m * 2048); \
+        _Pragma("unroll") for (int n = 0; n < 4; n++) {                            \
+            bx[n][0] = *(const double*)(pB[ST][n]);                                \
+            bx[n][1] = *(const double*)(pB[ST][n] + 1024);                         \
+        }                                                                          \
+    } while (0)
+#define V2_READ_Y(ST)                                                              \
+    do {                                                                           \
+        _Pragma("unroll") for (int m = 0; m < 4; m++) ay[m] = *(const f64x2*)(pAy[ST] + m * 2048); \
+        _Pragma("unroll") for (int n = 0; n < 4; n++) {                            \
+            by[n][0] = *(const double*)(pB[ST][n] + 8192);                         \
+            by[n][1] = *(const double*)(pB[ST][n] + 8192 + 1024);                  \
+        }                                                                          \
+    } while (0)
+#define V2_MFMA(A_, B_, M0, M1)                                                    \
+    do {                                                                           \
+        _Pragma("unroll") for (int e = 0; e < 2; e++)                              \
+            _Pragma("unroll") for (int m = M0; m < M1; m++)                        \
+                if (!SPLIT || m < mlim) {                                          \
+                    _Pragma("unroll") for (int n = 0; n < 4; n++)                  \
+                        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(A_[m][e], B_[n][e], acc[m][n], 0, 0, 0); \
+                }                                                                  \
+    } while (0)
+            // region = the code between two barriers, on stage buffer ST holding K block kb_ (see k_gemm_f64_dma): stage kb_+1 is
+            // made here -- A bytes (loaded a region ago) converted and written, B by DMA -- and the A bytes of kb_+2 are requested
+#define V2_REGION(ST, kb_, first, more, more2)                                     \
+    do {                                                                           \
+        if (more) a_store(lds[(ST) ^ 1]);                                          \
+        V2_READ_X(ST);                                                             \
+        if (!(first)) V2_MFMA(ay, by, 2, 4);                                       \
+        V2_READ_Y(ST);                                                             \
+        if (!SPLIT) {                                                              \
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                     \
+            if (!(first)) __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);      \
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                     \
+            __builtin_amdgcn_sched_barrier(0);                                     \
+        }                                                                          \
+        /* the DMA of the next stage's Wu rows and the request for the A bytes after next go out BEHIND this region's last LDS  */ \
+        /* read: hipcc puts an s_waitcnt vmcnt(0) in front of the first LDS read that follows an LDS-DMA here (measured: 0.81   */ \
+        /* of the peak with the DMA at the top of the region, every wave waiting a memory latency per K block)                  */ \
+        if (more) b_dma((kb_) + 1, lds[(ST) ^ 1]);                                  \
+        if (more2) a_load((kb_) + 2);                                              \
+        V2_MFMA(ax, bx, 0, 4);                                                     \
+        V2_MFMA(ay, by, 0, 2);                                                     \
+        if (!SPLIT) __builtin_amdgcn_sched_barrier(0);                             \
+        __syncthreads();                                                           \
+    } while (0)
+            a_load(0);
+            __syncthreads();   // the previous chunk's readers are done with both stage buffers
+            a_store(lds[0]);
+            b_dma(0, lds[0]);
+            if (nkb > 1) a_load(1);
+            __syncthreads();
+            V2_REGION(0, 0, true, nkb > 1, nkb > 2);
+            int i = 1;
+            for (; i + 2 <= nkb; i += 2) {
+                V2_REGION(1, i, false, true, i + 2 < nkb);
+                V2_REGION(0, i + 1, false, i + 2 < nkb, i + 3 < nkb);
+            }
+            if (i < nkb) V2_REGION(1, i, false, false, false);
+            V2_MFMA(ay, by, 2, 4);
+#undef V2_REGION
+#undef V2_MFMA
+#undef V2_READ_X
+#undef V2_READ_Y
+            // C/D map of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const long r = row0 + wr * 64 + m * 16 + g + 4 * q;
+                    const int8_t* mr = A8 + r * lda + (long)ct * GF_T + wc * 64 + i16;
+                    double sdot = 0.0;
+#pragma unroll
+                    for (int n = 0; n < 4; n++) sdot += acc[m][n][q] * (double)mr[n * 16];
+                    sdot += __shfl_xor(sdot, 1);
+                    sdot += __shfl_xor(sdot, 2);
+                    sdot += __shfl_xor(sdot, 4);
+                    sdot += __shfl_xor(sdot, 8);
+                    if (SPLIT) {
+                        if (i16 == 0)
+                            partial[((((long)blockIdx.x * n_coltiles + ct) * nchunk_max + c) * 2 + wc) * GF_T + wr * 64 + m * 16 + g + 4 * q] = sdot;
+                    } else if (i16 == 0) {
+                        Psum[wc][wr * 64 + m * 16 + g + 4 * q] += sdot;   // this lane alone owns the element: same chain as a register
+                    }
+                }
+        }
+    }
+    if (!SPLIT) {
+        __syncthreads();
+        if (t < 128) out[row0 + t] = Psum[0][t] + Psum[1][t];
+    }
+}
+
 // device tile lists, cached per (device, tiles per side, kind): 0 = all tiles, 1 = row tile <= column tile, 2 = row tile > column tile
 #include <map>
 #include <mutex>
@@ -1537,8 +1736,12 @@ extern "C" int eagle_dev_vara_f64_gated(eagle_ctx* ctx, const int8_t* Mt8, long 
         return eagle_fail(ctx, EAGLE_ERR_ARG, "vara_f64: layout contract violated");
     if (L_pad == 0) return EAGLE_OK;
     dim3 grid((unsigned)(L_pad / GF_T));
-    hipLaunchKernelGGL((k_vara_f64<false>), grid, dim3(256), 0, (hipStream_t)stream, Mt8, ld, Wu, n_pad, vara_out, (int)(n_pad / GF_T), n_pad,
-                       run_if, (double*)nullptr);
+    if (ctx->tune == 28)  // the round-2 kernel (A/B runs)
+        hipLaunchKernelGGL((k_vara_f64<false>), grid, dim3(256), 0, (hipStream_t)stream, Mt8, ld, Wu, n_pad, vara_out, (int)(n_pad / GF_T), n_pad,
+                           run_if, (double*)nullptr);
+    else
+        hipLaunchKernelGGL((k_vara_f64d<false>), grid, dim3(256), 0, (hipStream_t)stream, Mt8, ld, Wu, n_pad, vara_out, (int)(n_pad / GF_T), n_pad,
+                           run_if, (double*)nullptr);
     LAUNCH_CHECK(ctx);
     return EAGLE_OK;
 }
@@ -1555,8 +1758,12 @@ extern "C" int eagle_dev_vara_f64_split(eagle_ctx* ctx, const int8_t* rows8, lon
     if (rows_cap == 0) return EAGLE_OK;
     const int nct = (int)(n_pad / GF_T);
     dim3 grid((unsigned)(rows_cap / GF_T), (unsigned)nct, (unsigned)((n_pad + GF_KC - 1) / GF_KC));
-    hipLaunchKernelGGL((k_vara_f64<true>), grid, dim3(256), 0, (hipStream_t)stream, rows8, ld, Wu, n_pad, (double*)nullptr, nct, n_pad, count_dev,
-                       partial);
+    if (ctx->tune == 28)
+        hipLaunchKernelGGL((k_vara_f64<true>), grid, dim3(256), 0, (hipStream_t)stream, rows8, ld, Wu, n_pad, (double*)nullptr, nct, n_pad, count_dev,
+                           partial);
+    else
+        hipLaunchKernelGGL((k_vara_f64d<true>), grid, dim3(256), 0, (hipStream_t)stream, rows8, ld, Wu, n_pad, (double*)nullptr, nct, n_pad, count_dev,
+                           partial);
     hipLaunchKernelGGL(k_vara_f64_sum, dim3((unsigned)(rows_cap / GF_T)), dim3(GF_T), 0, (hipStream_t)stream, partial, nct, n_pad, count_dev, dst_dev, out);
     LAUNCH_CHECK(ctx);
     return EAGLE_OK;

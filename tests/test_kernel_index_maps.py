@@ -196,3 +196,57 @@ def test_gemm_f64_dma_tile_lists_cover_every_128_tile_once():
         assert {(i, j) for i in range(nt) for j in range(nt) if i <= j} <= up       # every 128-tile on or above the diagonal
         below = {(ii, j) for i, j in tiles(nt, 3, 0, nt) for ii in (i, i + 1)}
         assert {(i, j) for i in range(nt) for j in range(nt) if i >= j} <= below    # ... on or below it (stored transposed)
+
+
+def test_vara_f64d_lds_maps():
+    """k_vara_f64d: the staging threads' fp64 A tile, the Wu DMA and the fragment reads agree on one layout, the reads are free of
+    bank conflicts and a K block's sixteen k are owned once each."""
+    A_BYTES = 128 * 128
+    # (1) A: thread t converts bytes k = 8 ah + 2j, 2j + 1 of row ar = t >> 1 and writes logical chunk 4 ah + j at chunk ^ ((ar >> 1) & 7)
+    written = {}
+    for t in range(256):
+        ar, ah = t >> 1, t & 1
+        for j in range(4):
+            a = ar * 128 + (((4 * ah + j) ^ ((ar >> 1) & 7)) << 4)
+            r, p = a // 128, (a % 128) // 16
+            assert r == ar and p ^ ((r >> 1) & 7) == 4 * ah + j
+            assert a not in written
+            written[a] = (ar, 8 * ah + 2 * j)
+    assert len(written) == 128 * 8
+    # (2) Wu by DMA: wave w, instruction i writes row k = 4w + i of the stage (wave-linear 1 KiB); source block q of lane at q ^ ((k >> 1) & 1)
+    for w in range(4):
+        for i in range(4):
+            k = 4 * w + i
+            for lane in range(64):
+                voffB0 = ((lane >> 3) << 7) + ((lane & 7) << 4)
+                voff = voffB0 ^ 128 if (i & 2) else voffB0
+                phys_blk, within = lane >> 3, lane & 7
+                assert voff == ((phys_blk ^ ((k >> 1) & 1)) << 7) + within * 16
+    # (3) fragment reads
+    for wr in range(2):
+        for m in range(4):
+            for h in range(2):
+                def addrA(lane):
+                    i16, g = lane & 15, lane >> 4
+                    offA = (wr * 64 + i16) * 128 + ((g ^ (i16 >> 1)) << 4)
+                    return (offA ^ (h << 6)) + m * 2048
+                assert _conflict_free(addrA, B128_GROUPS, 16)
+                for lane in range(64):
+                    i16, g = lane & 15, lane >> 4
+                    r, k0 = written[addrA(lane)]
+                    assert r == wr * 64 + m * 16 + i16 and k0 == 2 * g + 8 * h
+    for wc in range(2):
+        for n in range(4):
+            for h in range(2):
+                for e in range(2):
+                    def addrB(lane):
+                        i16, g = lane & 15, lane >> 4
+                        return A_BYTES + (2 * g) * 1024 + i16 * 8 + h * 8192 + e * 1024 + (((wc * 4 + n) ^ (g & 1)) << 7)
+                    assert _conflict_free(addrB, B64_GROUPS, 8)
+                    for lane in range(64):
+                        i16, g = lane & 15, lane >> 4
+                        a = addrB(lane) - A_BYTES
+                        k, blk, col = a // 1024, (a % 1024) // 128, (a % 128) // 8
+                        assert k == 2 * g + e + 8 * h
+                        assert blk ^ ((k >> 1) & 1) == wc * 4 + n and col == i16
+    assert A_BYTES + 16 * 1024 == 32768                                    # one stage; two stages + Psum = 66 KiB: two workgroups per CU
