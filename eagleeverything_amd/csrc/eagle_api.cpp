@@ -310,6 +310,13 @@ extern "C" int eagle_set_scan_rounding(eagle_ctx* ctx, int stochastic) {
     for (eagle_ctx* p : ctx->peers) p->scan_stochastic = stochastic;
     return EAGLE_OK;
 }
+extern "C" int eagle_set_scan_budget(eagle_ctx* ctx, double relative_budget) {
+    if (!ctx || !(relative_budget >= 1e-12 && relative_budget <= 5e-7)) return EAGLE_ERR_ARG;   // 1.8 x budget is enforced per marker: never above 0.9e-6
+    ctx->scan_budget = relative_budget;
+    ctx->spectral_off = false;
+    for (eagle_ctx* p : ctx->peers) { p->scan_budget = relative_budget; p->spectral_off = false; }
+    return EAGLE_OK;
+}
 extern "C" int eagle_set_scan_slices(eagle_ctx* ctx, int nslices) {
     if (!ctx || nslices < 0 || nslices > 8) return EAGLE_ERR_ARG;
     ctx->scan_slices = nslices;
@@ -1389,9 +1396,15 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
         HIPCHK(ctx, hipMemcpyAsync(vara_out + m0, ctx->d_vara, sizeof(double) * (size_t)Lr, hipMemcpyDeviceToHost, ctx->stream));
     }
     HIPCHK(ctx, hipMemcpyAsync(totals, cert_totals, sizeof totals, hipMemcpyDeviceToHost, ctx->stream));
+    struct { double maxabs_off; int S, pad; double bound, sumdiag, R, specH; int S_sliced, pad2; } vh = {};   // head of the digit workspace (VaraHdr)
+    if (use_i8 && Lr > 0) HIPCHK(ctx, hipMemcpyAsync(&vh, ws, sizeof vh, hipMemcpyDeviceToHost, ctx->stream));
     ph.mark(ctx->stream, PH_D2H);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cert_reevaluated = totals[0]; ctx->cert_flagged = totals[1]; ctx->cert_fell_back = totals[2] != 0;
+    ctx->scan_digits_used = vh.S; ctx->scan_digits_cut = vh.S_sliced; ctx->scan_specH = vh.specH;
+    // a scan that took a digit off under the spectral bound and then had to redo a block in fp64: markers of this data set sit
+    // outside what the bound covers -- this context keeps the worst-case digit count from now on (eagle_set_scan_budget re-arms)
+    if (ctx->cert_fell_back && vh.specH > 0.0) ctx->spectral_off = true;
     ph.sum(ctx->scan_phase_ms);
     ctx->scan_blocks = streamed ? ring.k : 1;
     ctx->scan_host_setup_s = t_setup - t0;
@@ -1441,7 +1454,10 @@ extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_asc
     if (rc) return rc;
     for (eagle_ctx* p : ctx->peers) {
         ctx->cert_reevaluated += p->cert_reevaluated; ctx->cert_flagged += p->cert_flagged; ctx->cert_fell_back |= p->cert_fell_back;
+        ctx->spectral_off |= p->spectral_off;
+        if (!ctx->scan_digits_cut) { ctx->scan_digits_used = p->scan_digits_used; ctx->scan_digits_cut = p->scan_digits_cut; ctx->scan_specH = p->scan_specH; }
     }
+    for (eagle_ctx* p : ctx->peers) p->spectral_off = ctx->spectral_off;   // every device of the next scan decides alike
     return EAGLE_OK;
 }
 
@@ -1471,7 +1487,10 @@ extern "C" int eagle_scan_with_W(eagle_ctx* ctx, const char* f_name_ascii, const
     if (rc) return rc;
     for (eagle_ctx* p : ctx->peers) {
         ctx->cert_reevaluated += p->cert_reevaluated; ctx->cert_flagged += p->cert_flagged; ctx->cert_fell_back |= p->cert_fell_back;
+        ctx->spectral_off |= p->spectral_off;
+        if (!ctx->scan_digits_cut) { ctx->scan_digits_used = p->scan_digits_used; ctx->scan_digits_cut = p->scan_digits_cut; ctx->scan_specH = p->scan_specH; }
     }
+    for (eagle_ctx* p : ctx->peers) p->spectral_off = ctx->spectral_off;   // every device of the next scan decides alike
     return EAGLE_OK;
 }
 
@@ -1515,6 +1534,14 @@ extern "C" int eagle_last_scan_certificate(eagle_ctx* ctx, long* n_reevaluated, 
     if (n_reevaluated) *n_reevaluated = ctx->cert_reevaluated;
     if (n_flagged) *n_flagged = ctx->cert_flagged;
     if (fell_back) *fell_back = ctx->cert_fell_back;
+    return EAGLE_OK;
+}
+
+extern "C" int eagle_last_scan_digits(eagle_ctx* ctx, int* digits_used, int* digits_cut, double* spectral_bound) {
+    if (!ctx) return EAGLE_ERR_ARG;
+    if (digits_used) *digits_used = ctx->scan_digits_used;
+    if (digits_cut) *digits_cut = ctx->scan_digits_cut;
+    if (spectral_bound) *spectral_bound = ctx->scan_specH;
     return EAGLE_OK;
 }
 

@@ -53,12 +53,15 @@ struct eagle_ctx {
     int scan_mode = 1;   // 1 = int8 digit slices on the int8 MFMA (default), 0 = fp64 MFMA
     int scan_slices = 0; // 0 = chosen per call from the error bound (3..7), 1..8 = fixed
     int scan_stochastic = 0;  // 1 = digits of W rounded at random (unbiased): probabilistic certificate, one digit fewer (opt-in)
+    double scan_budget = 5e-7;  // relative digit budget of the int8 scan (eagle_set_scan_budget): half of the path's 1e-6 tolerance
+    bool spectral_off = false;  // a scan that took a digit off under the spectral bound fell back to fp64: this context stops trying
     std::vector<GenoEntry> cache;
     // results of the last calls, kept in HBM
     double* d_mmt = nullptr; long mmt_n = 0; double* d_mmt_max = nullptr;
     double* d_a = nullptr; double* d_vara = nullptr; long scan_L = 0; long scan_cap = 0;
     double* d_bound = nullptr;  // a-posteriori error bound of every vara_i of the last digit-slice scan that ran in marker blocks / device shards
     long cert_reevaluated = 0, cert_flagged = 0; int cert_fell_back = 0;  // certification counters of the last digit-slice scan
+    int scan_digits_used = 0, scan_digits_cut = 0; double scan_specH = 0.0;  // digit slices of the last digit-slice scan (eagle_last_scan_digits)
     double scan_phase_ms[8] = {0}; long scan_blocks = 0;                  // phase clock of the last scan on this device (eagle_last_scan_timing)
     double scan_host_setup_s = 0, scan_range_wall_s = 0, scan_call_wall_s = 0;
     // S = inv_MMt_sqrt of the last scan, kept on the device: MMt^-1/2 is the same matrix in every find_qtl call of an AM() run

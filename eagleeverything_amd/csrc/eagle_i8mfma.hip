@@ -262,7 +262,7 @@ extern "C" int eagle_dev_mmt_accumulate_i8(eagle_ctx* ctx, const int8_t* M8, lon
 // vara from int8 digit slices of Wu.
 //
 //   Wu (upper triangular fold of W, fp64) = 2^(e+2) * sum_{s<S} D_s * 256^-(s+1)  +  R,   |R_jk| <= 2^(e+1-8S)
-//   with max|Wu| < 2^e, D_0 in [-65,65], D_s in [-128,127]: the balanced base-256 digits of the exact integer
+//   with max|Wu| < 2^e (< 1.96 * 2^e when the mantissa leaves room: w_scale_exp), D_s in [-128,127]: the balanced base-256 digits of the exact integer
 //   round(Wu * 2^(8S-e-2)) (below 2^(8S-2) <= 2^62, so int64 arithmetic; a balanced digit set needs 257 values per
 //   level when produced most-significant first, so the digits are peeled least-significant first with a carry).
 //   q_s[i] = sum_k m_ik sum_{j<=k} m_ij D_s[j][k]   is an exact integer (int32 MFMA sums, int64 across tiles), so
@@ -291,7 +291,25 @@ struct VaraHdr {        // head of the workspace, written on the device, never r
     double bound;       // n_pad^2 * 2^(e+1-8S): absolute error bound of every vara_i
     double sumdiag;     // sum_k |Wu[k][k]|
     double R;           // sum_{j<k} Wu[j][k] (the off-diagonal quadratic form of the all-ones vector)
+    double specH;       // > 0: the scan runs on S = S_sliced - 1 digits and |digit error of marker i| <= specH * sum_j m'_ij^2 (k_spectral_decide)
+    int S_sliced;       // digits k_slice_w cut (the scale of the integers Q); S_sliced - S is 0 or 1
+    int pad2;
+    double budget;      // the digit budget of this scan (eagle_set_scan_budget)
+    int e;              // the scale exponent w_scale_exp(maxabs_off): the digits are those of round(Wu * 2^(8 S_sliced - e - 2))
+    int pad3;
 };
+// Scale exponent of the digits: max|Wu_jk| (j != k) < 2^e, lowered by one when the mantissa leaves room (round 3) -- a balanced S-digit
+// number reaches 127 (256^S - 1)/255 = 0.498 * 256^S, and |Q| <= max|Wu| 2^(8S-e-2) + 1 stays below 0.49 * 256^S + 1 for a mantissa up
+// to 0.98: one more bit of resolution for the same digits on 96 % of all scales (rounds 1-2 always kept the leading digit inside
+// [-65, 65]).  A power of two, so that Wu * 2^(8S-e-2) is exact and llrint rounds the true value.
+__device__ __forceinline__ int w_scale_exp(double mx) {
+    int e = 0;
+    if (mx > 0.0) {
+        const double f = frexp(mx, &e);
+        if (f <= 0.98) e -= 1;
+    }
+    return e;
+}
 
 __global__ __launch_bounds__(256) void k_absmax_offdiag(const double* __restrict__ x, long np, unsigned long long* __restrict__ bits) {
     double m = 0.0;
@@ -315,7 +333,12 @@ __global__ __launch_bounds__(256) void k_absmax_offdiag(const double* __restrict
 // and monomorphic markers (vara = 0 up to fp64 noise in the reference too) take no digit error at all.
 // Measured errors sit three orders below the bound (C2, S = 4: bound 1.7e-8, largest error against an fp64 evaluation
 // 1.5e-11).  eagle_set_scan_slices forces more digits.
-#define VARA_DIGIT_BUDGET 1e-7
+// Round 3: the budget is a property of the context (eagle_set_scan_budget, default VARA_DIGIT_BUDGET = 5e-7 = half the path's
+// tolerance; 1e-7 until round 2), and one digit fewer than the worst case asks for is taken when the SPECTRAL bound below allows it.
+#define VARA_DIGIT_BUDGET 5e-7
+// What the certificate enforces per marker: a bound above VARA_FLAG_FACTOR x budget sends the marker to the fp64 kernel (0.9e-6 of
+// the 1e-6 tolerance with the default budget; the rest covers the fp64 roundings, orders of magnitude smaller).
+#define VARA_FLAG_FACTOR 1.8
 // Stochastic rounding (EAGLE_SLICES_STOCHASTIC, opt-in).  With round-to-nearest the truncation errors R_jk of the digits are
 // only known to lie in [-delta, delta], delta = 2^(e+1-8S), and the guaranteed bound must add them up in absolute value:
 // l1^2/2 * delta.  If instead each entry is rounded down or up AT RANDOM with the probabilities that make the rounding
@@ -329,7 +352,7 @@ __global__ __launch_bounds__(256) void k_absmax_offdiag(const double* __restrict
 #define VARA_HOEFFDING_K 8.355  /* sqrt(ln(2 / 1e-30)) */
 // One block: dW[k] = Wu[k][k] (contiguous copy), sumdiag in a fixed order, then the slice count (forced = 1..8: that S).
 __global__ __launch_bounds__(256) void k_vara_prep(const double* __restrict__ Wu, long n_pad, int forced_arg, VaraHdr* __restrict__ hdr,
-                                                   double* __restrict__ dW) {
+                                                   double* __restrict__ dW, double budget) {
     const int forced = forced_arg & 0xff, stochastic = (forced_arg & EAGLE_SLICES_STOCHASTIC) ? 1 : 0;
     double s = 0.0;
     for (long k = threadIdx.x; k < n_pad; k += 256) {
@@ -345,13 +368,12 @@ __global__ __launch_bounds__(256) void k_vara_prep(const double* __restrict__ Wu
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        int e = 0;
         const double mx = hdr->maxabs_off;
-        if (mx > 0.0) (void)frexp(mx, &e);
+        const int e = w_scale_exp(mx);
         const double nn = (double)n_pad * (double)n_pad;
         int S = forced;
         if (S <= 0) {
-            const double target = VARA_DIGIT_BUDGET * 0.5 * red[0];
+            const double target = budget * 0.5 * red[0];
             S = 7;
             for (int c = stochastic ? 2 : 3; c <= 7; c++) {
                 // worst case over markers: every entry non-zero (nearest: errors aligned; stochastic: q2 = n, the Hoeffding radius)
@@ -361,9 +383,146 @@ __global__ __launch_bounds__(256) void k_vara_prep(const double* __restrict__ Wu
         }
         if (mx == 0.0) S = 1;
         hdr->S = S;
+        hdr->S_sliced = S;
+        hdr->specH = 0.0;
+        hdr->budget = budget;
+        hdr->e = e;
         hdr->pad = stochastic;
         hdr->sumdiag = red[0];
         hdr->bound = mx > 0.0 ? ldexp(nn, e + 1 - 8 * S) * (stochastic ? 2.0 : 1.0) : 0.0;  // what can never be exceeded
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// One digit fewer under a SPECTRAL bound of the truncation error (round 3).
+//
+// With S digits cut (k_slice_w), Wu_jk / u = Q_jk + rho_jk, u = 2^(e+2-8S), |rho_jk| <= 1/2, Q = sum_s d_s 256^(S-1-s).  A scan on the
+// leading S-1 digits alone leaves, for marker i (re-centred row m'),
+//     err_i = sum_{j<k} m'_j m'_k (Wu_jk - u (Q_jk - d_jk))  =  (u/2) m'^T (Ds + P) m',     d = the LAST digit, Ds = d + d^T, P = rho + rho^T,
+// so |err_i| <= (u/2) (||Ds||_2 + ||P||_2) q2_i with q2_i = sum_j m'_j^2 -- against the worst case l1_i^2/2 * 128.5 u of errors that all
+// line up.  The last digit of W is as good as random: ||Ds||_2 ~ 2 sqrt(n) sigma_d ~ 150 sqrt(n), and the spectral bound wins by
+// ~ l1^2 / (q2 sqrt(n)): two orders of magnitude for a common marker at n = 10,000, which with the budget above pays for a whole digit
+// (a quarter of the matrix work of the scan) on the operands of an AM() run.
+// The bound has to be RIGOROUS, and cheap next to the 33 ms it saves:  ||P||_2 <= ||P||_inf <= (n_pad - 1)/2, and
+//     ||Ds||_2^2 = lambda_max(Ds Ds) <= max_j sum_k |(Ds Ds)_jk|          (Gershgorin on the Gram matrix)
+// where Ds Ds is an EXACT int32 matrix product of an int8 matrix with itself: the tile engine above, 2 n^3 int8 MAC-flop (~1 ms at
+// n = 10,240), never stored -- the tile epilogue adds |.| into per-row int64 sums (k_gram_rowabs_i8).  Row sums of a random Gram matrix
+// overestimate lambda_max by ~0.45 n^(1/4) in the norm (5.3x at n = 10,240: tools/diag_spectral.py prints it against a power iteration);
+// enough.  k_spectral_decide then takes S-1 digits if a marker with q2 = n_pad stays inside the budget against 0.5 sum_k |W_kk| -- the
+// worst-case rule's yardstick -- and leaves specH = (u/2)(||Ds|| + (n_pad-1)/2) in the header: cert_bound uses
+// min(specH q2_i, l1_i^2/2 * 128.5 u) per marker.  Markers whose own bound still exceeds the budget are re-evaluated in fp64 like any
+// flagged marker; should more than CERT_CAP of them do (the fp64 fallback of the whole block), the context stops taking the digit
+// off (eagle_api.cpp).  Deterministic, a function of W alone: every device and every marker block of a scan decides the same.
+// Not used with a forced digit count, with stochastic rounding, or under tune 29 (A/B switch).
+// ------------------------------------------------------------------------------------------------
+// Ds[i][j] = last digit of Wu[min(i,j)][max(i,j)], 0 on the diagonal: symmetric int8 image, n_pad x n_pad (same llrint as k_slice_w)
+__global__ __launch_bounds__(256) void k_last_digit_sym(const double* __restrict__ Wu, long np, const VaraHdr* __restrict__ hdr, int8_t* __restrict__ Ds,
+                                                        int smax) {
+    __shared__ double tile[32][33];
+    if (hdr->S_sliced >= smax) return;   // every slot of the slice area holds a digit in use: no spare one for this image (S = 7: never taken down)
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long bx = blockIdx.x, by = blockIdx.y;
+    const long lo = bx < by ? bx : by, hi = bx < by ? by : bx;
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = Wu[(lo * 32 + r) * np + hi * 32 + tx];  // tile[a][b] = Wu[32 lo + a][32 hi + b]
+    __syncthreads();
+    const int e = hdr->e;
+    const int S = hdr->S_sliced;
+    for (int r = ty; r < 32; r += 8) {
+        double v;   // element (i = 32 by + r, j = 32 bx + tx)
+        if (by < bx) v = tile[r][tx];
+        else if (by > bx) v = tile[tx][r];
+        else v = r < tx ? tile[r][tx] : (r > tx ? tile[tx][r] : 0.0);
+        const long long Q = llrint(ldexp(v, 8 * S - (e + 2)));
+        Ds[(by * 32 + r) * np + bx * 32 + tx] = (int8_t)(((Q + 128) & 255) - 128);
+    }
+}
+
+// rs[i] += sum_j |(D D^T)_ij| over the upper-triangular 256-tile pairs of the symmetric product (both the row sums of a tile and, off
+// the diagonal, its column sums = the row sums of the mirrored tile).  Whole K per workgroup: |.| does not commute with a K split.
+__global__ __launch_bounds__(512, 2) void k_gram_rowabs_i8(const int8_t* __restrict__ D, long ld, const int* __restrict__ pairs, int npairs,
+                                                           long nstages, unsigned long long* __restrict__ rs) {
+    __shared__ __attribute__((aligned(1024))) int8_t lds[2][2][TILE_BYTES];
+    const int cpx = (gridDim.x + 7) / 8;
+    const int lid = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);   // an XCD gets a contiguous range of the super-tile ordered list
+    if (lid >= npairs) return;
+    const int pr = pairs[lid];
+    const int ti = pr >> 16, tj = pr & 0xffff;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = w >> 2, wc = w & 3;
+    const int ldi = (int)ld;
+    const T8Lane ln = t8_lane(lane, ldi);
+    const __amdgpu_buffer_rsrc_t rsA = t8_rsrc(D + (long)ti * T8 * ld, ldi);
+    const __amdgpu_buffer_rsrc_t rsB = t8_rsrc(D + (long)tj * T8 * ld, ldi);
+    i32x16 acc[4][2];
+    t8_zero(acc);
+    t8_stage(rsA, ln, ldi, 0, lds[0][0], w);
+    t8_stage(rsB, ln, ldi, 0, lds[0][1], w);
+    __syncthreads();
+    int cur = 0;
+    const T8Read rd = t8_read_init(wr, wc, lane);
+    for (long s = 0; s < nstages; s++) {
+        const int kn = (int)((s + 1) * BK8);
+        t8_stage_compute<0>(acc, lds[cur][0], lds[cur][1], rd, s + 1 < nstages, rsA, ln, ldi, kn, lds[cur ^ 1][0], rsB, ln, ldi, kn,
+                            lds[cur ^ 1][1], w);
+        __syncthreads();
+        cur ^= 1;
+    }
+    // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  |acc| <= 128^2 K: int64 sums throughout.
+    if (ti != tj) {
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+            unsigned long long cs = 0;
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int q = 0; q < 16; q++) { const int v = acc[m][n][q]; cs += (unsigned long long)(v < 0 ? -v : v); }
+            cs += __shfl_xor(cs, 32);
+            if (lane < 32) atomicAdd(&rs[(long)tj * T8 + wc * 64 + n * 32 + lane], cs);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int v0 = acc[m][0][q], v1 = acc[m][1][q];
+            unsigned long long r = (unsigned long long)(v0 < 0 ? -v0 : v0) + (unsigned long long)(v1 < 0 ? -v1 : v1);
+            r += __shfl_xor(r, 1);
+            r += __shfl_xor(r, 2);
+            r += __shfl_xor(r, 4);
+            r += __shfl_xor(r, 8);
+            r += __shfl_xor(r, 16);
+            if ((lane & 31) == 0) atomicAdd(&rs[(long)ti * T8 + wr * 128 + m * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5)], r);
+        }
+}
+
+// One block: g = max_j rs[j]; the decision (see above).  rs is exact, the fp64 steps round up.
+__global__ __launch_bounds__(256) void k_spectral_decide(const unsigned long long* __restrict__ rs, long n_pad, VaraHdr* __restrict__ hdr, double budget,
+                                                         int smax) {
+    unsigned long long g = 0;
+    for (long k = threadIdx.x; k < n_pad; k += 256) g = rs[k] > g ? rs[k] : g;
+    __shared__ unsigned long long red[256];
+    red[threadIdx.x] = g;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] = red[threadIdx.x + o] > red[threadIdx.x] ? red[threadIdx.x + o] : red[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double mx = hdr->maxabs_off;
+        const int S = hdr->S_sliced;
+        if (mx > 0.0 && S >= 2 && S < smax && hdr->S == S && !hdr->pad) {
+            const int e = hdr->e;
+            const double u = ldexp(1.0, e + 2 - 8 * S);
+            const double up = 1.0 + 0x1p-50;
+            const double normDs = sqrt((double)red[0] * up) * up;       // red[0] < 2^53 for n_pad < 2^19: the conversion is exact or rounds within `up`
+            const double H = 0.5 * u * (normDs + 0.5 * (double)(n_pad - 1)) * up;
+            if (H * (double)n_pad <= budget * 0.5 * hdr->sumdiag) {
+                hdr->S = S - 1;
+                hdr->specH = H;
+                hdr->bound = ldexp((double)n_pad * (double)n_pad, e + 1 - 8 * (S - 1)) * (1.0 + 0x1p-8);
+            }
+        }
     }
 }
 
@@ -380,14 +539,12 @@ __global__ __launch_bounds__(256) void k_slice_w(const double* __restrict__ Wu, 
     const long bj = (long)blockIdx.y * 32, bk = (long)blockIdx.x * 32;
     for (int r = ty; r < 32; r += 8) tile[r][tx] = Wu[(bj + r) * np + bk + tx];  // tile[jj][kk]
     __syncthreads();
-    int e = 0;
-    const double mx = hdr->maxabs_off;
+    const int e = hdr->e;   // w_scale_exp: mx < 2^e, or mx < 1.96 * 2^e when the mantissa leaves room
     const int nslices = hdr->S;
-    if (mx > 0.0) { (void)frexp(mx, &e); }  // mx = f * 2^e, f in [0.5,1)  ->  mx < 2^e
     for (int r = ty; r < 32; r += 8) {
-        // output element (k = bk + r, j = bj + tx):  Q = round(Wu * 2^(8S - e - 2)) is an exact integer below 2^(8S-2)
+        // output element (k = bk + r, j = bj + tx):  Q = round(Wu * 2^(8S - e - 2)) is an exact integer below 0.49 * 256^S + 1
         // (llrint of a double of that size is exact); its balanced base-256 digits, least significant first,
-        // d = ((Q + 128) mod 256) - 128 in [-128,127], Q <- (Q - d)/256; the leading digit ends in [-65,65].
+        // d = ((Q + 128) mod 256) - 128 in [-128,127], Q <- (Q - d)/256; the leading digit ends in [-126,126].
         long long Q = 0;
         if (bk + r != bj + tx) {
             const double yv = ldexp(tile[tx][r], 8 * nslices - (e + 2));
@@ -1205,10 +1362,8 @@ __global__ __launch_bounds__(256) void k_vara_i8_finish(const long long* __restr
                                                         const double* __restrict__ mrho, double* __restrict__ vara) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= Lp) return;
-    int e = 0;
-    const double mx = hdr->maxabs_off;
+    const int e = hdr->e;
     const int nslices = hdr->S;
-    if (mx > 0.0) (void)frexp(mx, &e);
     double s = 0.0;
     for (int k = nslices - 1; k >= 0; k--) s += ldexp((double)q[(long)k * Lp + i], e + 2 - 8 * (k + 1));  // smallest first
     const double c = cshift ? (double)cshift[i] : 0.0;  // re-centred marker: off(m) = off(m') + c m^T rho - c^2 R
@@ -1220,12 +1375,12 @@ __global__ __launch_bounds__(256) void k_vara_i8_finish(const long long* __restr
 // Certification of a digit-slice scan (find_qtl.R:71-83 must select the marker the fp64 arithmetic selects).
 //
 // Every vara_i of k_vara_i8_finish differs from the exact m_i^T W m_i by at most
-//     b_i = l1_i^2 / 2 * 2^(e+1-8S)  +  2^-48 (|diag_i| + |vara_i - diag_i| + 2|c_i m_i^T rho| + 2 c_i^2 |R|)  +  2^-50 sum_k |W_kk|,
+//     b_i = min(l1_i^2 / 2 * 2^(e+1-8S), specH q2_i [k_spectral_decide])  +  2^-48 (|diag_i| + |vara_i - diag_i| + 2|c_i m_i^T rho| + 2 c_i^2 |R|)  +  2^-50 sum_k |W_kk|,
 // l1_i = sum_j |m'_ij| of the re-centred marker (k_marker_shift): the first term is the truncation of W to S digits
 // (|sum_{j<k} m'_j m'_k R_jk| <= 2^(e+1-8S) ((sum|m'_j|)^2 - sum m'_j^2)/2), the others cover the fp64 roundings of the
 // handful of terms the finish kernel adds (each an exactly evaluated integer sum rounded once).
 // Markers are RE-EVALUATED with the fp64 kernel (k_vara_f64<SPLIT>, bitwise the value scan mode 0 gives that marker) when
-//   (1) b_i > 1e-7 |vara_i|                      -- the digit result is not certified to a tenth of the path's 1e-6 tolerance
+//   (1) b_i > 1.8 budget |vara_i|                -- the digit result is not certified to 0.9 of the path's 1e-6 tolerance (default budget 5e-7)
 //                                                   (a quadratic form that cancels against its diagonal term, or W with huge
 //                                                   off-diagonal entries), or
 //   (2) a_i^2 / (vara_i - b_i) >= LB (1 - 1e-9),  LB = max_j a_j^2 / (vara_j + b_j)  -- marker i cannot be excluded from being
@@ -1239,14 +1394,16 @@ __global__ __launch_bounds__(256) void k_vara_i8_finish(const long long* __restr
 #define CERT_CAP 2048
 struct CertHdr { unsigned long long lb_bits; int count; int overflow; int flagged; int pad; };  // = eagle_cert_info of the public header
 
-struct CertCtx { double delta, absR, sumdiag; int stochastic; };
+struct CertCtx { double delta, absR, sumdiag, specH, flag_rel; int stochastic; };
 __device__ __forceinline__ CertCtx cert_ctx(const VaraHdr* hdr) {
     CertCtx c;
-    int e = 0;
     const double mx = hdr->maxabs_off;
-    if (mx > 0.0) (void)frexp(mx, &e);
+    const int e = hdr->e;
     c.delta = mx > 0.0 ? ldexp(1.0, e + 1 - 8 * hdr->S) : 0.0;
+    c.specH = hdr->specH;
+    if (c.specH > 0.0) c.delta *= 1.0 + 0x1p-8;   // the leading S digits of an (S+1)-digit rounding: |R_jk| <= (128 + 1/2) u
     c.absR = fabs(hdr->R);
+    c.flag_rel = VARA_FLAG_FACTOR * hdr->budget;
     c.sumdiag = hdr->sumdiag;
     c.stochastic = hdr->pad;
     return c;
@@ -1256,6 +1413,7 @@ __device__ __forceinline__ double cert_bound(const CertCtx& cc, const int32_t* l
     // round to nearest: guaranteed; stochastic rounding: exceeded with probability below 1e-30 per marker (and never above
     // the guaranteed l1^2 * delta of an interval of twice the width)
     double b = cc.stochastic ? fmin(VARA_HOEFFDING_K * (double)l1q2[2 * i + 1] * cc.delta, l * l * cc.delta) : 0.5 * l * l * cc.delta;
+    if (cc.specH > 0.0) b = fmin(b, cc.specH * (double)l1q2[2 * i + 1]);   // the spectral bound of k_spectral_decide
     double mag = fabs(vdiag) + fabs(vara - vdiag);
     if (c != 0) mag += 2.0 * (fabs(mrho) + cc.absR);
     return b + 0x1p-48 * mag + 0x1p-50 * cc.sumdiag;
@@ -1292,7 +1450,7 @@ __global__ __launch_bounds__(256) void k_cert_select(const double* __restrict__ 
         const double x = a[i], v = vara[i];
         if (!(isfinite(x) && isfinite(v))) continue;  // NaN / Inf operands: the fp64 kernel gives the same
         const double b = cert_bound(cc, l1, i, cshift[i], vdiag[i], mrho[i], v);
-        const bool flagged = b > 1e-7 * fabs(v);
+        const bool flagged = b > cc.flag_rel * fabs(v);
         const double den = v - b;
         const bool cand = !(den > 0.0) || (x * x) / den >= thr;
         if (flagged) atomicAdd(&ch->flagged, 1);
@@ -1403,7 +1561,7 @@ extern "C" int eagle_dev_scan_certify(eagle_ctx* ctx, const int8_t* Mt8, long L,
 // to 64 vara values differed at 1e-9 between a streamed and a resident scan of the same file).
 //   per block, right after the vara kernel:  bound[i] = b_i                      (eagle_dev_cert_bounds; 8 bytes per marker stay)
 //   after the last block:                    LB = max_i a_i^2 / (vara_i + b_i)   (eagle_dev_cert_lb_b; devices exchange theirs)
-//                                            idx[] = markers with b_i > 1e-7 |vara_i| or a_i^2 / (vara_i - b_i) >= LB (1 - 1e-9)
+//                                            idx[] = markers with b_i > 1.8 budget |vara_i| or a_i^2 / (vara_i - b_i) >= LB (1 - 1e-9)
 //                                                                                 (eagle_dev_cert_select_b)
 //   the caller gathers those rows (from the resident image, or by re-reading just them from the file) and runs
 //   eagle_dev_vara_f64_split on them: bitwise the values, and so the selected marker, of the one-block scan.
@@ -1431,13 +1589,13 @@ __global__ __launch_bounds__(256) void k_cert_lb_b(const double* __restrict__ a,
     if ((threadIdx.x & 63) == 0 && best > 0.0 && isfinite(best)) atomicMax(&ch->lb_bits, (unsigned long long)__double_as_longlong(best));
 }
 __global__ __launch_bounds__(256) void k_cert_select_b(const double* __restrict__ a, const double* __restrict__ vara, const double* __restrict__ bound,
-                                                       long L, CertHdr* __restrict__ ch, long* __restrict__ idx, double lb) {
+                                                       long L, CertHdr* __restrict__ ch, long* __restrict__ idx, double lb, double flag_rel) {
     const double thr = lb * (1.0 - 1e-9);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L; i += (long)gridDim.x * 256) {
         const double x = a[i], v = vara[i];
         if (!(isfinite(x) && isfinite(v))) continue;
         const double b = bound[i];
-        const bool flagged = b > 1e-7 * fabs(v);
+        const bool flagged = b > flag_rel * fabs(v);
         const double den = v - b;
         const bool cand = !(den > 0.0) || (x * x) / den >= thr;
         if (flagged) atomicAdd(&ch->flagged, 1);
@@ -1486,7 +1644,7 @@ extern "C" int eagle_dev_cert_select_b(eagle_ctx* ctx, long L, const double* a, 
     unsigned blocks = (unsigned)((L + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_cert_select_b, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, vara, bound, L, (CertHdr*)cert_ws,
-                       (long*)((char*)cert_ws + cert_idx_off()), lb);
+                       (long*)((char*)cert_ws + cert_idx_off()), lb, VARA_FLAG_FACTOR * ctx->scan_budget);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "k_cert_select_b");
     return EAGLE_OK;
@@ -1569,7 +1727,7 @@ extern "C" int eagle_dev_vara_i8_prepare_part(eagle_ctx* ctx, const int8_t* Mt8,
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "vara_i8 memset");
     if (part != 2) {
         hipLaunchKernelGGL(k_absmax_offdiag, dim3(1024), dim3(256), 0, s, Wu, n_pad, (unsigned long long*)&hdr->maxabs_off);
-        hipLaunchKernelGGL(k_vara_prep, dim3(1), dim3(256), 0, s, Wu, n_pad, nslices, hdr, dW);
+        hipLaunchKernelGGL(k_vara_prep, dim3(1), dim3(256), 0, s, Wu, n_pad, nslices, hdr, dW, ctx->scan_budget);
         // correction terms of the re-centred markers: rho and R from Wu, m^T rho from the genotype pass
         double* colpart = (double*)((char*)ws + ws_cp_off(n_pad, L_pad, smax));
         hipLaunchKernelGGL(k_rho_rows, dim3((unsigned)n_pad), dim3(256), 0, s, Wu, n_pad, rho);
@@ -1585,6 +1743,23 @@ extern "C" int eagle_dev_vara_i8_prepare_part(eagle_ctx* ctx, const int8_t* Mt8,
     if (part != 2) {
         dim3 g2((unsigned)(n_pad / 32), (unsigned)(n_pad / 32));
         hipLaunchKernelGGL(k_slice_w, g2, dim3(256), 0, s, Wu, n_pad, hdr, Bs, vara_piped(ctx, n_pad) ? 1 : 0);
+        // one digit fewer if the spectral bound of the last digit allows it (automatic digit count, round to nearest): the last digit's
+        // symmetric image goes into the spare slot of the slice area (at most 6 of the 7 are in use), the row sums into the column
+        // partials of rho (free again after k_rho_final)
+        if (nslices == 0 && !ctx->spectral_off && ctx->tune != 29) {
+            int8_t* Ds = Bs + (size_t)(smax - 1) * n_pad * n_pad;
+            unsigned long long* rsum = (unsigned long long*)((char*)ws + ws_cp_off(n_pad, L_pad, smax));
+            const int* pairs = nullptr;
+            const int nt = (int)(n_pad / T8);
+            rc = syrk_pair_table(ctx, nt, &pairs, s);
+            if (rc) return rc;
+            const int npairs = nt * (nt + 1) / 2;
+            hipLaunchKernelGGL(k_last_digit_sym, g2, dim3(256), 0, s, Wu, n_pad, hdr, Ds, smax);
+            e = hipMemsetAsync(rsum, 0, sizeof(unsigned long long) * (size_t)n_pad, s);
+            if (e != hipSuccess) return eagle_fail_hip(ctx, e, "spectral row sums memset");
+            hipLaunchKernelGGL(k_gram_rowabs_i8, dim3((unsigned)((npairs + 7) / 8 * 8)), dim3(512), 0, s, Ds, n_pad, pairs, npairs, n_pad / BK8, rsum);
+            hipLaunchKernelGGL(k_spectral_decide, dim3(1), dim3(256), 0, s, rsum, n_pad, hdr, ctx->scan_budget, smax);
+        }
     }
     e = hipGetLastError();
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "vara_i8_prepare");
@@ -1797,7 +1972,7 @@ extern "C" int eagle_dev_transpose_pack_fp4(eagle_ctx* ctx, const int8_t* Mt8, l
 }
 
 // One block: dW, sumdiag, digit count (hdr->S), scale exponent f (hdr->pad) and the error bound n_pad^2 2^(-f-1).
-__global__ __launch_bounds__(256) void k_vara_prep6(const double* __restrict__ Wu, long n_pad, int forced, VaraHdr* __restrict__ hdr,
+__global__ __launch_bounds__(256) void k_vara_prep6(const double* __restrict__ Wu, long n_pad, int forced, VaraHdr* __restrict__ hdr, double budget,
                                                     double* __restrict__ dW) {
     double s = 0.0;
     for (long k = threadIdx.x; k < n_pad; k += 256) {
@@ -1819,7 +1994,7 @@ __global__ __launch_bounds__(256) void k_vara_prep6(const double* __restrict__ W
         const double nn = (double)n_pad * (double)n_pad;
         int S = forced;
         if (S <= 0) {
-            const double target = VARA_DIGIT_BUDGET * 0.5 * red[0];
+            const double target = budget * 0.5 * red[0];
             S = VARA6_SMAX_AUTO;
             for (int c = 4; c <= VARA6_SMAX_AUTO; c++)
                 if (ldexp(nn, e - 5 * c) <= target) { S = c; break; }
@@ -2053,7 +2228,7 @@ extern "C" int eagle_dev_vara_f6_prepare(eagle_ctx* ctx, const int8_t* Mt8, long
     hipError_t e = hipMemsetAsync(ws, 0, ws_dw_off(L_pad, smax), s);  // header and q
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "vara_f6 memset");
     hipLaunchKernelGGL(k_absmax_offdiag, dim3(1024), dim3(256), 0, s, Wu, n_pad, (unsigned long long*)&hdr->maxabs_off);
-    hipLaunchKernelGGL(k_vara_prep6, dim3(1), dim3(256), 0, s, Wu, n_pad, nslices, hdr, dW);
+    hipLaunchKernelGGL(k_vara_prep6, dim3(1), dim3(256), 0, s, Wu, n_pad, nslices, hdr, ctx->scan_budget, dW);
     rc = eagle_dev_gemv2_i8(ctx, Mt8, L_pad, n_pad, ld, v ? v : dW, dW, 1.0, v ? a_out : nullptr, vdiag, stream);
     if (rc) return rc;
     dim3 g2((unsigned)(n_pad / 32), (unsigned)(n_pad / 32));

@@ -115,6 +115,13 @@ def set_scan_rounding(stochastic, device=0):
     _check(ctx, _lib.load().eagle_set_scan_rounding(ctx, int(stochastic)))
 
 
+def set_scan_budget(relative_budget, device=0):
+    """Relative digit budget of the int8 scan (default 5e-7 = half of the path's 1e-6 tolerance; 1e-7 = rounds 1-2).  The certificate
+    sends every marker whose own bound exceeds 1.8 x budget to the fp64 kernel."""
+    ctx = context(device)
+    _check(ctx, _lib.load().eagle_set_scan_budget(ctx, float(relative_budget)))
+
+
 def drop_cache(device=0):
     _lib.load().eagle_drop_cache(context(device))
 
@@ -276,6 +283,15 @@ def last_scan_certificate(device=0):
     nre, nfl, fell = C.c_long(), C.c_long(), C.c_int()
     _check(ctx, L.eagle_last_scan_certificate(ctx, C.byref(nre), C.byref(nfl), C.byref(fell)))
     return nre.value, nfl.value, bool(fell.value)
+
+
+def last_scan_digits(device=0):
+    """(digit slices the last digit-slice scan used, slices cut from W, spectral bound or 0.0): eagle_last_scan_digits."""
+    L = _lib.load()
+    ctx = context(device)
+    used, cut, H = C.c_int(), C.c_int(), C.c_double()
+    _check(ctx, L.eagle_last_scan_digits(ctx, C.byref(used), C.byref(cut), C.byref(H)))
+    return used.value, cut.value, H.value
 
 
 class _ScanTiming(C.Structure):

@@ -380,8 +380,12 @@ class DeviceShard:
 
     def vara_i8_info(self):
         """(slices used, absolute error bound, max |off-diagonal W|) of the last int8-slice vara launch (synchronises)."""
-        h = self.ws[:32].cpu().numpy().tobytes()
+        h = self.ws[:72].cpu().numpy().tobytes()
+        self.last_e = int(np.frombuffer(h[64:68], dtype=np.int32)[0])   # scale exponent of the digits: unit of digit s = 2^(e + 2 - 8 (s + 1))
         self.last_sumdiag = float(np.frombuffer(h[24:32], dtype=np.float64)[0])  # sum_k |W_kk|
+        # round 3: the spectral bound of the last digit (0: not in use) and the digits that were cut (= used, or one more)
+        self.last_specH = float(np.frombuffer(h[40:48], dtype=np.float64)[0])
+        self.last_sliced = int(np.frombuffer(h[48:52], dtype=np.int32)[0])
         return (int(np.frombuffer(h[8:12], dtype=np.int32)[0]), float(np.frombuffer(h[16:24], dtype=np.float64)[0]),
                 float(np.frombuffer(h[0:8], dtype=np.float64)[0]))
 

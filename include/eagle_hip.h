@@ -72,13 +72,22 @@ int eagle_device_info(eagle_ctx* ctx, char* arch_out, int arch_len, int* cu_coun
 /* vara kernel: 1 (default) = exact int8 digit slices of W on v_mfma_i32_32x32x32_i8, 0 = fp64 MFMA
  * (v_mfma_f64_16x16x4_f64; also taken automatically when n is too large for the int32 tile sums).
  * eagle_set_scan_slices: S = 1..8 base-256 digits of the off-diagonal part of W, or 0 (default) = chosen per call:
- * the smallest S in 3..7 whose worst-case bound is below 1e-7 of 0.5 * sum_k |W_kk| -- a tenth of the 1e-6 relative
- * tolerance of this path, relative to the smallest diagonal term a marker can have (at least half of its genotypes are
+ * the smallest S in 3..7 whose worst-case bound is below the budget (eagle_set_scan_budget, default 5e-7) times 0.5 * sum_k |W_kk| -- half
+ * of the 1e-6 relative tolerance of this path, relative to the smallest diagonal term a marker can have (at least half of its genotypes are
  * non-zero in the g-1 coding); measured errors are ~1000x below the bound.  The diagonal term
  * sum_k m_ik^2 W_kk is evaluated in fp64; every vara_i then differs from the exact m_i^T W m_i by at most
- * (sum_j |m_ij|)^2 * 2^(e+1-8S), max_{j!=k} |W_jk + W_kj| < 2^e, plus fp64 rounding of an n-term and an S-term sum. */
+ * (sum_j |m_ij|)^2 * 2^(e+1-8S), max_{j!=k} |W_jk + W_kj| < 2^e (or < 1.96 * 2^e: the exponent is lowered by one when the largest
+ * entry's mantissa leaves the balanced digits room), plus fp64 rounding of an n-term and an S-term sum. */
 int eagle_set_scan_mode(eagle_ctx* ctx, int mode);
 int eagle_set_scan_slices(eagle_ctx* ctx, int nslices);
+/* Round 3.  The relative digit budget of the int8 scan, 1e-12 .. 5e-7 (default 5e-7 = half of the path's 1e-6 tolerance; rounds 1-2
+ * used 1e-7, which this call restores).  It enters twice: the automatic digit count is the smallest S whose bound keeps a typical
+ * marker inside the budget, and the certificate sends every marker whose OWN bound exceeds 1.8 x budget (0.9e-6 by default) to the
+ * fp64 kernel.  With the automatic count the library also tries ONE DIGIT FEWER than the worst-case bound asks for, under a spectral
+ * bound of the truncation error: |error_i| <= (u/2)(||Ds||_2 + (n_pad-1)/2) sum_j m'_ij^2, Ds = the symmetrised last digit of W,
+ * ||Ds||_2^2 <= max row sum of |Ds Ds| from an exact int8 MFMA Gram product (csrc/eagle_i8mfma.hip, k_spectral_decide) -- rigorous,
+ * deterministic, a function of W alone.  At n = 10,000 this takes the scan of an AM() run from 4 digit slices to 3. */
+int eagle_set_scan_budget(eagle_ctx* ctx, double relative_budget);
 /* How the digits of W are rounded (digit-slice mode).  0 (default): to nearest -- every vara_i is GUARANTEED within
  * l1_i^2 / 2 * 2^(e+1-8S) of the exact quadratic form (l1_i = sum_j |m'_ij| of the re-centred marker).  1: stochastic
  * rounding -- each entry rounded down or up at random with the probabilities that make it unbiased, from a counter-based
@@ -369,6 +378,9 @@ int eagle_dev_scan_certify_apply(eagle_ctx* ctx, const int8_t* Mt8, long L, long
  * marker blocks of a streamed file): markers re-evaluated in fp64, of which flagged by their own error bound, and
  * whether a block fell back to the fp64 kernel entirely. */
 int eagle_last_scan_certificate(eagle_ctx* ctx, long* n_reevaluated, long* n_flagged, int* fell_back);
+/* Digit slices of the LAST eagle_calculate_a_and_vara call in digit-slice mode: used by the scan, cut from W (the same, or one more
+ * when the spectral bound took the last one off), and that bound (|error_i| <= spectral_bound * sum_j m'_ij^2; 0 = not in use). */
+int eagle_last_scan_digits(eagle_ctx* ctx, int* digits_used, int* digits_cut, double* spectral_bound);
 /* Out-of-core bookkeeping of the LAST call of this ctx that streamed its file through HBM in marker chunks (a file larger than
  * free HBM or than EAGLE_HIP_MAX_RESIDENT_GB; the lead device's share in a multi-device context): what SURVEY 8(d) asks to be
  * reported for the streamed configurations.  The loader of chunk k+1 (pread -> pinned -> H2D -> decode / 2-bit unpack) runs

@@ -121,7 +121,7 @@ def test_scan_with_W_shortcut_matches_the_reference_shaped_scan(golden, tmp_path
     assert rcpp_api.last_scan_argmax()[0] == idx_ref
     np.testing.assert_allclose(res["a"], ref["a"], rtol=1e-8, atol=1e-10 * np.abs(ref["a"]).max())
     vs = np.abs(ref["vara"]).max()
-    np.testing.assert_allclose(res["vara"], ref["vara"], rtol=1e-7, atol=1e-10 * vs)
+    np.testing.assert_allclose(res["vara"], ref["vara"], rtol=9e-7, atol=1e-10 * vs)
     # masking and a non-symmetric W work as in the reference-shaped call
     W = np.random.default_rng(0).standard_normal((n, n)) * 0.01 + np.eye(n)
     v = np.random.default_rng(1).standard_normal(n)
@@ -132,7 +132,7 @@ def test_scan_with_W_shortcut_matches_the_reference_shaped_scan(golden, tmp_path
     v_ref = np.einsum("ij,jk,ik->i", Mt, W, Mt)
     a_ref[[3, 77]] = 0.0; v_ref[[3, 77]] = 0.0
     np.testing.assert_allclose(res2["a"].ravel(), a_ref, rtol=1e-9, atol=1e-11 * np.abs(a_ref).max())
-    np.testing.assert_allclose(res2["vara"].ravel(), v_ref, rtol=1e-7, atol=1e-9 * np.abs(v_ref).max())
+    np.testing.assert_allclose(res2["vara"].ravel(), v_ref, rtol=9e-7, atol=1e-9 * np.abs(v_ref).max())
     rcpp_api.drop_cache()
 
 
@@ -158,7 +158,7 @@ def test_spectral_scan_matches_the_reference_shaped_scan(golden, tmp_path):
         idx_ref = rcpp_api.last_scan_argmax()[0]
         res = rcpp_api.spectral_scan(lam, U.T @ X, U.T @ y, varE, varG, L)
         np.testing.assert_allclose(res["a"], ref["a"], rtol=1e-8, atol=1e-10 * np.abs(ref["a"]).max())
-        np.testing.assert_allclose(res["vara"], ref["vara"], rtol=1e-7, atol=1e-10 * np.abs(ref["vara"]).max())
+        np.testing.assert_allclose(res["vara"], ref["vara"], rtol=9e-7, atol=1e-10 * np.abs(ref["vara"]).max())
         with np.errstate(all="ignore"):
             tsq = res["a"].ravel() ** 2 / res["vara"].ravel()
         assert int(np.nanargmax(tsq)) + 1 == idx_ref

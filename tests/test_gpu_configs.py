@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-RTOL_DIGITS = 1e-7  # digit-slice kernel's certified budget (a tenth of north_star's 1e-6)
+RTOL_DIGITS = 9e-7  # what the digit-slice certificate enforces per marker (1.8 x the default budget 5e-7; north_star: 1e-6)
 
 
 @pytest.fixture(scope="module")

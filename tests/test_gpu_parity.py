@@ -14,8 +14,9 @@ from eagleeverything_amd import synth
 pytestmark = pytest.mark.gpu
 NA = np.nan
 RTOL = 1e-9        # a, and vara from the fp64 MFMA kernel (mode 0)
-RTOL_DIGITS = 1e-7  # vara from the digit-slice kernels: the library's worst-case digit budget, a tenth of the 1e-6 relative
-                    # tolerance BASELINE.json's north_star states for the score statistics (measured errors are far smaller)
+RTOL_DIGITS = 9e-7  # vara from the digit-slice kernels: what the certificate ENFORCES per marker (1.8 x the default budget of 5e-7; a
+                    # marker whose bound is larger is re-evaluated in fp64), inside the 1e-6 relative tolerance BASELINE.json's
+                    # north_star states for the score statistics.  Measured errors on unstructured operands are orders smaller.
 
 
 @pytest.fixture(scope="module")
@@ -206,7 +207,7 @@ def test_find_qtl_mirror_selects_same_marker(files, api, oracle):
     idx, st = r_api.find_qtl(geno, 8.0, sel, MMt, invMMt, float(g["varE"]), float(g["varG"]), g["X"], 2, True, g["y"],
                              return_stats=True)
     assert idx == int(g["argmax"])
-    np.testing.assert_allclose(st["tsqmax"], float(g["tsqmax"]), rtol=1e-7)
+    np.testing.assert_allclose(st["tsqmax"], float(g["tsqmax"]), rtol=RTOL_DIGITS)
 
 
 # ---- larger seeded case, ragged sizes, cache reuse, cross-check by properties ---------------------------
@@ -700,7 +701,7 @@ def test_overflow_fallback_through_the_reference_shaped_call_resident_streamed_a
 def test_stochastic_rounding_option(api, oracle):
     """eagle_set_scan_rounding(1) / EAGLE_SLICES_STOCHASTIC (opt-in): the digits of W rounded at random (unbiased, keyed by
     position).  One digit fewer than round-to-nearest at n = 5000; every error inside the Hoeffding radius
-    8.355 q2 2^(e+1-8S) that the certification uses and inside the 1e-7 budget; reproducible; same selected marker."""
+    8.355 q2 2^(e+1-8S) that the certification uses and inside the digit budget; reproducible; same selected marker."""
     import torch
     from eagleeverything_amd.sharded import DeviceShard
     n, L = 5000, 32768
@@ -717,8 +718,10 @@ def test_stochastic_rounding_option(api, oracle):
     Mt_s = sh.Mt8[rows][:, :n].cpu().numpy()
     a_ref, v_ref = oracle.scan_from_i8(Mt_s, S.cpu().numpy(), V.cpu().numpy(), ahat.cpu().numpy())
     sh.mode = 1
+    sh.L.eagle_dev_set_tune(sh.ctx, 29)        # round to nearest WITHOUT the spectral digit saving: the worst-case digit count
     sh.scan()
     torch.cuda.synchronize()
+    sh.L.eagle_dev_set_tune(sh.ctx, 0)
     S_near, _, maxoff = sh.vara_i8_info()
     best_near = sh.best()[:2]
     sh.stochastic = True
@@ -728,14 +731,15 @@ def test_stochastic_rounding_option(api, oracle):
     S_rand = sh.vara_i8_info()[0]
     assert S_rand == S_near - 1, (S_near, S_rand)
     raw = sh.vara[rows].cpu().numpy()
-    e = int(np.floor(np.log2(maxoff))) + 1     # max |off-diagonal| < 2^e
+    e = sh.last_e                              # the digits' scale exponent (max |off-diagonal| < 2^e, or < 1.96 * 2^e)
+    assert maxoff < 1.96 * 2.0 ** e and maxoff >= 0.49 * 2.0 ** e
     cs = sh.cshift[rows].cpu().numpy().astype(np.int64)
     q2 = ((Mt_s.astype(np.int64) - cs[:, None]) ** 2).sum(axis=1)
     assert np.array_equal(sh.l1[rows, 1].cpu().numpy(), q2)
     radius = 8.355 * q2 * 2.0 ** (e + 1 - 8 * S_rand)
     err = np.abs(raw - v_ref)
     assert np.all(err <= radius + 1e-12 * np.abs(v_ref))
-    assert np.max(radius / np.abs(v_ref)) < 1e-7          # what the certification checks per marker
+    assert np.max(radius / np.abs(v_ref)) < 9e-7          # what the certification checks per marker (1.8 x the budget of 5e-7)
     assert np.max(err / np.abs(v_ref)) < 1e-8             # the Hoeffding radius is generous: typical errors are ~ a tenth of it
     sh.certified = True
     sh.scan()

@@ -1,0 +1,185 @@
+"""The spectral bound of the last digit (csrc/eagle_i8mfma.hip: k_last_digit_sym, k_gram_rowabs_i8, k_spectral_decide; round 3).
+
+A digit-slice scan may run on ONE digit fewer than the worst-case bound asks for when
+    |digit error of marker i| <= specH * sum_j m'_ij^2,   specH = (u/2) (||Ds||_2 bound + (n_pad-1)/2)
+keeps a typical marker inside the budget.  The tests check what makes that legitimate: the bound is an upper bound of the true
+spectral norm of the residual (recomputed on the host from the folded W), every raw digit value sits inside its per-marker bound
+against the fp64 kernel, the certified result and the selected marker are those of the scan without the saving, and a context whose
+certificate overflowed under the saving stops taking the digit off."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _operands(torch, dev, n, off_scale, diag_scale, seed):
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    E = torch.randn((n, n), generator=gen, device=dev, dtype=torch.float64) * off_scale
+    V = torch.diag(diag_scale * (0.8 + 0.4 * torch.rand(n, generator=gen, device=dev, dtype=torch.float64))) + 0.5 * (E + E.T)
+    S = 0.9 * torch.eye(n, dtype=torch.float64, device=dev)
+    ahat = torch.randn(n, generator=gen, device=dev, dtype=torch.float64)
+    return S, V, ahat
+
+
+def _residual_norm(Wu, e, S_cut):
+    """||H||_2 of H = sym(R)/2, R = Wu - (leading S_cut - 1 digits of round(Wu 2^(8 S_cut - e - 2))), off-diagonal part only."""
+    off = np.triu(Wu, 1)
+    Q = np.rint(np.ldexp(off, 8 * S_cut - (e + 2)))
+    d = np.mod(Q + 128, 256) - 128
+    u = 2.0 ** (e + 2 - 8 * S_cut)
+    R = off - (Q - d) * u
+    H = 0.5 * (R + R.T)
+    ev = np.linalg.eigvalsh(H)
+    return max(abs(ev[0]), abs(ev[-1])), d
+
+
+def test_one_digit_fewer_under_a_rigorous_spectral_bound():
+    import torch
+    from eagleeverything_amd.sharded import DeviceShard
+    n, L = 2048, 8192
+    sh = DeviceShard(n, L)
+    sh.fill_synthetic(seed=11)
+    # off-diagonal ~1e-3, diagonal ~2: the worst-case rule needs 4 digits with room to spare, the spectral bound certifies 3
+    S, V, ahat = _operands(torch, sh.dev, n, 1e-3, 2.0, 5)
+    sh.set_operands(S, V, ahat)
+    sh.mode = 0
+    sh.scan()
+    torch.cuda.synchronize()
+    v64 = sh.vara[:L].cpu().numpy().copy()
+    best64 = sh.best()[:2]
+    sh.mode = 1
+    sh.L.eagle_dev_set_tune(sh.ctx, 29)            # the saving switched off: the worst-case digit count
+    sh.scan()
+    torch.cuda.synchronize()
+    sh.L.eagle_dev_set_tune(sh.ctx, 0)
+    S_wc = sh.vara_i8_info()[0]
+    assert sh.last_specH == 0.0 and sh.last_sliced == S_wc
+    v_wc = sh.vara[:L].cpu().numpy().copy()
+    best_wc = sh.best()[:2]
+    sh.certified = False                            # raw digit values first
+    sh.scan()
+    torch.cuda.synchronize()
+    S_used, bound_abs, maxoff = sh.vara_i8_info()
+    assert (S_used, sh.last_sliced) == (S_wc - 1, S_wc) and sh.last_specH > 0.0, (S_used, sh.last_sliced, sh.last_specH)
+    raw = sh.vara[:L].cpu().numpy().copy()
+    # (1) the bound is an upper bound of the true norm, and not absurdly loose
+    true_norm, d = _residual_norm(sh.Wu.cpu().numpy(), sh.last_e, S_wc)
+    assert true_norm <= sh.last_specH <= 12.0 * true_norm, (true_norm, sh.last_specH)
+    # (2) every raw value inside its own bound against the fp64 kernel
+    q2 = sh.l1[:L, 1].cpu().numpy().astype(np.float64)
+    l1 = sh.l1[:L, 0].cpu().numpy().astype(np.float64)
+    b = np.minimum(sh.last_specH * q2, 0.5 * l1 * l1 * 2.0 ** (sh.last_e + 1 - 8 * S_used) * (1 + 2.0 ** -8))
+    err = np.abs(raw - v64)
+    assert np.all(err <= b + 1e-12 * np.abs(v64)), float((err / np.maximum(b, 1e-300)).max())
+    assert np.abs(raw - v64).max() <= bound_abs
+    assert (sh.last_specH * q2 < 0.5 * l1 * l1 * 2.0 ** (sh.last_e + 1 - 8 * S_used)).mean() > 0.9    # the spectral term is the one that binds
+    # (3) certified: inside the enforced budget, same marker and same fp64 value for it as the scan without the saving
+    sh.certified = True
+    sh.scan()
+    torch.cuda.synchronize()
+    v3 = sh.vara[:L].cpu().numpy()
+    np.testing.assert_allclose(v3, v64, rtol=9e-7)
+    np.testing.assert_allclose(v_wc, v64, rtol=9e-7)
+    assert sh.best()[:2] == best_wc == best64
+    cert = sh.certificate()
+    assert cert["overflow"] == 0 and cert["flagged"] == 0 and 1 <= cert["reevaluated"] <= 16
+    # (4) the Gram row sums on the device are those of the symmetrised last digit (exact integers)
+    Ds = (d + d.T).astype(np.int64)
+    g = np.abs(Ds @ Ds).sum(axis=1).max()
+    u = 2.0 ** (sh.last_e + 2 - 8 * S_wc)
+    H_host = 0.5 * u * (np.sqrt(float(g)) + 0.5 * (sh.np_ - 1))
+    assert H_host <= sh.last_specH <= H_host * (1 + 1e-12)
+
+
+def _host_decision(Wu, n_pad, budget=5e-7):
+    """The library's digit rule restated on the host: (worst-case digit count, whether the spectral bound takes one off)."""
+    off = np.triu(Wu, 1)
+    mx = np.abs(off).max()
+    f, e = np.frexp(mx)
+    e = int(e) - (1 if f <= 0.98 else 0)
+    target = budget * 0.5 * np.abs(np.diag(Wu)).sum()
+    S_wc = next((c for c in range(3, 8) if float(n_pad) ** 2 * 2.0 ** (e + 1 - 8 * c) <= target), 7)
+    Q = np.rint(np.ldexp(off, 8 * S_wc - (e + 2)))
+    d = (np.mod(Q + 128, 256) - 128).astype(np.int64)
+    Ds = d + d.T
+    g = np.abs(Ds @ Ds).sum(axis=1).max()
+    H = 0.5 * 2.0 ** (e + 2 - 8 * S_wc) * (np.sqrt(float(g)) + 0.5 * (n_pad - 1))
+    return S_wc, bool(H * n_pad <= target), H
+
+
+def test_saving_is_not_taken_when_it_does_not_pay_or_is_not_allowed():
+    import torch
+    from eagleeverything_amd.sharded import DeviceShard
+    n, L = 1024, 2048
+    sh = DeviceShard(n, L)
+    sh.fill_synthetic(seed=12)
+    sh.mode = 1
+    seen = []
+    for diag in (0.05, 1.0):        # small diagonal: the worst-case count has no room for a whole digit at this n; larger: it has
+        S, V, ahat = _operands(torch, sh.dev, n, 1e-3, diag, 6)
+        sh.set_operands(S, V, ahat)
+        sh.scan()
+        torch.cuda.synchronize()
+        S_used = sh.vara_i8_info()[0]
+        S_wc, take, H = _host_decision(sh.Wu.cpu().numpy(), sh.np_)
+        assert sh.last_sliced == S_wc and S_used == S_wc - (1 if take else 0) and (sh.last_specH > 0.0) == take, (diag, S_used, S_wc, take)
+        if take:
+            assert H <= sh.last_specH <= H * (1 + 1e-12)
+        seen.append(take)
+    assert seen == [False, True]
+    # a forced digit count and stochastic rounding never take it (operands of the second case)
+    sh.nslices, sh.ws = 4, None
+    sh.scan()
+    torch.cuda.synchronize()
+    assert sh.vara_i8_info()[0] == 4 and sh.last_specH == 0.0
+    sh.nslices, sh.ws, sh.stochastic = 0, None, True
+    sh.scan()
+    torch.cuda.synchronize()
+    sh.vara_i8_info()
+    assert sh.last_specH == 0.0
+    sh.stochastic = False
+
+
+def test_context_stops_saving_after_a_fallback(tmp_path):
+    """Markers whose quadratic form is far below q2 * mean(W_kk) (all their non-zero genotypes on individuals with a tiny W_kk) are
+    outside what the spectral bound certifies to the budget: more than 2,048 of them overflow the re-evaluation buffer, the block is
+    redone in fp64 (results still right), and the context keeps the worst-case digit count from then on."""
+    from eagleeverything_amd import rcpp_api as api, synth
+    from oracle import oracle_c
+    oracle_c.build()
+    n, L = 2048, 6144
+    rng = np.random.default_rng(3)
+    Mt8 = (rng.binomial(2, rng.uniform(0.1, 0.5, size=L)[:, None], size=(L, n)) - 1).astype(np.int8)
+    quiet = np.arange(n) < n // 2                      # individuals with a tiny diagonal entry of W and no off-diagonal ones
+    odd = np.arange(L) % 2 == 1
+    Mt8[np.ix_(odd, ~quiet)] = 0                       # 3,072 markers are non-zero only on the quiet individuals (0 = their majority genotype)
+    E = rng.standard_normal((n, n)) * 2e-4
+    E[quiet, :] = 0.0
+    E[:, quiet] = 0.0
+    V = np.diag(np.where(quiet, 1e-4, 1.0) * rng.uniform(0.8, 1.2, size=n)) + 0.5 * (E + E.T)
+    S = 0.9 * np.eye(n)
+    ahat = rng.standard_normal(n)
+    geno = synth.write_geno_pair(str(tmp_path), Mt8)
+    ref = oracle_c.calculate_a_and_vara_rcpp(geno["asciifileMt"], np.nan, S, V, 8.0, (L, n), ahat)
+    try:
+        api.set_scan_mode(1)
+        api.set_scan_budget(5e-7)                      # re-arms the saving
+        r1 = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], np.nan, S, V, 8.0, (L, n), ahat)
+        used1, cut1, H1 = api.last_scan_digits()
+        nre1, nfl1, fell1 = api.last_scan_certificate()
+        assert (used1, cut1) == (cut1 - 1, cut1) and H1 > 0.0 and fell1 and nfl1 > 2048, (used1, cut1, H1, nre1, nfl1, fell1)
+        np.testing.assert_allclose(r1["vara"].ravel(), ref["vara"].ravel(), rtol=9e-7, atol=1e-12 * np.abs(ref["vara"]).max())
+        r2 = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], np.nan, S, V, 8.0, (L, n), ahat)
+        used2, cut2, H2 = api.last_scan_digits()
+        assert used2 == cut2 == cut1 and H2 == 0.0
+        np.testing.assert_allclose(r2["vara"].ravel(), ref["vara"].ravel(), rtol=9e-7, atol=1e-12 * np.abs(ref["vara"]).max())
+        assert api.last_scan_argmax()[0] == oracle_c.tsq_argmax(ref["a"], ref["vara"])[1]
+        api.set_scan_budget(5e-7)
+        api.calculate_a_and_vara_rcpp(geno["asciifileMt"], np.nan, S, V, 8.0, (L, n), ahat)
+        assert api.last_scan_digits()[2] > 0.0         # re-armed
+    finally:
+        api.set_scan_budget(5e-7)
+        api.drop_cache()

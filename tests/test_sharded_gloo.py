@@ -163,9 +163,9 @@ def _gpu_worker(rank, world, port, out_dir):
             vara = np.einsum("ij,jk,ik->i", Mt8.astype(np.float64), W, Mt8.astype(np.float64))
             tsq = a * a / vara
             assert sel == int(np.nanargmax(tsq)) + 1, (nn, sel, int(np.nanargmax(tsq)) + 1)
-            np.testing.assert_allclose(best, np.nanmax(tsq), rtol=1e-7)
+            np.testing.assert_allclose(best, np.nanmax(tsq), rtol=9e-7)
             mine = slice(rank * Lloc, (rank + 1) * Lloc)
-            np.testing.assert_allclose(sh.vara[:Lloc].cpu().numpy(), vara[mine], rtol=1e-7, atol=1e-10 * np.abs(vara).max())
+            np.testing.assert_allclose(sh.vara[:Lloc].cpu().numpy(), vara[mine], rtol=9e-7, atol=1e-10 * np.abs(vara).max())
             np.testing.assert_allclose(sh.a[:Lloc].cpu().numpy(), a[mine], rtol=1e-9, atol=1e-12 * np.abs(a).max())
         open(os.path.join(out_dir, "gpu_ok%d" % rank), "w").write("ok")
     finally:
