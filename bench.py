@@ -255,7 +255,7 @@ def vara_roofline(sh, kern_s, S_used):
     if sh.mode == 0:
         nct = np_ // 128  # executed = algorithmic for the triangular fp64 kernel: column tile ct needs k < (ct+1)*128
         flops = sum(2.0 * Lp * 128 * min((ct + 1) * 128, np_) for ct in range(nct))
-        roof = {"bound": "mfma", "kernel": "k_vara_f64 (v_mfma_f64_16x16x4_f64)", "dtype": "f64",
+        roof = {"bound": "mfma", "kernel": "k_vara_f64d (v_mfma_f64_16x16x4_f64, 128 x 128 tiles, A converted once per K block, Wu by LDS-DMA)", "dtype": "f64",
                 "achieved": flops / kern_s / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
     else:
         nct8 = np_ // 256
@@ -571,6 +571,11 @@ def main():
     # ---- roofline of the dominant kernel (vara) ---------------------------------------------------
     np_, Lp, Lloc = sh.np_, sh.Lp, sh.Lloc
     S_used, vara_bound = (sh.vara_i8_info()[:2] if sh.mode else (None, None))
+    digits = None
+    if sh.mode:   # round 3: the digits cut from W, the digits the scan ran on (one fewer under the spectral bound), the budget
+        digits = {"used": S_used, "cut": sh.last_sliced, "spectral_bound_H": sh.last_specH, "budget": 5e-7, "enforced_per_marker": 9e-7,
+                  "note": "|digit error_i| <= min(H q2_i, l1_i^2/2 * 2^(e+1-8 used)); markers above 1.8 x budget are re-evaluated in fp64 "
+                          "(certificate.flagged); rounds 1-2 ran budget 1e-7 without the spectral bound: roofline_secondary.scan_budget_1e-7"}
     roof = vara_roofline(sh, kern_s, S_used)
     # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command (tools/profile_gpu.sh):
     # they cannot be collected in-process.  The committed figure is attached only when it was measured on these very
@@ -687,7 +692,7 @@ def main():
         parity = {"a_max_rel": rel(a_g, a_ref), "vara_max_rel": float(np.max(np.abs(v_g - vara_ref) / np.abs(vara_ref))),
                   "sample_argmax_equal": bool(np.argmax(a_g ** 2 / v_g) == np.argmax(a_ref ** 2 / vara_ref))}
         # SURVEY 8(d) parity gate run with every measurement: north_star's tolerance is 1e-6 relative on the score statistics
-        parity["gate"] = {"a_rel_tol": 1e-9, "vara_rel_tol": 1e-7 if sh.mode else 1e-9, "north_star_tol": 1e-6}
+        parity["gate"] = {"a_rel_tol": 1e-9, "vara_rel_tol": 9e-7 if sh.mode else 1e-9, "north_star_tol": 1e-6}
         parity["gate"]["passed"] = bool(parity["a_max_rel"] <= parity["gate"]["a_rel_tol"] and
                                         parity["vara_max_rel"] <= parity["gate"]["vara_rel_tol"] and parity["sample_argmax_equal"])
         # MM^T baseline on a marker subsample, scaled linearly in L
@@ -709,6 +714,15 @@ def main():
                                        "selected_marker_equal_to_digit_mode": bool(s64[0] == sel_i8[0]),
                                        "roofline": vara_roofline(sh, p64["kern"], None)}
         sh.mode = 1
+        # the digit rule of rounds 1-2 (budget 1e-7: no digit is taken off on these operands), for comparison with the headline
+        sh._check(sh.L.eagle_set_scan_budget(sh.ctx, 1e-7))
+        sb, elb, pb = run.timed(3, 1)
+        Sb = sh.vara_i8_info()[0]
+        secondary["scan_budget_1e-7"] = {"value": Ltot * 3 / elb, "unit": "markers/s", "ms_per_step": elb / 3 * 1e3, "slices": Sb,
+                                         "slices_cut": sh.last_sliced, "spectral_bound_H": sh.last_specH,
+                                         "selected_marker_equal": bool(sb[0] == sel_i8[0]), "certificate": sh.certificate(),
+                                         "roofline": vara_roofline(sh, pb["kern"], Sb)}
+        sh._check(sh.L.eagle_set_scan_budget(sh.ctx, 5e-7))
         sh.nslices = 7
         sh.ws = None
         s7, el7, p7 = run.timed(1, 1)
@@ -856,7 +870,7 @@ def main():
                        "n": n, "markers_total": Ltot, "markers_rank0": Lloc,
                        "parallelism": "marker-shard x%d" % world + (", W rows 1/%d per rank + all-gather" % world if world > 1 and w_choice and w_choice["shared_s"] <= w_choice["replicated_s"] else "")
                                       + (" (REHEARSAL: gloo, ranks share one card)" if backend == "gloo" and world > 1 else ""),
-                       "scan_mode": args.mode, "slices": S_used, "vara_abs_error_bound_worst_case": vara_bound,
+                       "scan_mode": args.mode, "slices": S_used, "digits": digits, "vara_abs_error_bound_worst_case": vara_bound,
                        "certificate": cert,
                        "operands": "simple" if args.simple_operands else "model algebra on MM^T" + (" (reloaded)" if args.load_operands else "")},
             "rccl_ranks": dist.get_world_size() if world > 1 and backend == "nccl" else 0,   # ranks in the RCCL process group (0: none was made)

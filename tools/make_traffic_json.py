@@ -33,14 +33,6 @@ read(d, vals)
 vals2 = {}
 if d2:
     read(d2, vals2)
-for line in []:
-    m = re.match(r"(\S+)\s+(\S+)\s+n=(\d+)\s+mean=(\S+)", line)
-    if m:
-        vals[(m.group(1), m.group(2))] = float(m.group(4))
-    m = re.match(r"(\S+)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.e+-]+)(\s+[\d.]+\s+[\d.]+)?\s*$", line)
-    if m and (m.group(1), "avg_ms") not in vals:
-        vals[(m.group(1), "avg_ms")] = float(m.group(4))
-
 
 def entry(k, algorithmic, secondary=False):
     global vals
@@ -86,7 +78,8 @@ out = {"kernel_sha16": kernel_sha16(),
        "k_syrk_f4": entry("k_syrk_f4w", float(lpad) * npad / 2.0),
        "k_gemm_f64_dma": entry("k_gemm_f64_dma", 3.0 * 8 * npad * npad),
        "k_transpose_pack_fp4": entry("k_transpose_pack_fp4", 1.5 * float(lpad) * npad),
-       "k_vara_f64": entry("k_vara_f64", float(lpad) * npad + 8.0 * npad * npad / 2.0, True),
+       "k_vara_f64d": entry("k_vara_f64d", float(lpad) * npad + 8.0 * npad * npad / 2.0, True),
+       "k_gram_rowabs_i8": entry("k_gram_rowabs_i8", float(npad) * npad),
        "k_spectral_scan": entry("k_spectral_scan", 8.0 * float(lpad) * npad, True),
        "k_zbuild_i8": entry("k_zbuild_i8", float(lpad) * npad + 6.0 * npad * npad + 8.0 * float(lpad) * npad, True)}
 json.dump(out, open(os.path.join(ROOT, "profiles", "r03_traffic.json"), "w"), indent=1)
