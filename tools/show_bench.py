@@ -15,4 +15,4 @@ for k, v in s.items():
                          ("value", "ms_per_step", "slices", "slices_cut", "markers_per_s", "ms_per_call", "frac", "ms") if kk in v},
           ("roofline.frac %.3f ms %.2f" % (r["frac"], r.get("kernel_ms", 0.0))) if r else "")
 print("mmt_build_s", d.get("mmt_build_s"), "parity", d.get("parity"))
-print("cpu", {k: d["cpu_baseline"].get(k) for k in ("value", "cores", "kind")})
+print("cpu", {k: (d.get("cpu_baseline") or {}).get(k) for k in ("value", "cores", "kind")})
