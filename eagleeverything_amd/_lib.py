@@ -124,6 +124,7 @@ SIGNATURES = {
                                        C.c_void_p]),
     # internal helpers exported for tests / the sharded driver
     "eagle_dev_set_tune": (None, [C.c_void_p, C.c_int]),
+    "eagle_dev_set_spectral": (None, [C.c_void_p, C.c_int]),
     "eagle_dev_gemm_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]),
     "eagle_dev_colgemv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p]),
 }

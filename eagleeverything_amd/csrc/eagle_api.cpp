@@ -317,6 +317,10 @@ extern "C" int eagle_set_scan_budget(eagle_ctx* ctx, double relative_budget) {
     for (eagle_ctx* p : ctx->peers) { p->scan_budget = relative_budget; p->spectral_off = false; }
     return EAGLE_OK;
 }
+// on = 0: this context stops taking a digit off under the spectral bound (what eagle_calculate_a_and_vara does by itself after a
+// certificate that overflowed under it); on = 1 re-arms.  For callers of the device-resident entry points, which see the certificate
+// themselves (eagleeverything_amd/sharded.py).  Not part of the public ABI.
+extern "C" void eagle_dev_set_spectral(eagle_ctx* ctx, int on) { if (ctx) ctx->spectral_off = !on; }
 extern "C" int eagle_set_scan_slices(eagle_ctx* ctx, int nslices) {
     if (!ctx || nslices < 0 || nslices > 8) return EAGLE_ERR_ARG;
     ctx->scan_slices = nslices;

@@ -358,7 +358,7 @@ class DeviceShard:
                                                               self._stream()))
 
     def certify(self):
-        """Digit-slice mode: re-evaluate in fp64 every marker whose error bound exceeds 1e-7 |vara| and every marker the
+        """Digit-slice mode: re-evaluate in fp64 every marker whose error bound exceeds 1.8 x budget (0.9e-6) of |vara| and every marker the
         bounds cannot exclude from being the arg-max, so that the arg-max below is the fp64 scan's (find_qtl.R:71-83)."""
         if self.mode != 1:
             return
@@ -407,7 +407,19 @@ class DeviceShard:
 
     def best(self):
         """(tsqmax, GLOBAL 0-based index or -1, near ties) of the last scan (synchronises)."""
-        b = self._best.cpu().numpy()
+        if self.mode == 1 and self.certified and self.cert_ws is not None and self.ws is not None:
+            # the same copy brings the certificate's overflow flag and the spectral bound: a scan that took a digit off under the
+            # spectral bound and then had to redo the block in fp64 makes this context keep the worst-case digit count (as
+            # eagle_calculate_a_and_vara does for the reference-shaped call; eagle_set_scan_budget re-arms)
+            u8 = self.torch.uint8
+            raw = self.torch.cat([self._best.view(u8), self.cert_ws[:24], self.ws[40:48]]).cpu().numpy()
+            b = np.frombuffer(raw[:24].tobytes(), dtype=np.int64)
+            overflow = int(np.frombuffer(raw[24:48].tobytes()[12:16], dtype=np.int32)[0])
+            spec = float(np.frombuffer(raw[48:56].tobytes(), dtype=np.float64)[0])
+            if overflow and spec > 0.0:
+                self.L.eagle_dev_set_spectral(self.ctx, 0)
+        else:
+            b = self._best.cpu().numpy()
         tsqmax = float(np.frombuffer(b[:1].tobytes(), dtype=np.float64)[0])
         idx0 = int(b[1])
         return tsqmax, (idx0 + self.first if idx0 >= 0 else -1), int(b[2])

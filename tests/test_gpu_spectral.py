@@ -183,3 +183,39 @@ def test_context_stops_saving_after_a_fallback(tmp_path):
     finally:
         api.set_scan_budget(5e-7)
         api.drop_cache()
+
+
+def test_device_resident_driver_stops_saving_after_a_fallback():
+    """The same rule for callers of the device-resident entry points (sharded.py: bench.py --gpus N): best() sees the certificate."""
+    import torch
+    from eagleeverything_amd.sharded import DeviceShard
+    n, L = 2048, 6144
+    rng = np.random.default_rng(3)
+    Mt8 = (rng.binomial(2, rng.uniform(0.1, 0.5, size=L)[:, None], size=(L, n)) - 1).astype(np.int8)
+    quiet = np.arange(n) < n // 2
+    Mt8[np.ix_(np.arange(L) % 2 == 1, ~quiet)] = 0
+    E = rng.standard_normal((n, n)) * 2e-4
+    E[quiet, :] = 0.0
+    E[:, quiet] = 0.0
+    V = np.diag(np.where(quiet, 1e-4, 1.0) * rng.uniform(0.8, 1.2, size=n)) + 0.5 * (E + E.T)
+    sh = DeviceShard(n, L)
+    sh.Mt8[:L, :n] = torch.from_numpy(Mt8).to(sh.dev)
+    sh.set_operands(0.9 * np.eye(n), V, rng.standard_normal(n))
+    try:
+        sh.L.eagle_dev_set_spectral(sh.ctx, 1)
+        sh.mode = 0
+        sh.scan()
+        best64 = sh.best()[:2]
+        sh.mode = 1
+        sh.scan()
+        b1 = sh.best()[:2]
+        S1 = sh.vara_i8_info()[0]
+        c1 = sh.certificate()
+        assert sh.last_specH > 0.0 and S1 == sh.last_sliced - 1 and c1["overflow"] == 1 and c1["flagged"] > 2048
+        sh.scan()
+        b2 = sh.best()[:2]
+        S2 = sh.vara_i8_info()[0]
+        assert sh.last_specH == 0.0 and S2 == sh.last_sliced == S1 + 1
+        assert b1 == b2 == best64
+    finally:
+        sh.L.eagle_dev_set_spectral(sh.ctx, 1)
