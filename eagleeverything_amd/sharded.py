@@ -380,7 +380,8 @@ class DeviceShard:
 
     def vara_i8_info(self):
         """(slices used, absolute error bound, max |off-diagonal W|) of the last int8-slice vara launch (synchronises)."""
-        h = self.ws[:72].cpu().numpy().tobytes()
+        h = self.ws[:96].cpu().numpy().tobytes()
+        self.last_level = int(np.frombuffer(h[92:96], dtype=np.int32)[0])   # which level of the spectral bound took the digit off (0: none)
         self.last_e = int(np.frombuffer(h[64:68], dtype=np.int32)[0])   # scale exponent of the digits: unit of digit s = 2^(e + 2 - 8 (s + 1))
         self.last_sumdiag = float(np.frombuffer(h[24:32], dtype=np.float64)[0])  # sum_k |W_kk|
         # round 3: the spectral bound of the last digit (0: not in use) and the digits that were cut (= used, or one more)

@@ -85,8 +85,9 @@ int eagle_set_scan_slices(eagle_ctx* ctx, int nslices);
  * marker inside the budget, and the certificate sends every marker whose OWN bound exceeds 1.8 x budget (0.9e-6 by default) to the
  * fp64 kernel.  With the automatic count the library also tries ONE DIGIT FEWER than the worst-case bound asks for, under a spectral
  * bound of the truncation error: |error_i| <= (u/2)(||Ds||_2 + (n_pad-1)/2) sum_j m'_ij^2, Ds = the symmetrised last digit of W,
- * ||Ds||_2^2 <= max row sum of |Ds Ds| from an exact int8 MFMA Gram product (csrc/eagle_i8mfma.hip, k_spectral_decide) -- rigorous,
- * deterministic, a function of W alone.  At n = 10,000 this takes the scan of an AM() run from 4 digit slices to 3. */
+ * ||Ds||_2^2 <= max row sum of |Ds Ds| from an exact int8 MFMA Gram product, or, one level down, max_j (Ds Ds)_jj + ||offdiag(Ds Ds)||_2
+ * with the off-diagonal part bounded the same way (csrc/eagle_i8mfma.hip, k_spectral_decide) -- rigorous, deterministic, a function of
+ * W alone.  At n = 10,000 this takes the scan of an AM() run from 4 digit slices to 3, with the default budget and with 1e-7 alike. */
 int eagle_set_scan_budget(eagle_ctx* ctx, double relative_budget);
 /* How the digits of W are rounded (digit-slice mode).  0 (default): to nearest -- every vara_i is GUARANTEED within
  * l1_i^2 / 2 * 2^(e+1-8S) of the exact quadratic form (l1_i = sum_j |m'_ij| of the re-centred marker).  1: stochastic

@@ -86,6 +86,7 @@ def test_one_digit_fewer_under_a_rigorous_spectral_bound():
     assert sh.best()[:2] == best_wc == best64
     cert = sh.certificate()
     assert cert["overflow"] == 0 and cert["flagged"] == 0 and 1 <= cert["reevaluated"] <= 16
+    assert sh.last_level == 1
     # (4) the Gram row sums on the device are those of the symmetrised last digit (exact integers)
     Ds = (d + d.T).astype(np.int64)
     g = np.abs(Ds @ Ds).sum(axis=1).max()
@@ -95,7 +96,7 @@ def test_one_digit_fewer_under_a_rigorous_spectral_bound():
 
 
 def _host_decision(Wu, n_pad, budget=5e-7):
-    """The library's digit rule restated on the host: (worst-case digit count, whether the spectral bound takes one off)."""
+    """The library's digit rule restated on the host: (worst-case digit count, level of the spectral bound that takes one off or 0, H)."""
     off = np.triu(Wu, 1)
     mx = np.abs(off).max()
     f, e = np.frexp(mx)
@@ -105,9 +106,24 @@ def _host_decision(Wu, n_pad, budget=5e-7):
     Q = np.rint(np.ldexp(off, 8 * S_wc - (e + 2)))
     d = (np.mod(Q + 128, 256) - 128).astype(np.int64)
     Ds = d + d.T
-    g = np.abs(Ds @ Ds).sum(axis=1).max()
-    H = 0.5 * 2.0 ** (e + 2 - 8 * S_wc) * (np.sqrt(float(g)) + 0.5 * (n_pad - 1))
-    return S_wc, bool(H * n_pad <= target), H
+    G = Ds @ Ds
+    u = 2.0 ** (e + 2 - 8 * S_wc)
+    H1 = 0.5 * u * (np.sqrt(float(np.abs(G).sum(axis=1).max())) + 0.5 * (n_pad - 1))
+    if H1 * n_pad <= target:
+        return S_wc, 1, H1
+    # level 2: lambda_max(G) <= max G_jj + 2^s ||E_hi||_2 + ||E_lo||_F
+    shift = 8
+    while shift < 23 and 127.0 * (1 << shift) < 8.0 * 5476.0 * np.sqrt(n_pad):
+        shift += 1
+    E = G - np.diag(np.diag(G))
+    hi = (E + (1 << (shift - 1))) >> shift
+    lo = E - (hi << shift)
+    if np.abs(hi).max() > 127 and hi.min() < -128 or hi.max() > 127:
+        return S_wc, 0, 0.0
+    g2 = np.abs(hi @ hi).sum(axis=1).max()
+    normsq = float(np.diag(G).max()) + 2.0 ** shift * np.sqrt(float(g2)) + np.sqrt(float((lo * lo).sum()))
+    H2 = 0.5 * u * (np.sqrt(normsq) + 0.5 * (n_pad - 1))
+    return S_wc, (2 if H2 * n_pad <= target else 0), H2
 
 
 def test_saving_is_not_taken_when_it_does_not_pay_or_is_not_allowed():
@@ -118,18 +134,21 @@ def test_saving_is_not_taken_when_it_does_not_pay_or_is_not_allowed():
     sh.fill_synthetic(seed=12)
     sh.mode = 1
     seen = []
-    for diag in (0.05, 1.0):        # small diagonal: the worst-case count has no room for a whole digit at this n; larger: it has
+    # diagonal 0.02: the worst-case count has no room for a whole digit at this n; 0.08: room for the second level of the bound only; 1.0: for the first
+    for diag in (0.02, 0.08, 1.0):
         S, V, ahat = _operands(torch, sh.dev, n, 1e-3, diag, 6)
         sh.set_operands(S, V, ahat)
         sh.scan()
         torch.cuda.synchronize()
         S_used = sh.vara_i8_info()[0]
-        S_wc, take, H = _host_decision(sh.Wu.cpu().numpy(), sh.np_)
-        assert sh.last_sliced == S_wc and S_used == S_wc - (1 if take else 0) and (sh.last_specH > 0.0) == take, (diag, S_used, S_wc, take)
-        if take:
+        S_wc, level, H = _host_decision(sh.Wu.cpu().numpy(), sh.np_)
+        assert sh.last_sliced == S_wc and S_used == S_wc - (1 if level else 0) and sh.last_level == level, (diag, S_used, S_wc, level, sh.last_level)
+        if level:
             assert H <= sh.last_specH <= H * (1 + 1e-12)
-        seen.append(take)
-    assert seen == [False, True]
+        else:
+            assert sh.last_specH == 0.0
+        seen.append(level)
+    assert seen == [0, 2, 1], seen
     # a forced digit count and stochastic rounding never take it (operands of the second case)
     sh.nslices, sh.ws = 4, None
     sh.scan()
