@@ -95,6 +95,8 @@ SIGNATURES = {
     "eagle_last_stream_stats": (C.c_int, [C.c_void_p, C.c_void_p]),
     "eagle_last_scan_timing": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "eagle_scan_operand_cache_stats": (C.c_int, [C.c_void_p, c_lp, c_lp]),
+    "eagle_dev_vara_i8_extend": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_long, C.c_int, C.c_void_p,
+                                           C.c_void_p, C.c_void_p]),
     "eagle_dev_vara_i8_mfma_shifted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_int, C.c_void_p,
                                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     "eagle_vara_f6_workspace_bytes": (C.c_int64, [C.c_long, C.c_long, C.c_int]),

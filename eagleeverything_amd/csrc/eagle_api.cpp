@@ -1295,6 +1295,10 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
             ph.mark(ctx->stream, PH_PREPARE);
             rc = eagle_dev_vara_i8_mfma_shifted(ctx, Ms, cv, nrp, np, ldm, nslices, ws, ctx->d_vara + r0, nullptr, ctx->stream);
             if (rc) break;
+            // markers that fail their budget under the spectral bound get the dropped digit back (a per-marker decision: the same
+            // whatever the blocking; dropped on the device when nobody qualifies)
+            rc = eagle_dev_vara_i8_extend(ctx, Ms, cv, l1, nr, nrp, np, ldm, nslices, ws, ctx->d_vara + r0, ctx->stream);
+            if (rc) break;
             ph.mark(ctx->stream, PH_VARA);
             // a-posteriori certificate: markers the digit bounds cannot settle are re-evaluated by the fp64 kernel, so that
             // which(tsq == max(tsq))[1] on the returned arrays is the marker the fp64 scan selects (find_qtl.R:71-83).  One resident

@@ -1444,18 +1444,23 @@ extern "C" int eagle_dev_spectral_zbuild_i8(eagle_ctx* ctx, const int8_t* Mt8, l
     return EAGLE_OK;
 }
 
+// vara_i from the exact integer row-dots q_s[i] of `nslices` digit slices (smallest term first), the fp64 diagonal term and the
+// re-centring corrections
+__device__ __forceinline__ double vara_from_q(const long long* __restrict__ q, long Lp, long i, int nslices, const VaraHdr* __restrict__ hdr,
+                                              const double* __restrict__ vdiag, const int8_t* __restrict__ cshift, const double* __restrict__ mrho) {
+    const int e = hdr->e;
+    double s = 0.0;
+    for (int k = nslices - 1; k >= 0; k--) s += ldexp((double)q[(long)k * Lp + i], e + 2 - 8 * (k + 1));  // smallest first
+    const double c = cshift ? (double)cshift[i] : 0.0;  // re-centred marker: off(m) = off(m') + c m^T rho - c^2 R
+    if (c != 0.0) s += c * mrho[i] - c * c * hdr->R;
+    return vdiag[i] + s;  // diagonal term sum_k m_ik^2 W_kk (fp64) + exact-integer off-diagonal term
+}
 __global__ __launch_bounds__(256) void k_vara_i8_finish(const long long* __restrict__ q, long Lp, const VaraHdr* __restrict__ hdr,
                                                         const double* __restrict__ vdiag, const int8_t* __restrict__ cshift,
                                                         const double* __restrict__ mrho, double* __restrict__ vara) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= Lp) return;
-    const int e = hdr->e;
-    const int nslices = hdr->S;
-    double s = 0.0;
-    for (int k = nslices - 1; k >= 0; k--) s += ldexp((double)q[(long)k * Lp + i], e + 2 - 8 * (k + 1));  // smallest first
-    const double c = cshift ? (double)cshift[i] : 0.0;  // re-centred marker: off(m) = off(m') + c m^T rho - c^2 R
-    if (c != 0.0) s += c * mrho[i] - c * c * hdr->R;
-    vara[i] = vdiag[i] + s;  // diagonal term sum_k m_ik^2 W_kk (fp64) + exact-integer off-diagonal term
+    vara[i] = vara_from_q(q, Lp, i, hdr->S, hdr, vdiag, cshift, mrho);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1495,8 +1500,14 @@ __device__ __forceinline__ CertCtx cert_ctx(const VaraHdr* hdr) {
     c.stochastic = hdr->pad;
     return c;
 }
-__device__ __forceinline__ double cert_bound(const CertCtx& cc, const int32_t* l1q2, long i, int c, double vdiag, double mrho, double vara) {
+__device__ __forceinline__ double cert_bound(const CertCtx& cc, const int32_t* l1q2, long i, int c, double vdiag, double mrho, double vara,
+                                             int ext = 0) {
     const double l = (double)l1q2[2 * i];
+    if (ext && cc.specH > 0.0) {   // a marker that got the dropped digit back (eagle_dev_vara_i8_extend): all digits cut, rounding only
+        double mag = fabs(vdiag) + fabs(vara - vdiag);
+        if (c != 0) mag += 2.0 * (fabs(mrho) + cc.absR);
+        return 0.5 * l * l * (cc.delta * (0x1p-8 / (1.0 + 0x1p-8))) + 0x1p-48 * mag + 0x1p-50 * cc.sumdiag;
+    }
     // round to nearest: guaranteed; stochastic rounding: exceeded with probability below 1e-30 per marker (and never above
     // the guaranteed l1^2 * delta of an interval of twice the width)
     double b = cc.stochastic ? fmin(VARA_HOEFFDING_K * (double)l1q2[2 * i + 1] * cc.delta, l * l * cc.delta) : 0.5 * l * l * cc.delta;
@@ -1508,13 +1519,13 @@ __device__ __forceinline__ double cert_bound(const CertCtx& cc, const int32_t* l
 __global__ __launch_bounds__(256) void k_cert_lb(const double* __restrict__ a, const double* __restrict__ vara, long L,
                                                  const int32_t* __restrict__ l1, const int8_t* __restrict__ cshift,
                                                  const double* __restrict__ vdiag, const double* __restrict__ mrho,
-                                                 const VaraHdr* __restrict__ hdr, CertHdr* __restrict__ ch) {
+                                                 const VaraHdr* __restrict__ hdr, CertHdr* __restrict__ ch, const unsigned char* __restrict__ xflag) {
     const CertCtx cc = cert_ctx(hdr);
     double best = 0.0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L; i += (long)gridDim.x * 256) {
         const double x = a[i], v = vara[i];
         if (!(isfinite(x) && isfinite(v))) continue;
-        const double up = v + cert_bound(cc, l1, i, cshift[i], vdiag[i], mrho[i], v);
+        const double up = v + cert_bound(cc, l1, i, cshift[i], vdiag[i], mrho[i], v, xflag ? xflag[i] : 0);
         if (!(up > 0.0)) continue;
         const double lb = (x * x) / up;
         best = lb > best ? lb : best;
@@ -1527,7 +1538,7 @@ __global__ __launch_bounds__(256) void k_cert_select(const double* __restrict__ 
                                                      const int32_t* __restrict__ l1, const int8_t* __restrict__ cshift,
                                                      const double* __restrict__ vdiag, const double* __restrict__ mrho,
                                                      const VaraHdr* __restrict__ hdr, CertHdr* __restrict__ ch, long* __restrict__ idx,
-                                                     double lb_override) {
+                                                     double lb_override, const unsigned char* __restrict__ xflag) {
     const CertCtx cc = cert_ctx(hdr);
     // lb_override (not NaN): the lower bound of the maximum over ALL shards of a multi-device scan (exchanged on the host),
     // so that every device selects exactly the candidates a single-device scan of the whole file selects
@@ -1536,7 +1547,7 @@ __global__ __launch_bounds__(256) void k_cert_select(const double* __restrict__ 
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L; i += (long)gridDim.x * 256) {
         const double x = a[i], v = vara[i];
         if (!(isfinite(x) && isfinite(v))) continue;  // NaN / Inf operands: the fp64 kernel gives the same
-        const double b = cert_bound(cc, l1, i, cshift[i], vdiag[i], mrho[i], v);
+        const double b = cert_bound(cc, l1, i, cshift[i], vdiag[i], mrho[i], v, xflag ? xflag[i] : 0);
         const bool flagged = b > cc.flag_rel * fabs(v);
         const double den = v - b;
         const bool cand = !(den > 0.0) || (x * x) / den >= thr;
@@ -1577,6 +1588,7 @@ extern "C" int eagle_dev_cert_accumulate(eagle_ctx* ctx, const void* cert_ws, lo
 
 static int ws_smax(int nslices);  // layout of the vara workspace (defined with it, below)
 static size_t ws_vd_off(long n_pad, long L_pad, int smax);
+static size_t ws_xflag_off(long n_pad, long L_pad, int smax);
 static size_t ws_mr_off(long n_pad, long L_pad, int smax);
 static size_t cert_idx_off() { return 256; }
 static size_t cert_rows_off() { return cert_idx_off() + (size_t)CERT_CAP * sizeof(long); }
@@ -1600,7 +1612,8 @@ extern "C" int eagle_dev_scan_certify_lb(eagle_ctx* ctx, long L, long L_pad, lon
     const double* mrho = (const double*)((const char*)vara_ws + ws_mr_off(n_pad, L_pad, smax));
     unsigned blocks = (unsigned)((L + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_cert_lb, dim3(blocks), dim3(256), 0, s, a, vara, L, l1norm, cshift, vdiag, mrho, hdr, ch);
+    hipLaunchKernelGGL(k_cert_lb, dim3(blocks), dim3(256), 0, s, a, vara, L, l1norm, cshift, vdiag, mrho, hdr, ch,
+                       (const unsigned char*)vara_ws + ws_xflag_off(n_pad, L_pad, smax));
     e = hipGetLastError();
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "k_cert_lb");
     return EAGLE_OK;
@@ -1623,7 +1636,8 @@ extern "C" int eagle_dev_scan_certify_apply(eagle_ctx* ctx, const int8_t* Mt8, l
     double* partial = (double*)((char*)cert_ws + cert_part_off(n_pad));
     unsigned blocks = (unsigned)((L + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_cert_select, dim3(blocks), dim3(256), 0, s, a, vara, L, l1norm, cshift, vdiag, mrho, hdr, ch, idx, lb_override);
+    hipLaunchKernelGGL(k_cert_select, dim3(blocks), dim3(256), 0, s, a, vara, L, l1norm, cshift, vdiag, mrho, hdr, ch, idx, lb_override,
+                       (const unsigned char*)vara_ws + ws_xflag_off(n_pad, L_pad, smax));
     hipLaunchKernelGGL(k_cert_gather, dim3(CERT_CAP), dim3(256), 0, s, Mt8, ld, n_pad, ch, idx, rows);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "scan_certify");
@@ -1655,10 +1669,11 @@ extern "C" int eagle_dev_scan_certify(eagle_ctx* ctx, const int8_t* Mt8, long L,
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_cert_bounds(const double* __restrict__ vara, long L, const int32_t* __restrict__ l1,
                                                      const int8_t* __restrict__ cshift, const double* __restrict__ vdiag,
-                                                     const double* __restrict__ mrho, const VaraHdr* __restrict__ hdr, double* __restrict__ bound) {
+                                                     const double* __restrict__ mrho, const VaraHdr* __restrict__ hdr, double* __restrict__ bound,
+                                                     const unsigned char* __restrict__ xflag) {
     const CertCtx cc = cert_ctx(hdr);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L; i += (long)gridDim.x * 256)
-        bound[i] = cert_bound(cc, l1, i, cshift[i], vdiag[i], mrho[i], vara[i]);
+        bound[i] = cert_bound(cc, l1, i, cshift[i], vdiag[i], mrho[i], vara[i], xflag ? xflag[i] : 0);
 }
 __global__ __launch_bounds__(256) void k_cert_lb_b(const double* __restrict__ a, const double* __restrict__ vara, const double* __restrict__ bound,
                                                    long L, CertHdr* __restrict__ ch) {
@@ -1704,7 +1719,8 @@ extern "C" int eagle_dev_cert_bounds(eagle_ctx* ctx, long L, long L_pad, long n_
     const double* mrho = (const double*)((const char*)vara_ws + ws_mr_off(n_pad, L_pad, smax));
     unsigned blocks = (unsigned)((L + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_cert_bounds, dim3(blocks), dim3(256), 0, (hipStream_t)stream, vara, L, l1norm, cshift, vdiag, mrho, hdr, bound);
+    hipLaunchKernelGGL(k_cert_bounds, dim3(blocks), dim3(256), 0, (hipStream_t)stream, vara, L, l1norm, cshift, vdiag, mrho, hdr, bound,
+                       (const unsigned char*)vara_ws + ws_xflag_off(n_pad, L_pad, smax));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "k_cert_bounds");
     return EAGLE_OK;
@@ -1773,9 +1789,21 @@ static size_t ws_bs_off(long n_pad, long L_pad, int smax) {
     return (ws_cp_off(n_pad, L_pad, smax) + (size_t)n_pad * (size_t)(n_pad / T8 + 1) * 8 + 255) / 256 * 256;
 }
 
+// Behind the slice slots: the area of eagle_dev_vara_i8_extend (markers that get the dropped digit back, see there)
+//   [ ExtHdr 256 B | idx: cap int32 | flag: L_pad bytes | qc: cap int64 | Xc: cap x n_pad int8 ],  cap = min(65,536, L_pad) rounded to 768
+#define EXT_CAP_MAX 65536
+struct ExtHdr { VaraHdr h2; int count; int overflow; };   // h2: a header for the vara kernels, which read only its S (1: run, 0: every worker leaves)
+static long ext_cap(long L_pad) { const long c = L_pad < EXT_CAP_MAX ? L_pad : EXT_CAP_MAX; return (c + 767) / 768 * 768; }
+static size_t r256(size_t x) { return (x + 255) / 256 * 256; }
+static size_t ws_ext_off(long n_pad, long L_pad, int smax) { return r256(ws_bs_off(n_pad, L_pad, smax) + (size_t)smax * n_pad * n_pad); }
+static size_t ws_xidx_off(long n_pad, long L_pad, int smax) { return ws_ext_off(n_pad, L_pad, smax) + 256; }
+static size_t ws_xflag_off(long n_pad, long L_pad, int smax) { return ws_xidx_off(n_pad, L_pad, smax) + r256(4 * (size_t)ext_cap(L_pad)); }
+static size_t ws_xq_off(long n_pad, long L_pad, int smax) { return ws_xflag_off(n_pad, L_pad, smax) + r256((size_t)L_pad); }
+static size_t ws_xc_off(long n_pad, long L_pad, int smax) { return ws_xq_off(n_pad, L_pad, smax) + r256(8 * (size_t)ext_cap(L_pad)); }
+
 extern "C" int64_t eagle_vara_i8_workspace_bytes(long n_pad, long L_pad, int nslices) {
     const int smax = ws_smax(nslices);
-    return (int64_t)(ws_bs_off(n_pad, L_pad, smax) + (size_t)smax * n_pad * n_pad);
+    return (int64_t)(ws_xc_off(n_pad, L_pad, smax) + (size_t)ext_cap(L_pad) * (size_t)n_pad);
 }
 
 static int vara_i8_check(eagle_ctx* ctx, long L_pad, long n_pad, long ld, int nslices) {
@@ -1812,6 +1840,11 @@ extern "C" int eagle_dev_vara_i8_prepare_part(eagle_ctx* ctx, const int8_t* Mt8,
     hipError_t e = part == 2 ? hipMemsetAsync((char*)ws + ws_q_off(), 0, ws_dw_off(L_pad, smax) - ws_q_off(), s)   // q only
                              : hipMemsetAsync(ws, 0, ws_dw_off(L_pad, smax), s);                                     // header and q
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "vara_i8 memset");
+    if (part != 1) {   // per marker block: nobody has been given the dropped digit back yet (eagle_dev_vara_i8_extend)
+        e = hipMemsetAsync((char*)ws + ws_ext_off(n_pad, L_pad, smax), 0, 256, s);
+        if (e == hipSuccess) e = hipMemsetAsync((char*)ws + ws_xflag_off(n_pad, L_pad, smax), 0, (size_t)L_pad, s);
+        if (e != hipSuccess) return eagle_fail_hip(ctx, e, "vara_i8 extension memset");
+    }
     if (part != 2) {
         hipLaunchKernelGGL(k_absmax_offdiag, dim3(1024), dim3(256), 0, s, Wu, n_pad, (unsigned long long*)&hdr->maxabs_off);
         hipLaunchKernelGGL(k_vara_prep, dim3(1), dim3(256), 0, s, Wu, n_pad, nslices, hdr, dW, ctx->scan_budget);
@@ -1868,21 +1901,9 @@ extern "C" int eagle_dev_vara_i8_prepare(eagle_ctx* ctx, const int8_t* Mt8, long
     return eagle_dev_vara_i8_prepare_part(ctx, Mt8, L_pad, n_pad, ld, Wu, nslices, ws, v, a_out, stream, 0);
 }
 
-// Phase 2: the int8 MFMA kernel over all (marker tile, slice) workers + the S-term finish.
-// Mt8s / cshift: the re-centred genotype image and the per-marker shifts of eagle_dev_marker_shift (prepare ran on the
-// original image); cshift == NULL: Mt8s is the original image and no correction applies.
-extern "C" int eagle_dev_vara_i8_mfma_shifted(eagle_ctx* ctx, const int8_t* Mt8s, const int8_t* cshift, long L_pad, long n_pad, long ld,
-                                              int nslices, void* ws, double* vara_out, double* err_bound_dev, void* stream) {
-    int rc = vara_i8_check(ctx, L_pad, n_pad, ld, nslices);
-    if (rc) return rc;
-    if (L_pad == 0) return EAGLE_OK;
-    hipStream_t s = (hipStream_t)stream;
-    const int smax = ws_smax(nslices);
-    VaraHdr* hdr = (VaraHdr*)ws;
-    long long* q = (long long*)((char*)ws + ws_q_off());
-    double* vdiag = (double*)((char*)ws + ws_vd_off(n_pad, L_pad, smax));
-    double* mrho = (double*)((char*)ws + ws_mr_off(n_pad, L_pad, smax));
-    int8_t* Bs = (int8_t*)((char*)ws + ws_bs_off(n_pad, L_pad, smax));
+// The int8 MFMA kernel over all (marker tile, slice) workers of an image: q[s][i] += ... for the hdr->S slices at Bs (grid sized for smax).
+static int vara_i8_launch(eagle_ctx* ctx, const int8_t* Mt8s, long L_pad, long n_pad, long ld, int smax, const VaraHdr* hdr, const int8_t* Bs,
+                          long long* q, hipStream_t s) {
     const int ntm = (int)(L_pad / T8);
     const int groups = (ntm + 7) / 8;
     if (!ctx->attr_vara_i8) {  // per device: a second ctx on another GPU must set it again
@@ -1925,12 +1946,137 @@ extern "C" int eagle_dev_vara_i8_mfma_shifted(eagle_ctx* ctx, const int8_t* Mt8s
         }
     } else
     hipLaunchKernelGGL(k_vara_i8, dim3((unsigned)(groups * 8 * smax)), dim3(512), 5 * TILE_BYTES, s, Mt8s, ld, ntm, Bs, n_pad, hdr, q, L_pad);
+    return EAGLE_OK;
+}
+
+// Phase 2: the int8 MFMA kernel over all (marker tile, slice) workers + the S-term finish.
+// Mt8s / cshift: the re-centred genotype image and the per-marker shifts of eagle_dev_marker_shift (prepare ran on the
+// original image); cshift == NULL: Mt8s is the original image and no correction applies.
+extern "C" int eagle_dev_vara_i8_mfma_shifted(eagle_ctx* ctx, const int8_t* Mt8s, const int8_t* cshift, long L_pad, long n_pad, long ld,
+                                              int nslices, void* ws, double* vara_out, double* err_bound_dev, void* stream) {
+    int rc = vara_i8_check(ctx, L_pad, n_pad, ld, nslices);
+    if (rc) return rc;
+    if (L_pad == 0) return EAGLE_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int smax = ws_smax(nslices);
+    VaraHdr* hdr = (VaraHdr*)ws;
+    long long* q = (long long*)((char*)ws + ws_q_off());
+    double* vdiag = (double*)((char*)ws + ws_vd_off(n_pad, L_pad, smax));
+    double* mrho = (double*)((char*)ws + ws_mr_off(n_pad, L_pad, smax));
+    int8_t* Bs = (int8_t*)((char*)ws + ws_bs_off(n_pad, L_pad, smax));
+    rc = vara_i8_launch(ctx, Mt8s, L_pad, n_pad, ld, smax, hdr, Bs, q, s);
+    if (rc) return rc;
     hipLaunchKernelGGL(k_vara_i8_finish, dim3((unsigned)((L_pad + 255) / 256)), dim3(256), 0, s, q, L_pad, hdr, vdiag, cshift, mrho, vara_out);
     if (err_bound_dev) hipLaunchKernelGGL(k_vara_i8_bound, dim3(1), dim3(1), 0, s, hdr, err_bound_dev, (int*)nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "vara_i8_mfma");
     return EAGLE_OK;
 }
+// ------------------------------------------------------------------------------------------------
+// Giving single markers the dropped digit back (round 3).  Under the spectral bound the scan runs on S = S_sliced - 1 digits and
+// |digit error_i| <= specH q2_i.  A marker whose quadratic form is far below q2_i mean(W_kk) -- one that IS a top eigenvector of the
+// kinship, in a panel of strongly diverged sub-populations -- fails its budget under that bound although the digit that was cut would
+// settle it.  Instead of sending thousands of such markers to the fp64 kernel (or the block to the fp64 fallback), they get the last
+// digit's term exactly: rows gathered from the re-centred image into a compact image, ONE more run of the vara kernel on it with the
+// last digit slice only, q[S_sliced-1][i] filled in, vara_i re-formed from all S_sliced digits (bitwise the value a scan on S_sliced
+// digits gives that marker) and a flag that makes cert_bound use the rounding bound of S_sliced digits for it.  A per-marker decision
+// from the marker's own numbers: the same whatever the blocking.  Everything is dropped on the device when nobody qualifies (the
+// vara kernel sees S = 0: every worker leaves).  More than `cap` markers in a block: nobody is extended, the certificate will
+// overflow and the block take the fp64 fallback as before.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ext_select(const double* __restrict__ vara, long L, const int32_t* __restrict__ l1q2, const VaraHdr* __restrict__ hdr,
+                                                    ExtHdr* __restrict__ xh, int* __restrict__ idx, unsigned char* __restrict__ flag, int cap) {
+    const double H = hdr->specH;
+    if (!(H > 0.0)) return;
+    const double delta = ldexp(1.0, hdr->e + 1 - 8 * hdr->S) * (1.0 + 0x1p-8), thr = VARA_FLAG_FACTOR * hdr->budget;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L; i += (long)gridDim.x * 256) {
+        const double v = vara[i];
+        if (!isfinite(v)) continue;
+        const double l = (double)l1q2[2 * i];
+        const double b = fmin(H * (double)l1q2[2 * i + 1], 0.5 * l * l * delta);
+        if (b > thr * fabs(v)) {
+            const int k = atomicAdd(&xh->count, 1);
+            if (k < cap) { idx[k] = (int)i; flag[i] = 1; } else xh->overflow = 1;
+        }
+    }
+}
+// S of the second header: 1 = run the last digit slice on the compact image.  The slice is copied to the fixed slot `spare` (the
+// kernels take their slice base from the host, which does not know S_sliced); no spare slot: nobody is extended.
+__global__ void k_ext_head(const VaraHdr* __restrict__ hdr, ExtHdr* __restrict__ xh, unsigned char* __restrict__ flag, const int* __restrict__ idx, int cap,
+                           int spare) {
+    const bool on = xh->count > 0 && !xh->overflow && hdr->S_sliced - 1 < spare;
+    if (!on && threadIdx.x == 0 && xh->count > 0) {   // take the flags back: these markers keep the spectral bound (and will be re-evaluated)
+        const int c = xh->count < cap ? xh->count : cap;
+        for (int k = 0; k < c; k++) flag[idx[k]] = 0;
+        xh->count = 0;
+    }
+    if (threadIdx.x == 0) xh->h2.S = on ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_ext_copy_slice(const ExtHdr* __restrict__ xh, const VaraHdr* __restrict__ hdr, int8_t* __restrict__ Bs, long nn, int spare) {
+    if (!xh->h2.S) return;
+    const i32x4* src = (const i32x4*)(Bs + (long)(hdr->S_sliced - 1) * nn);
+    i32x4* dst = (i32x4*)(Bs + (long)spare * nn);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nn / 16; i += (long)gridDim.x * 256) dst[i] = src[i];
+}
+// Xc[k][0..n_pad) = Mt8s[idx[k]][0..n_pad) for k < count, zero rows behind them up to cap; qc zeroed
+__global__ __launch_bounds__(256) void k_ext_gather(const int8_t* __restrict__ Mt8s, long ld, long n_pad, const ExtHdr* __restrict__ xh, const int* __restrict__ idx,
+                                                    int8_t* __restrict__ Xc, long long* __restrict__ qc) {
+    if (!xh->h2.S) return;
+    const int k = blockIdx.x;
+    const int8_t* src = k < xh->count ? Mt8s + (long)idx[k] * ld : nullptr;
+    for (long j = (long)threadIdx.x * 16; j < n_pad; j += 256 * 16) {
+        i32x4 x = {0, 0, 0, 0};
+        if (src) x = *(const i32x4*)(src + j);
+        *(i32x4*)(Xc + (long)k * n_pad + j) = x;
+    }
+    if (threadIdx.x == 0) qc[k] = 0;
+}
+__global__ __launch_bounds__(256) void k_ext_apply(const ExtHdr* __restrict__ xh, const int* __restrict__ idx, const long long* __restrict__ qc,
+                                                   long long* __restrict__ q, long Lp, const VaraHdr* __restrict__ hdr, const double* __restrict__ vdiag,
+                                                   const int8_t* __restrict__ cshift, const double* __restrict__ mrho, double* __restrict__ vara) {
+    if (!xh->h2.S) return;
+    const int cnt = xh->count;
+    const int Sc = hdr->S_sliced;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < cnt; k += gridDim.x * 256) {
+        const long i = idx[k];
+        q[(long)(Sc - 1) * Lp + i] = qc[k];
+        vara[i] = vara_from_q(q, Lp, i, Sc, hdr, vdiag, cshift, mrho);
+    }
+}
+// After eagle_dev_vara_i8_mfma_shifted and before the certification, same workspace / image / cshift / l1norm {sum |m'|, sum m'^2}.
+extern "C" int eagle_dev_vara_i8_extend(eagle_ctx* ctx, const int8_t* Mt8s, const int8_t* cshift, const int32_t* l1norm, long L, long L_pad, long n_pad,
+                                        long ld, int nslices, void* ws, double* vara, void* stream) {
+    int rc = vara_i8_check(ctx, L_pad, n_pad, ld, nslices);
+    if (rc) return rc;
+    if (L <= 0 || nslices != 0 || !l1norm || !cshift) return EAGLE_OK;   // the spectral bound is only ever in use with the automatic digit count
+    hipStream_t s = (hipStream_t)stream;
+    const int smax = ws_smax(nslices);
+    const VaraHdr* hdr = (const VaraHdr*)ws;
+    long long* q = (long long*)((char*)ws + ws_q_off());
+    const double* vdiag = (const double*)((char*)ws + ws_vd_off(n_pad, L_pad, smax));
+    const double* mrho = (const double*)((char*)ws + ws_mr_off(n_pad, L_pad, smax));
+    int8_t* Bs = (int8_t*)((char*)ws + ws_bs_off(n_pad, L_pad, smax));
+    ExtHdr* xh = (ExtHdr*)((char*)ws + ws_ext_off(n_pad, L_pad, smax));
+    int* idx = (int*)((char*)ws + ws_xidx_off(n_pad, L_pad, smax));
+    unsigned char* flag = (unsigned char*)ws + ws_xflag_off(n_pad, L_pad, smax);
+    long long* qc = (long long*)((char*)ws + ws_xq_off(n_pad, L_pad, smax));
+    int8_t* Xc = (int8_t*)ws + ws_xc_off(n_pad, L_pad, smax);
+    const long cap = ext_cap(L_pad);
+    const int spare = smax - 3;   // slot 4 of 7: slots 5 and 6 hold E_hi and Ds of the spectral bound
+    unsigned blocks = (unsigned)((L + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_ext_select, dim3(blocks), dim3(256), 0, s, vara, L, l1norm, hdr, xh, idx, flag, (int)cap);
+    hipLaunchKernelGGL(k_ext_head, dim3(1), dim3(64), 0, s, hdr, xh, flag, idx, (int)cap, spare);
+    hipLaunchKernelGGL(k_ext_copy_slice, dim3(1024), dim3(256), 0, s, xh, hdr, Bs, n_pad * n_pad, spare);
+    hipLaunchKernelGGL(k_ext_gather, dim3((unsigned)cap), dim3(256), 0, s, Mt8s, ld, n_pad, xh, idx, Xc, qc);
+    rc = vara_i8_launch(ctx, Xc, cap, n_pad, n_pad, 1, &xh->h2, Bs + (size_t)spare * n_pad * n_pad, qc, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_ext_apply, dim3(64), dim3(256), 0, s, xh, idx, qc, q, L_pad, hdr, vdiag, cshift, mrho, vara);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "vara_i8_extend");
+    return EAGLE_OK;
+}
+
 extern "C" int eagle_dev_vara_i8_mfma(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, int nslices, void* ws,
                                       double* vara_out, double* err_bound_dev, void* stream) {
     return eagle_dev_vara_i8_mfma_shifted(ctx, Mt8, nullptr, L_pad, n_pad, ld, nslices, ws, vara_out, err_bound_dev, stream);

@@ -150,6 +150,7 @@ class DeviceShard:
         self.mode = 0
         self.nslices = 0  # 0 = chosen by the library from its error bound
         self.stochastic = False  # digits of W rounded at random (eagle_set_scan_rounding): probabilistic certificate, one digit fewer
+        self.extend = True       # eagle_dev_vara_i8_extend after the vara kernel (tests switch it off to see the raw values)
 
     # ---- plumbing -------------------------------------------------------------------------------
     def _stream(self):
@@ -356,6 +357,10 @@ class DeviceShard:
             self._check(self.L.eagle_dev_vara_i8_mfma_shifted(self.ctx, Ms.data_ptr(), cs.data_ptr(), self.Lp, self.np_, self.np_,
                                                               self._ns(), self._ws().data_ptr(), self.vara.data_ptr(), None,
                                                               self._stream()))
+            if self.extend:   # markers that fail their budget under the spectral bound get the dropped digit back (dropped on the device otherwise)
+                self._check(self.L.eagle_dev_vara_i8_extend(self.ctx, Ms.data_ptr(), cs.data_ptr(), self.l1.data_ptr(), self.Lloc, self.Lp,
+                                                            self.np_, self.np_, self._ns(), self._ws().data_ptr(), self.vara.data_ptr(),
+                                                            self._stream()))
 
     def certify(self):
         """Digit-slice mode: re-evaluate in fp64 every marker whose error bound exceeds 1.8 x budget (0.9e-6) of |vara| and every marker the

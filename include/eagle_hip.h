@@ -349,6 +349,15 @@ int eagle_dev_marker_shift(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n
                            int8_t* cshift, int32_t* l1norm, void* stream);
 int eagle_dev_vara_i8_mfma_shifted(eagle_ctx* ctx, const int8_t* Mt8s, const int8_t* cshift, long L_pad, long n_pad, long ld,
                                    int nslices, void* ws, double* vara_out, double* err_bound_dev, void* stream);
+/* Between eagle_dev_vara_i8_mfma_shifted and the certification (same image, cshift, l1norm, workspace), automatic digit count only:
+ * when the scan ran on one digit fewer than cut (spectral bound, eagle_set_scan_budget), every marker whose own bound
+ * min(specH q2_i, l1_i^2/2 * 128.5 u) exceeds 1.8 x budget of |vara_i| is given the dropped digit back: its rows are gathered, the
+ * vara kernel runs once more on them with the last digit slice alone, and vara_i becomes, bit for bit, the value a scan on all the
+ * cut digits gives that marker (the certificate then uses the rounding bound of that digit count for it).  Up to min(65,536, L_pad)
+ * markers per call; more: nobody is extended and the certificate decides (fp64 fallback of the block).  Nothing runs when no marker
+ * qualifies.  A call that skips this step is still certified correctly -- its flagged markers go to the fp64 kernel instead. */
+int eagle_dev_vara_i8_extend(eagle_ctx* ctx, const int8_t* Mt8s, const int8_t* cshift, const int32_t* l1norm, long L, long L_pad, long n_pad,
+                             long ld, int nslices, void* ws, double* vara, void* stream);
 int eagle_dev_vara_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad, long ld, const double* Wu,
                       int nslices, void* ws, double* vara_out, double* err_bound_dev, void* stream);
 /* Certification of a digit-slice scan (after eagle_dev_vara_i8_mfma_shifted, before the arg-max), all on the device:

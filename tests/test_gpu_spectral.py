@@ -12,6 +12,9 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+# W_kk of the "quiet" individuals in the constructed panels below: markers that are non-zero only on them have vara = q2 * 0.81 * W_kk.
+QUIET_HOPELESS = 1e-6   # below what ANY digit count of the automatic rule certifies: > 2,048 flagged markers -> fp64 fallback of the block
+QUIET_RESCUED = 5e-3    # above their budget under the spectral bound (one digit fewer), inside it once they get the dropped digit back
 
 
 def _operands(torch, dev, n, off_scale, diag_scale, seed):
@@ -164,8 +167,9 @@ def test_saving_is_not_taken_when_it_does_not_pay_or_is_not_allowed():
 
 def test_context_stops_saving_after_a_fallback(tmp_path):
     """Markers whose quadratic form is far below q2 * mean(W_kk) (all their non-zero genotypes on individuals with a tiny W_kk) are
-    outside what the spectral bound certifies to the budget: more than 2,048 of them overflow the re-evaluation buffer, the block is
-    redone in fp64 (results still right), and the context keeps the worst-case digit count from then on."""
+    outside what the digits certify to the budget, with or without the dropped digit: more than 2,048 of them overflow the
+    re-evaluation buffer, the block is redone in fp64 (results still right), and the context keeps the worst-case digit count from
+    then on."""
     from eagleeverything_amd import rcpp_api as api, synth
     from oracle import oracle_c
     oracle_c.build()
@@ -178,7 +182,7 @@ def test_context_stops_saving_after_a_fallback(tmp_path):
     E = rng.standard_normal((n, n)) * 2e-4
     E[quiet, :] = 0.0
     E[:, quiet] = 0.0
-    V = np.diag(np.where(quiet, 1e-4, 1.0) * rng.uniform(0.8, 1.2, size=n)) + 0.5 * (E + E.T)
+    V = np.diag(np.where(quiet, QUIET_HOPELESS, 1.0) * rng.uniform(0.8, 1.2, size=n)) + 0.5 * (E + E.T)
     S = 0.9 * np.eye(n)
     ahat = rng.standard_normal(n)
     geno = synth.write_geno_pair(str(tmp_path), Mt8)
@@ -216,7 +220,7 @@ def test_device_resident_driver_stops_saving_after_a_fallback():
     E = rng.standard_normal((n, n)) * 2e-4
     E[quiet, :] = 0.0
     E[:, quiet] = 0.0
-    V = np.diag(np.where(quiet, 1e-4, 1.0) * rng.uniform(0.8, 1.2, size=n)) + 0.5 * (E + E.T)
+    V = np.diag(np.where(quiet, QUIET_HOPELESS, 1.0) * rng.uniform(0.8, 1.2, size=n)) + 0.5 * (E + E.T)
     sh = DeviceShard(n, L)
     sh.Mt8[:L, :n] = torch.from_numpy(Mt8).to(sh.dev)
     sh.set_operands(0.9 * np.eye(n), V, rng.standard_normal(n))
@@ -238,3 +242,88 @@ def test_device_resident_driver_stops_saving_after_a_fallback():
         assert b1 == b2 == best64
     finally:
         sh.L.eagle_dev_set_spectral(sh.ctx, 1)
+
+
+def _panel(n, L, quiet_diag, seed=3):
+    rng = np.random.default_rng(seed)
+    Mt8 = (rng.binomial(2, rng.uniform(0.1, 0.5, size=L)[:, None], size=(L, n)) - 1).astype(np.int8)
+    quiet = np.arange(n) < n // 2
+    odd = np.arange(L) % 2 == 1
+    Mt8[np.ix_(odd, ~quiet)] = 0
+    E = rng.standard_normal((n, n)) * 2e-4
+    E[quiet, :] = 0.0
+    E[:, quiet] = 0.0
+    V = np.diag(np.where(quiet, quiet_diag, 1.0) * rng.uniform(0.8, 1.2, size=n)) + 0.5 * (E + E.T)
+    return Mt8, odd, 0.9 * np.eye(n), V, rng.standard_normal(n)
+
+
+def test_markers_outside_the_spectral_bound_get_the_dropped_digit_back():
+    """eagle_dev_vara_i8_extend: 3,072 markers fail their budget under the spectral bound; each gets the last digit's term exactly and then
+    carries, bit for bit, the value of the scan on all cut digits -- no fp64 fallback, nobody else touched."""
+    import torch
+    from eagleeverything_amd.sharded import DeviceShard
+    n, L = 2048, 6144
+    Mt8, odd, S, V, ahat = _panel(n, L, QUIET_RESCUED)
+    sh = DeviceShard(n, L)
+    sh.Mt8[:L, :n] = torch.from_numpy(Mt8).to(sh.dev)
+    sh.set_operands(S, V, ahat)
+    sh.L.eagle_dev_set_spectral(sh.ctx, 1)
+    sh.mode = 0
+    sh.scan()
+    v64 = sh.vara[:L].cpu().numpy().copy()
+    best64 = sh.best()[:2]
+    sh.mode = 1
+    sh.certified = False
+    sh.L.eagle_dev_set_tune(sh.ctx, 29)
+    sh.scan()
+    torch.cuda.synchronize()
+    sh.L.eagle_dev_set_tune(sh.ctx, 0)
+    S_wc = sh.vara_i8_info()[0]
+    v_all_digits = sh.vara[:L].cpu().numpy().copy()
+    sh.extend = False
+    sh.scan()
+    torch.cuda.synchronize()
+    assert sh.vara_i8_info()[0] == S_wc - 1 and sh.last_specH > 0.0
+    v_fewer = sh.vara[:L].cpu().numpy().copy()
+    sh.extend = True
+    sh.scan()
+    torch.cuda.synchronize()
+    v_ext = sh.vara[:L].cpu().numpy().copy()
+    changed = v_ext != v_fewer
+    assert changed.sum() > 2048 and not changed[~odd].any() and changed[odd].mean() > 0.9    # the constructed markers, nobody else
+    np.testing.assert_array_equal(v_ext[changed], v_all_digits[changed])                       # the value of the scan on all cut digits
+    np.testing.assert_array_equal(v_ext[~changed], v_fewer[~changed])
+    sh.certified = True
+    sh.scan()
+    b = sh.best()[:2]
+    cert = sh.certificate()
+    assert cert["overflow"] == 0 and cert["flagged"] <= 64 and cert["reevaluated"] <= 80, cert   # a few stragglers go to the fp64 kernel
+    assert b == best64
+    np.testing.assert_allclose(sh.vara[:L].cpu().numpy(), v64, rtol=9e-7)
+    sh.scan()
+    sh.best()
+    assert sh.vara_i8_info()[0] == S_wc - 1 and sh.last_specH > 0.0                          # no fallback: the saving stays
+
+
+def test_extension_is_a_per_marker_decision_resident_and_streamed(tmp_path, monkeypatch):
+    """Through the reference-shaped call: the panel resident and streamed in 256-marker blocks returns the same bits."""
+    from eagleeverything_amd import rcpp_api as api, synth
+    n, L = 2048, 3072
+    Mt8, odd, S, V, ahat = _panel(n, L, QUIET_RESCUED)
+    geno = synth.write_geno_pair(str(tmp_path), Mt8)
+    try:
+        api.set_scan_mode(1)
+        api.set_scan_budget(5e-7)
+        r1 = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], np.nan, S, V, 8.0, (L, n), ahat)
+        d1, c1 = api.last_scan_digits(), api.last_scan_certificate()
+        assert d1[0] == d1[1] - 1 and d1[2] > 0.0 and not c1[2] and c1[1] <= 64, (d1, c1)
+        api.drop_cache()
+        monkeypatch.setenv("EAGLE_HIP_MAX_RESIDENT_GB", "%.6f" % (2.0 * 256 * 2048 / 1e9))
+        r2 = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], np.nan, S, V, 8.0, (L, n), ahat)
+        assert api.last_stream_stats()["chunks"] >= 12
+        np.testing.assert_array_equal(r2["vara"], r1["vara"])
+        np.testing.assert_array_equal(r2["a"], r1["a"])
+        assert api.last_scan_digits() == d1 and api.last_scan_certificate() == c1
+    finally:
+        monkeypatch.delenv("EAGLE_HIP_MAX_RESIDENT_GB", raising=False)
+        api.drop_cache()

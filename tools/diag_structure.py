@@ -40,10 +40,11 @@ run.make_operands(MMt)
 sh.mode = 1
 for tune, name in ((29, "worst-case count"), (0, "with the spectral bound")):
     sh.L.eagle_dev_set_tune(sh.ctx, tune)
-    sel = run.step()
+    sel, el, parts = run.timed(3, 1)
     torch.cuda.synchronize()
     S_used = sh.vara_i8_info()[0]
-    print("%-24s digits used %d cut %d specH %.3g  certificate %s  selected %s" % (name, S_used, sh.last_sliced, sh.last_specH, sh.certificate(), sel))
+    print("%-24s digits used %d cut %d specH %.3g  step %.2f ms (vara kernel + extension %.2f, certify %.2f)  certificate %s  selected %s"
+          % (name, S_used, sh.last_sliced, sh.last_specH, el / 3 * 1e3, parts["kern"] * 1e3, parts["cert"] * 1e3, sh.certificate(), sel))
 sh.L.eagle_dev_set_tune(sh.ctx, 0)
 if sh.last_specH > 0:
     q2 = sh.l1[:L, 1].double(); l1 = sh.l1[:L, 0].double()
