@@ -1167,7 +1167,9 @@ __device__ __forceinline__ void tx_klast(TxAcc& c, i32x4 (&a)[3], i32x4 (&an)[3]
 // barrier before every column-tile pair -- one agent-scope counter per (XCD, round, pair), bounded spin (a worker that is not
 // co-resident with its round only costs the others the spin limit, never a hang) -- so that they stream the shared genotype and
 // W-digit stages in step and the L2 serves them once.  Same integer sums: bit-identical q.
-template <bool PACE>
+// EXT: the same kernel under a second name for the run on the compact image of eagle_dev_vara_i8_extend -- a launch that is dropped
+// on the device whenever nobody qualifies, and that a profile should not average into the scan's launches.
+template <bool PACE, bool EXT = false>
 __global__ __launch_bounds__(512, 2) void k_vara_i8p(const int8_t* __restrict__ Mt8, long ld, int ntm, const int8_t* __restrict__ Bs,
                                                      long np, const VaraHdr* __restrict__ hdr, long long* __restrict__ q, long Lp, int cut_last_round,
                                                      int* __restrict__ pace) {
@@ -1903,7 +1905,7 @@ extern "C" int eagle_dev_vara_i8_prepare(eagle_ctx* ctx, const int8_t* Mt8, long
 
 // The int8 MFMA kernel over all (marker tile, slice) workers of an image: q[s][i] += ... for the hdr->S slices at Bs (grid sized for smax).
 static int vara_i8_launch(eagle_ctx* ctx, const int8_t* Mt8s, long L_pad, long n_pad, long ld, int smax, const VaraHdr* hdr, const int8_t* Bs,
-                          long long* q, hipStream_t s) {
+                          long long* q, hipStream_t s, bool ext = false) {
     const int ntm = (int)(L_pad / T8);
     const int groups = (ntm + 7) / 8;
     if (!ctx->attr_vara_i8) {  // per device: a second ctx on another GPU must set it again
@@ -1917,9 +1919,11 @@ static int vara_i8_launch(eagle_ctx* ctx, const int8_t* Mt8s, long L_pad, long n
     // form (k_vara_i8w), 7 = whole workers in the last round.
     if (vara_piped(ctx, n_pad) || (ctx->tune == 9 && n_pad < 32768)) {
         const bool piped = vara_piped(ctx, n_pad);
-        const bool pace = piped && ctx->tune == 14;
-        const void* kfn = !piped ? (const void*)k_vara_i8w : (pace ? (const void*)k_vara_i8p<true> : (const void*)k_vara_i8p<false>);
-        bool& attr = !piped ? ctx->attr_vara_i8w : (pace ? ctx->attr_vara_i8pp : ctx->attr_vara_i8p);
+        const bool pace = piped && ctx->tune == 14 && !ext;
+        const bool px = piped && ext;
+        const void* kfn = !piped ? (const void*)k_vara_i8w
+                                 : (pace ? (const void*)k_vara_i8p<true> : (px ? (const void*)k_vara_i8p<false, true> : (const void*)k_vara_i8p<false>));
+        bool& attr = !piped ? ctx->attr_vara_i8w : (pace ? ctx->attr_vara_i8pp : (px ? ctx->attr_vara_i8px : ctx->attr_vara_i8p));
         if (!attr) {
             hipError_t ea = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TW_ABYTES + TILE_BYTES));
             if (ea != hipSuccess) return eagle_fail_hip(ctx, ea, "hipFuncSetAttribute(k_vara_i8p/w)");
@@ -1930,6 +1934,7 @@ static int vara_i8_launch(eagle_ctx* ctx, const int8_t* Mt8s, long L_pad, long n
         const dim3 gridw((unsigned)(8 * (gw * smax + 31 * VARA_TAIL_PMAX)));
         const int cut = ctx->tune == 7 ? 0 : 1;
         if (!piped) hipLaunchKernelGGL(k_vara_i8w, gridw, dim3(512), 2 * (TW_ABYTES + TILE_BYTES), s, Mt8s, ld, ntw, Bs, n_pad, hdr, q, L_pad, cut);
+        else if (px) hipLaunchKernelGGL((k_vara_i8p<false, true>), gridw, dim3(512), 2 * (TW_ABYTES + TILE_BYTES), s, Mt8s, ld, ntw, Bs, n_pad, hdr, q, L_pad, cut, (int*)nullptr);
         else if (!pace) hipLaunchKernelGGL(k_vara_i8p<false>, gridw, dim3(512), 2 * (TW_ABYTES + TILE_BYTES), s, Mt8s, ld, ntw, Bs, n_pad, hdr, q, L_pad, cut, (int*)nullptr);
         else {
             // counters [8 XCDs][rounds][pairs], zeroed per launch, in the ctx's GEMM scratch (free during the scan)
@@ -2069,7 +2074,7 @@ extern "C" int eagle_dev_vara_i8_extend(eagle_ctx* ctx, const int8_t* Mt8s, cons
     hipLaunchKernelGGL(k_ext_head, dim3(1), dim3(64), 0, s, hdr, xh, flag, idx, (int)cap, spare);
     hipLaunchKernelGGL(k_ext_copy_slice, dim3(1024), dim3(256), 0, s, xh, hdr, Bs, n_pad * n_pad, spare);
     hipLaunchKernelGGL(k_ext_gather, dim3((unsigned)cap), dim3(256), 0, s, Mt8s, ld, n_pad, xh, idx, Xc, qc);
-    rc = vara_i8_launch(ctx, Xc, cap, n_pad, n_pad, 1, &xh->h2, Bs + (size_t)spare * n_pad * n_pad, qc, s);
+    rc = vara_i8_launch(ctx, Xc, cap, n_pad, n_pad, 1, &xh->h2, Bs + (size_t)spare * n_pad * n_pad, qc, s, true);
     if (rc) return rc;
     hipLaunchKernelGGL(k_ext_apply, dim3(64), dim3(256), 0, s, xh, idx, qc, q, L_pad, hdr, vdiag, cshift, mrho, vara);
     hipError_t e = hipGetLastError();

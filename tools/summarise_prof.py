@@ -32,6 +32,8 @@ def short(name):
                 return "k_gemm_f64<i8A,rowdot>" if "Li1ELi1E" in name or "<1, 1>" in name else "k_gemm_f64<f64A,store>"
             if "k_vara_i8_finish" in name:
                 return "k_vara_i8_finish"
+            if "k_vara_i8p" in name and ("Lb0ELb1E" in name or "<false, true>" in name):
+                return "k_vara_i8p<ext>"   # the launch of eagle_dev_vara_i8_extend (dropped on the device when nobody qualifies)
             if "k_vara_f64_sum" in name:
                 return "k_vara_f64_sum"
             if "k_vara_f64d" in name:   # round 3's fp64 vara kernel (k_vara_f64 = round 2's, tune 28)
