@@ -739,7 +739,10 @@ def main():
         sh.ws = None
         s7, el7, p7 = run.timed(1, 1)
         secondary["scan_7_digits"] = {"value": Ltot / el7, "unit": "markers/s", "ms_per_step": el7 * 1e3,
-                                      "selected_marker_equal": bool(s7[0] == sel_i8[0]), "roofline": vara_roofline(sh, p7["kern"], 7)}
+                                      "selected_marker_equal": bool(s7[0] == sel_i8[0]), "roofline": vara_roofline(sh, p7["kern"], 7),
+                                      "note": "all 53 bits of W's largest entry in exact integer arithmetic (eagle_set_scan_slices(7)): per-marker "
+                                              "bound l1_i^2/2 * 2^(e-55), below the rounding of ANY fp64 summation order of the same form -- the "
+                                              "fp64-accuracy figure on the int8 matrix cores, beside scan_fp64_mode on the fp64 ones"}
         sh.nslices = args.slices
         sh.ws = None
         # opt-in stochastic rounding of W's digits (eagle_set_scan_rounding): probabilistic certificate, one digit fewer
