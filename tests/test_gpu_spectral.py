@@ -327,3 +327,29 @@ def test_extension_is_a_per_marker_decision_resident_and_streamed(tmp_path, monk
     finally:
         monkeypatch.delenv("EAGLE_HIP_MAX_RESIDENT_GB", raising=False)
         api.drop_cache()
+
+
+def test_extension_over_two_contexts_sharing_one_card(tmp_path):
+    """The shards of a multi-device context (one card named twice): every device takes the same digit decision from W alone and gives
+    the same markers the dropped digit back -- the bits of the single-device call."""
+    from eagleeverything_amd import rcpp_api as api, synth
+    n, L = 2048, 3072
+    Mt8, odd, S, V, ahat = _panel(n, L, QUIET_RESCUED)
+    geno = synth.write_geno_pair(str(tmp_path), Mt8)
+    try:
+        api.set_scan_mode(1)
+        api.set_scan_budget(5e-7)
+        r1 = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], np.nan, S, V, 8.0, (L, n), ahat)
+        d1, b1 = api.last_scan_digits(), api.last_scan_argmax()[:2]
+        api.drop_cache()
+        api.set_scan_mode(1, device=(0, 0))
+        api.set_scan_budget(5e-7, device=(0, 0))
+        r2 = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], np.nan, S, V, 8.0, (L, n), ahat, device=(0, 0))
+        np.testing.assert_array_equal(r2["vara"], r1["vara"])
+        np.testing.assert_array_equal(r2["a"], r1["a"])
+        assert api.last_scan_digits(device=(0, 0)) == d1 and d1[0] == d1[1] - 1
+        assert api.last_scan_argmax(device=(0, 0))[:2] == b1
+        assert not api.last_scan_certificate(device=(0, 0))[2]
+    finally:
+        api.drop_cache()
+        api.drop_cache(device=(0, 0))
