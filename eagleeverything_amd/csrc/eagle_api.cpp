@@ -26,6 +26,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <string>
 #include <thread>
 #include <vector>
@@ -141,8 +142,26 @@ struct RcclState {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;   // optional: a library without it keeps the old behaviour
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::mutex abort_mutex;
+    std::atomic<bool> dead{false};   // the communicators were aborted: every later call takes the host-staged exchange
 };
+// A device whose collective could not be enqueued AFTER the rendezvous that precedes it would leave its peers blocked inside
+// theirs: abort every communicator (the peers' collectives end with an error, their calls return it) and retire the RCCL leg of
+// this context.  Once, whoever comes first.
+static void rccl_abort_all(RcclState* r) {
+    std::lock_guard<std::mutex> lock(r->abort_mutex);
+    if (r->dead.exchange(true)) return;
+    for (ncclComm_t& c : r->comms)
+        if (c) { if (r->CommAbort) (void)r->CommAbort(c); c = nullptr; }
+}
+// EAGLE_HIP_FAULT=reduce | allgather: the named collective of the next call reports a failure instead of running (tests of the
+// abort path on a one-GPU box; never set in production)
+static bool rccl_fault(const char* which) {
+    const char* f = getenv("EAGLE_HIP_FAULT");
+    return f && strcmp(f, which) == 0;
+}
 static RcclState* rccl_open(const int* devices, int ndev, char* err, size_t errlen) {
     RcclState* r = new RcclState();
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
@@ -153,6 +172,7 @@ static RcclState* rccl_open(const int* devices, int ndev, char* err, size_t errl
     r->Reduce = (decltype(r->Reduce))dlsym(r->lib, "ncclReduce");
     r->AllGather = (decltype(r->AllGather))dlsym(r->lib, "ncclAllGather");
     r->GetErrorString = (decltype(r->GetErrorString))dlsym(r->lib, "ncclGetErrorString");
+    r->CommAbort = (decltype(r->CommAbort))dlsym(r->lib, "ncclCommAbort");
     if (!r->CommInitAll || !r->CommDestroy || !r->Reduce || !r->AllGather || !r->GetErrorString) {
         snprintf(err, errlen, "librccl lacks an entry point");
         dlclose(r->lib); delete r; return nullptr;
@@ -1001,6 +1021,7 @@ extern "C" int eagle_calculateMMt(eagle_ctx* ctx, const char* f_name_ascii, doub
     split_markers(L, nd, edge);
     const long packed = eagle_upper_tiles_count(np);
     RcclState* rccl = (RcclState*)ctx->rccl;
+    if (rccl && rccl->dead) rccl = nullptr;   // aborted in an earlier call: host-staged sums from now on
     Rendezvous rv;
     rv.n = nd;
     rc = run_on_devices(ctx, [&](int k, eagle_ctx* c) -> int {
@@ -1014,8 +1035,9 @@ extern "C" int eagle_calculateMMt(eagle_ctx* ctx, const char* f_name_ascii, doub
         if (!r && (e = hipStreamSynchronize(c->stream)) != hipSuccess) r = eagle_fail_hip(c, e, "MM^T partial");
         if (!rv.arrive(r == 0)) return r ? r : eagle_fail(c, EAGLE_ERR_HIP, "another device failed before the MM^T sum");
         if (rccl) {
-            ncclResult_t nr = rccl->Reduce(c->d_pack, c->d_pack, (size_t)packed, ncclInt32, ncclSum, 0, rccl->comms[k], c->stream);
-            if (nr != ncclSuccess) r = failf(c, EAGLE_ERR_HIP, "ncclReduce: %s", rccl->GetErrorString(nr));
+            ncclResult_t nr = rccl_fault("reduce") ? ncclSystemError
+                                                   : rccl->Reduce(c->d_pack, c->d_pack, (size_t)packed, ncclInt32, ncclSum, 0, rccl->comms[k], c->stream);
+            if (nr != ncclSuccess) { r = failf(c, EAGLE_ERR_HIP, "ncclReduce: %s", rccl->GetErrorString(nr)); rccl_abort_all(rccl); }
             else if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) r = eagle_fail_hip(c, e, "ncclReduce sync");
         } else if (k == 0) {  // host-staged stand-in: the peers' packed tiles are copied to the lead and added, one by one
             r = ensure_buf(c, &c->d_pack2, &c->pack2_cap, sizeof(int32_t) * (size_t)packed, "packed MM^T landing buffer");
@@ -1194,8 +1216,9 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
         if (!rc) rc = eagle_dev_scan_operands_rows(ctx, Sa, Va, ah, n, np, r0, r0 + rows, v, Wu, tmp, ctx->stream);
         if (!rc && (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) rc = eagle_fail_hip(ctx, e, "rows of W");
         EAGLE_ARRIVE(0.0);
-        ncclResult_t nr = rccl->AllGather(Wu + r0 * np, Wu, (size_t)(rows * np), ncclDouble, rccl->comms[k], ctx->stream);
-        if (nr != ncclSuccess) rc = failf(ctx, EAGLE_ERR_HIP, "ncclAllGather: %s", rccl->GetErrorString(nr));
+        ncclResult_t nr = rccl_fault("allgather") ? ncclSystemError
+                                                  : rccl->AllGather(Wu + r0 * np, Wu, (size_t)(rows * np), ncclDouble, rccl->comms[k], ctx->stream);
+        if (nr != ncclSuccess) { rc = failf(ctx, EAGLE_ERR_HIP, "ncclAllGather: %s", rccl->GetErrorString(nr)); rccl_abort_all(rccl); }
         if (!rc) rc = eagle_dev_fold_upper(ctx, Wu, np, ctx->stream);
     } else if (!rc) {
         if (w_direct) rc = eagle_dev_fold_upper(ctx, Wu, np, ctx->stream);
@@ -1453,6 +1476,7 @@ extern "C" int eagle_calculate_a_and_vara(eagle_ctx* ctx, const char* f_name_asc
     Rendezvous rv;
     rv.n = nd;
     RcclState* rccl = (RcclState*)ctx->rccl;
+    if (rccl && rccl->dead) rccl = nullptr;   // aborted in an earlier call: W on every device, host-staged exchange
     const double t_call = now_s();
     rc = run_on_devices(ctx, [&](int k, eagle_ctx* c) -> int {
         return scan_range(c, f_name_ascii, L, n, edge[k], edge[k + 1], sel, inv_MMt_sqrt, dim_reduced_vara, a, max_memory_in_Gbytes, quiet,

@@ -190,3 +190,39 @@ def test_exchange_steps_on_an_rccl_communicator_of_one(api, oracle, tmp_path, mo
         else:
             np.testing.assert_array_equal(one[key], forced[key], err_msg=key)
     api.drop_cache(device=(0,))
+
+
+def test_a_collective_that_cannot_be_enqueued_aborts_the_communicators_instead_of_hanging(api, tmp_path, monkeypatch):
+    """a device that fails at the enqueue of a collective, after the rendezvous that precedes it, must not leave its peers
+    blocked inside theirs.  EAGLE_HIP_FAULT makes the named collective report a failure (a communicator of ONE rank is what this box
+    has): the call returns the error, the communicators are aborted, and the context carries on with the host-staged exchange."""
+    from eagleeverything_amd._lib import EagleError
+    n, L = 300, 1200
+    rng = np.random.default_rng(8)
+    Mt8 = synth.genotypes_marker_major(n, L, seed=29)
+    A = rng.standard_normal((n, 20)) / 6.0
+    S = np.eye(n) + A @ A.T
+    V = 0.7 * np.eye(n) - 0.03 * (A[:, :3] @ A[:, :3].T)
+    ahat = rng.standard_normal(n)
+    geno = synth.write_geno_pair(str(tmp_path), Mt8)
+    G = Mt8.astype(np.float64)
+    monkeypatch.setenv("EAGLE_HIP_COLLECTIVES", "rccl")
+    dev = (0,)
+    ok = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat, device=dev)   # RCCL leg alive (or already retired)
+    monkeypatch.setenv("EAGLE_HIP_FAULT", "allgather")
+    try:
+        api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat, device=dev)
+        raised = False
+    except EagleError as e:
+        raised = "ncclAllGather" in str(e)
+    monkeypatch.delenv("EAGLE_HIP_FAULT")
+    # either the fault fired (RCCL leg was alive) or an earlier test of this module had retired it already: both leave a working context
+    again = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat, device=dev)
+    np.testing.assert_array_equal(again["a"], ok["a"])
+    np.testing.assert_allclose(again["vara"], ok["vara"], rtol=1e-10)
+    monkeypatch.setenv("EAGLE_HIP_FAULT", "reduce")
+    mmt = api.calculateMMt_rcpp(geno["asciifileM"], 8.0, 4, NA, (n, L), device=dev)     # the RCCL leg is retired: no collective is issued
+    monkeypatch.delenv("EAGLE_HIP_FAULT")
+    np.testing.assert_array_equal(mmt, G.T @ G)
+    assert raised
+    api.drop_cache(device=dev)
