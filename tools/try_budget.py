@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""GPU: the digit rule at budgets 5e-7 / 2e-7 / 1e-7 on the bench's operands (headline and C2): digits used / cut, level of the spectral
+bound that took the digit off, step and phase times, certificate."""
 import os, sys
 sys.path.insert(0, "/root/repo")
 import torch, bench
