@@ -109,6 +109,11 @@ extern "C" eagle_ctx* eagle_open(int device) {
     // EAGLE_HIP_TUNE=9: the compiler-scheduled forms of the two hand-scheduled kernels (k_vara_i8w, k_syrk_f4) for a whole session:
     // same results bit for bit, 3-8 % slower; a switch for ruling the inline-asm kernels out when chasing a problem
     if (const char* tv = getenv("EAGLE_HIP_TUNE")) ctx->tune = atoi(tv);
+    // EAGLE_HIP_SCAN_BUDGET=1e-7: the digit budget of the int8 scan for an R session that has no call for it (eagle_set_scan_budget)
+    if (const char* bv = getenv("EAGLE_HIP_SCAN_BUDGET")) {
+        const double b = atof(bv);
+        if (b >= 1e-12 && b <= 5e-7) ctx->scan_budget = b;
+    }
     // the loader stream outranks the compute stream: its decode / unpack / fill kernels are microseconds of work that must get
     // onto CUs the scan kernel's long-lived workgroups fill completely (2 waves x 256 VGPRs per SIMD), as soon as one retires
     int prio_least = 0, prio_greatest = 0;
