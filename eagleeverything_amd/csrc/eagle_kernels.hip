@@ -1064,15 +1064,19 @@ __global__ __launch_bounds__(256, 2) void k_vara_f64d(const int8_t* __restrict__
                                                       double* __restrict__ partial) {
     __shared__ __attribute__((aligned(1024))) char lds[2][V2_STAGE];
     __shared__ double Psum[2][GF_T];  // the running row-dots P_wc(row) of the non-SPLIT form (in LDS: 32 VGPRs the K loop needs)
+    // SPLIT: grid (column tile, K chunk, row block) -- the row block is the SLOWEST index: workgroup ids go round the XCDs, and with the
+    // row block fastest the few blocks that hold candidates (normally the first of 16) had all their workgroups on one XCD (1.16 ms for
+    // one 128-row block; rocprofv3, round 3)
+    const int rb = SPLIT ? (int)blockIdx.z : (int)blockIdx.x;
     if (gate) {
         if (!SPLIT && *gate == 0) return;
-        if (SPLIT && (long)blockIdx.x * GF_T >= (long)*gate) return;
+        if (SPLIT && (long)rb * GF_T >= (long)*gate) return;
     }
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = w >> 1, wc = w & 1;
     const int i16 = lane & 15, g = lane >> 4;
-    const long row0 = (long)blockIdx.x * GF_T;
+    const long row0 = (long)rb * GF_T;
     const int8_t* Ablk = A8 + row0 * lda;
     int mlim = 4;  // SPLIT with a row count: 16-row tiles entirely beyond the count are not computed (wave-uniform)
     if (SPLIT && gate) {
@@ -1102,13 +1106,13 @@ __global__ __launch_bounds__(256, 2) void k_vara_f64d(const int8_t* __restrict__
         pB[1][n] = lds[1] + offB + blk;
     }
     if (!SPLIT) { Psum[t >> 7][t & 127] = 0.0; }   // (made visible by the barriers of the first chunk)
-    const int ct0 = SPLIT ? (int)blockIdx.y : 0;
-    const int ct1 = SPLIT ? (int)blockIdx.y + 1 : n_coltiles;
+    const int ct0 = SPLIT ? (int)blockIdx.x : 0;
+    const int ct1 = SPLIT ? (int)blockIdx.x + 1 : n_coltiles;
     for (int ct = ct0; ct < ct1; ct++) {
         const double* Bblk = B + (long)ct * GF_T;
         const long kend = (long)(ct + 1) * GF_T < K ? (long)(ct + 1) * GF_T : K;
-        const int c0 = SPLIT ? (int)blockIdx.z : 0;
-        const int c1 = SPLIT ? (int)blockIdx.z + 1 : nchunk_max;
+        const int c0 = SPLIT ? (int)blockIdx.y : 0;
+        const int c1 = SPLIT ? (int)blockIdx.y + 1 : nchunk_max;
         for (int c = c0; c < c1; c++) {
             const long kc0 = (long)c * GF_KC;
             if (kc0 >= kend) break;
@@ -1225,7 +1229,7 @@ __global__ __launch_bounds__(256, 2) void k_vara_f64d(const int8_t* __restrict__
                     sdot += __shfl_xor(sdot, 8);
                     if (SPLIT) {
                         if (i16 == 0)
-                            partial[((((long)blockIdx.x * n_coltiles + ct) * nchunk_max + c) * 2 + wc) * GF_T + wr * 64 + m * 16 + g + 4 * q] = sdot;
+                            partial[((((long)rb * n_coltiles + ct) * nchunk_max + c) * 2 + wc) * GF_T + wr * 64 + m * 16 + g + 4 * q] = sdot;
                     } else if (i16 == 0) {
                         Psum[wc][wr * 64 + m * 16 + g + 4 * q] += sdot;   // this lane alone owns the element: same chain as a register
                     }
@@ -1762,8 +1766,8 @@ extern "C" int eagle_dev_vara_f64_split(eagle_ctx* ctx, const int8_t* rows8, lon
         hipLaunchKernelGGL((k_vara_f64<true>), grid, dim3(256), 0, (hipStream_t)stream, rows8, ld, Wu, n_pad, (double*)nullptr, nct, n_pad, count_dev,
                            partial);
     else
-        hipLaunchKernelGGL((k_vara_f64d<true>), grid, dim3(256), 0, (hipStream_t)stream, rows8, ld, Wu, n_pad, (double*)nullptr, nct, n_pad, count_dev,
-                           partial);
+        hipLaunchKernelGGL((k_vara_f64d<true>), dim3(grid.y, grid.z, grid.x), dim3(256), 0, (hipStream_t)stream, rows8, ld, Wu, n_pad, (double*)nullptr, nct,
+                           n_pad, count_dev, partial);
     hipLaunchKernelGGL(k_vara_f64_sum, dim3((unsigned)(rows_cap / GF_T)), dim3(GF_T), 0, (hipStream_t)stream, partial, nct, n_pad, count_dev, dst_dev, out);
     LAUNCH_CHECK(ctx);
     return EAGLE_OK;
