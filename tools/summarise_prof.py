@@ -7,9 +7,9 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
-OURS = ("k_vara_i8p", "k_vara_i8w", "k_syrk_f4w", "k_syrk_f4p", "k_vara_i8", "k_vara_f64", "k_cert_lb", "k_cert_select", "k_cert_gather", "k_tiles_pack", "k_syrk_f4", "k_pack_fp4", "k_marker_shift", "k_rho_rows", "k_rho_cols", "k_rho_final", "k_syrk_i8", "k_gemm_f64", "k_gemv_mfma", "k_slice_vec", "k_sym_check", "k_vara_prep", "k_absmax_offdiag", "k_slice_w", "k_fold_upper", "k_colgemv", "k_tsq", "k_absmax",
+OURS = ("k_vara_i8p", "k_vara_i8w", "k_syrk_f4w", "k_syrk_f4p", "k_vara_i8", "k_vara_f64", "k_cert_lb", "k_cert_select", "k_cert_gather", "k_tiles_pack", "k_syrk_f4", "k_pack_fp4", "k_marker_shift", "k_rho_rows", "k_rho_colsum", "k_rho_cols", "k_rho_final", "k_syrk_i8", "k_gemm_f64", "k_gemv_mfma", "k_slice_vec", "k_sym_check", "k_vara_prep", "k_absmax_offdiag", "k_slice_w", "k_fold_upper", "k_colgemv", "k_tsq", "k_absmax",
         "k_transpose_pack_fp4", "k_transpose_i8", "k_spectral_scan", "k_spectral_finish", "k_zbuild_i8", "k_zbuild", "k_slice_u", "k_cert_bounds", "k_cert_lb_b", "k_cert_select_b", "k_mmt_finish", "k_mmt_normalise", "k_decode_ascii", "k_vara_i8_finish",
-        "k_gram_rowabs_i8", "k_gram_hi_i8", "k_last_digit_sym", "k_spectral_decide", "k_rho_colsum", "k_ext_select", "k_ext_head", "k_ext_copy_slice", "k_ext_gather", "k_ext_apply")
+        "k_gram_rowabs_i8", "k_gram_hi_i8", "k_last_digit_sym", "k_spectral_decide", "k_ext_select", "k_ext_head", "k_ext_copy_slice", "k_ext_gather", "k_ext_apply")
 
 
 def find(pattern):
