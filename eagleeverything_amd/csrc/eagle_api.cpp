@@ -298,6 +298,7 @@ extern "C" void eagle_close(eagle_ctx* ctx) {
     if (ctx->d_pack) (void)hipFree(ctx->d_pack);
     if (ctx->d_pack2) (void)hipFree(ctx->d_pack2);
     for (int b = 0; b < 2; b++) { if (ctx->stage_pin[b]) (void)hipHostFree(ctx->stage_pin[b]); if (ctx->stage_raw[b]) (void)hipFree(ctx->stage_raw[b]); }
+    if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
     (void)hipStreamDestroy(ctx->stream);
     if (ctx->load_stream) (void)hipStreamDestroy(ctx->load_stream);
     delete ctx;
@@ -1107,7 +1108,9 @@ static int ensure_scan_out(eagle_ctx* ctx, long L_pad) {
 // (NULL for one device).  Every device passes the same rendezvous in the same order, failed or not.
 static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, long m0, long m1, const std::vector<long>& sel,
                       const double* inv_MMt_sqrt, const double* dim_reduced_vara, const double* a, double max_memory_in_Gbytes, int quiet,
-                      double* a_out, double* vara_out, int k, int nd, Rendezvous* rv, RcclState* rccl, bool w_direct = false) {
+                      double* a_out, double* vara_out, int k, int nd, Rendezvous* rv, RcclState* rccl, bool w_direct = false, bool s_trusted = false) {
+    // s_trusted: the device copy of S was uploaded from this very caller matrix a moment ago (the re-run after a deferred
+    // verification found another S): no verification this time
     // w_direct (eagle_scan_with_W): inv_MMt_sqrt is not S but W itself, `a` is v = S a_hat; dim_reduced_vara is unused
     const long Lr = m1 - m0;
     const long np = eagle_pad(n), Lp = eagle_pad(Lr > 0 ? Lr : 1);
@@ -1145,6 +1148,7 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
     const double t0 = now_s();
     double *Sa = nullptr, *Va = nullptr, *tmp = nullptr, *Wu = nullptr, *ah = nullptr, *v = nullptr;
     bool s_from_cache = false;  // the product runs on the device copy of the last call's S; the caller's S is verified under it
+    bool s_check_pending = false;  // ... and the outcome of that verification has not been collected yet
     void *ws = nullptr, *cert = nullptr;
     long* cert_totals = (long*)((char*)ctx->d_scratch + EAGLE_SCR_CERT_TOTALS);  // {re-evaluated, flagged, fell back}, summed over marker blocks
     ChunkRing ring;
@@ -1197,8 +1201,8 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
                 else { if (ctx->d_Scache) (void)hipFree(ctx->d_Scache); ctx->d_Scache = nullptr; (void)hipGetLastError(); }
             }
             if (cacheable && ctx->scache_np == np) {
-                s_from_cache = ctx->scache_n == n;
-                if (!s_from_cache && (r = upload_square(ctx, inv_MMt_sqrt, n, np, ctx->d_Scache))) return r;
+                s_from_cache = ctx->scache_n == n && !s_trusted;
+                if (!s_from_cache && !s_trusted && (r = upload_square(ctx, inv_MMt_sqrt, n, np, ctx->d_Scache))) return r;
                 ctx->scache_n = n;
                 Sa = ctx->d_Scache;
             } else if ((r = upload_square(ctx, inv_MMt_sqrt, n, np, Sa))) return r;
@@ -1254,25 +1258,37 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
             for (hipEvent_t ev : landed) (void)hipEventDestroy(ev);
         }
         if (!rc && s_from_cache) {
-            // under the product: the caller's S to the scratch copy (loader stream), compared with the cached one
+            // under the product: the caller's S to the scratch copy (loader stream), compared with the cached one.  One resident block
+            // on one device: nothing below needs the host before the results go back, so the answer is collected only then (S's 800 MB
+            // at n = 10,000 then hide under the whole scan, not under W alone: on a host whose pageable copies run at 25 GB/s the
+            // two uploads of a call took 64 ms against W's 47); otherwise (marker blocks, several devices: the host is in the loop
+            // anyway) right here.
             int* flag = (int*)((char*)ctx->d_scratch + EAGLE_SCR_SCACHE_FLAG);
-            int differ = 0;
-            e = hipMemsetAsync(flag, 0, sizeof(int), ctx->load_stream);
-            if (e == hipSuccess) rc = upload_square_on(ctx, inv_MMt_sqrt, n, np, ctx->d_Sscr, ctx->load_stream);
-            if (e == hipSuccess && !rc) {
-                hipLaunchKernelGGL(k_bits_differ, dim3(1024), dim3(256), 0, ctx->load_stream, (const unsigned long long*)ctx->d_Sscr,
-                                   (const unsigned long long*)ctx->d_Scache, np * np, flag);
-                e = hipMemcpyAsync(&differ, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->load_stream);
-                if (e == hipSuccess) e = hipStreamSynchronize(ctx->load_stream);
+            if (!ctx->h_flag && (e = hipHostMalloc((void**)&ctx->h_flag, 64, hipHostMallocDefault)) != hipSuccess) rc = eagle_fail_hip(ctx, e, "pinned flag");
+            if (!rc) {
+                *ctx->h_flag = 0;
+                e = hipMemsetAsync(flag, 0, sizeof(int), ctx->load_stream);
+                if (e == hipSuccess) rc = upload_square_on(ctx, inv_MMt_sqrt, n, np, ctx->d_Sscr, ctx->load_stream);
+                if (e == hipSuccess && !rc) {
+                    hipLaunchKernelGGL(k_bits_differ, dim3(1024), dim3(256), 0, ctx->load_stream, (const unsigned long long*)ctx->d_Sscr,
+                                       (const unsigned long long*)ctx->d_Scache, np * np, flag);
+                    e = hipMemcpyAsync(ctx->h_flag, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->load_stream);
+                }
+                if (e != hipSuccess && !rc) rc = eagle_fail_hip(ctx, e, "verification of the cached S");
+                s_check_pending = true;
             }
-            if (e != hipSuccess && !rc) rc = eagle_fail_hip(ctx, e, "verification of the cached S");
-            if (!rc && differ) {  // another S: it is already on the device -- start the product over with it
-                if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) rc = eagle_fail_hip(ctx, e, "scan operands");
-                std::swap(ctx->d_Scache, ctx->d_Sscr);
-                Sa = ctx->d_Scache;
-                if (!rc) rc = eagle_dev_scan_operands(ctx, Sa, Va, ah, n, np, v, Wu, tmp, ctx->stream);
-                ctx->scache_misses++;
-            } else if (!rc) ctx->scache_hits++;
+            if (s_check_pending && (streamed || bounds_flow || rc)) {
+                s_check_pending = false;
+                e = hipStreamSynchronize(ctx->load_stream);
+                if (e != hipSuccess && !rc) rc = eagle_fail_hip(ctx, e, "verification of the cached S");
+                if (!rc && *ctx->h_flag) {  // another S: it is already on the device -- start the product over with it
+                    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) rc = eagle_fail_hip(ctx, e, "scan operands");
+                    std::swap(ctx->d_Scache, ctx->d_Sscr);
+                    Sa = ctx->d_Scache;
+                    if (!rc) rc = eagle_dev_scan_operands(ctx, Sa, Va, ah, n, np, v, Wu, tmp, ctx->stream);
+                    ctx->scache_misses++;
+                } else if (!rc) ctx->scache_hits++;
+            }
         }
     }
     if (!rc) ph.mark(ctx->stream, PH_W);
@@ -1410,6 +1426,19 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
         }
     }
 #undef EAGLE_ARRIVE
+    if (s_check_pending) {   // the deferred outcome of the verification of the cached S (nothing of the caller's S may be in flight past here)
+        e = hipStreamSynchronize(ctx->load_stream);
+        if (e != hipSuccess && !rc) rc = eagle_fail_hip(ctx, e, "verification of the cached S");
+        if (!rc && *ctx->h_flag) {
+            // another S than the cached one: this scan ran on the wrong operand.  The caller's S is on the device already (the scratch
+            // copy): it becomes the cached one and the scan starts over, once, without another verification.
+            if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return eagle_fail_hip(ctx, e, "scan on a stale S");
+            std::swap(ctx->d_Scache, ctx->d_Sscr);
+            ctx->scache_misses++;
+            return scan_range(ctx, f_name_ascii, L, n, m0, m1, sel, inv_MMt_sqrt, dim_reduced_vara, a, max_memory_in_Gbytes, quiet, a_out, vara_out, k, nd,
+                              rv, rccl, w_direct, true);
+        } else if (!rc) ctx->scache_hits++;
+    }
     if (timing_on() && !rc) {
         (void)hipStreamSynchronize(ctx->stream);
         fprintf(stderr, "[eaglehip] scan n=%ld markers [%ld, %ld) of %ld on device %d%s: alloc+upload %.1f ms, device compute %.1f ms\n", n, m0, m1, L,

@@ -76,6 +76,7 @@ struct eagle_ctx {
     void* f4_buf = nullptr; size_t f4_cap = 0;  // fp4 image of the tile eagle_dev_mmt_accumulate is working on
     void* gemm_scratch = nullptr; size_t gemm_scratch_cap = 0;  // split-K partial tiles of the fp64 GEMM's last wave
     void* gemv_ws = nullptr;  // 16 digit-slice rows of the GEMV vectors + their exponents (k_gemv_mfma)
+    int* h_flag = nullptr;   // 64 pinned bytes: where an asynchronous device-to-host copy of a flag lands (the deferred verification of the cached S)
     void* stage_pin[2] = {nullptr, nullptr}; void* stage_raw[2] = {nullptr, nullptr}; size_t stage_cap = 0;  // tile streamer
     // per-device launch state (a process may hold one ctx per GPU): dynamic-LDS attributes set on this device, schedule
     // experiment switch of tools/bench_i8_engine.py (0 = shipped)
