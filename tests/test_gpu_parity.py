@@ -971,3 +971,20 @@ def test_cached_S_is_verified_and_never_changes_a_result(api, tmp_path, monkeypa
         np.testing.assert_array_equal(got["vara"], ref[key]["vara"])
     assert not np.array_equal(again["a"], other["a"])     # the changed entry does reach the result
     api.drop_cache()
+
+
+def test_mmt_of_many_individuals_comes_back_through_the_staged_download(api, tmp_path):
+    """n = 6,000: the 288 MB result returns through the two pinned staging buffers in 64 MiB pieces (csrc/eagle_api.cpp, download_big),
+    a path the smaller shapes above never take; the normalised form too.  Exact against the integer product."""
+    n, L = 6000, 192
+    rng = np.random.default_rng(41)
+    Mt8 = (rng.binomial(2, rng.uniform(0.1, 0.5, size=L)[:, None], size=(L, n)) - 1).astype(np.int8)
+    geno = synth.write_geno_pair(str(tmp_path), Mt8)
+    G = Mt8.astype(np.float64)
+    want = G.T @ G
+    got = api.calculateMMt_rcpp(geno["asciifileM"], 8.0, 4, NA, (n, L))
+    np.testing.assert_array_equal(got, want)
+    norm, mx = api.last_mmt_normalised(n)
+    assert mx == want.max()
+    np.testing.assert_allclose(norm, want / mx + 0.95 * np.eye(n), rtol=1e-15, atol=1e-15)
+    api.drop_cache()
