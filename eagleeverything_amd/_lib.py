@@ -34,6 +34,8 @@ SIGNATURES = {
     "eagle_set_scan_slices": (C.c_int, [C.c_void_p, C.c_int]),
     "eagle_set_scan_rounding": (C.c_int, [C.c_void_p, C.c_int]),
     "eagle_set_scan_budget": (C.c_int, [C.c_void_p, C.c_double]),
+    "eagle_set_w_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "eagle_last_w_info": (C.c_int, [C.c_void_p, C.c_void_p]),
     "eagle_last_scan_digits": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "eagle_get_row_column": (C.c_int, [C.c_void_p, C.c_char_p, c_lp]),
     "eagle_create_M_ascii": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,

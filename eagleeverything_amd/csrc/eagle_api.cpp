@@ -109,6 +109,10 @@ extern "C" eagle_ctx* eagle_open(int device) {
     // EAGLE_HIP_TUNE=9: the compiler-scheduled forms of the two hand-scheduled kernels (k_vara_i8w, k_syrk_f4) for a whole session:
     // same results bit for bit, 3-8 % slower; a switch for ruling the inline-asm kernels out when chasing a problem
     if (const char* tv = getenv("EAGLE_HIP_TUNE")) ctx->tune = atoi(tv);
+    if (const char* wm = getenv("EAGLE_HIP_W_MODE")) {   // 0 / 1 / 2: eagle_set_w_mode for an R session that has no call for it
+        const int m = atoi(wm);
+        if (m >= 0 && m <= 2) ctx->w_mode = m;
+    }
     // EAGLE_HIP_SCAN_BUDGET=1e-7: the digit budget of the int8 scan for an R session that has no call for it (eagle_set_scan_budget)
     if (const char* bv = getenv("EAGLE_HIP_SCAN_BUDGET")) {
         const double b = atof(bv);
@@ -294,6 +298,9 @@ extern "C" void eagle_close(eagle_ctx* ctx) {
     if (ctx->gemv_ws) (void)hipFree(ctx->gemv_ws);
     if (ctx->f4_buf) (void)hipFree(ctx->f4_buf);
     if (ctx->gemm_scratch) (void)hipFree(ctx->gemm_scratch);
+    if (ctx->w8_ws) (void)hipFree(ctx->w8_ws);
+    if (ctx->w8_true_ws) (void)hipFree(ctx->w8_true_ws);
+    if (ctx->w8_host) (void)hipHostFree(ctx->w8_host);
     if (ctx->d_c32) (void)hipFree(ctx->d_c32);
     if (ctx->d_pack) (void)hipFree(ctx->d_pack);
     if (ctx->d_pack2) (void)hipFree(ctx->d_pack2);
@@ -1255,6 +1262,7 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
     if (timing_on() && !rc) { (void)hipStreamSynchronize(ctx->stream); t1 = now_s(); }
     // W = S (V S) and v = S a_hat.  Several devices: each computes 1/nd of the rows of W's image and ONE all-gather completes
     // it everywhere (the n^3 part would otherwise not scale); without device collectives every device computes all of it.
+    if (share_w || w_direct) { ctx->w8_active = false; ctx->w8_info = W8Info(); ctx->w8_info.declined = 7; }
     if (share_w) {
         const long rows = np / nd, r0 = k * rows;
         if (!rc) rc = eagle_dev_scan_operands_rows(ctx, Sa, Va, ah, n, np, r0, r0 + rows, v, Wu, tmp, ctx->stream);
@@ -1270,6 +1278,24 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
             // v = S a_hat at once; then V in blocks of 1024 rows of its image: copy on the loader stream, event, the rows X = V S of
             // that block on the compute stream.  PCIe (57 GB/s) delivers a block in half the time its product takes, so all of
             // V's upload but the first block hides under the first n^3 product.
+            if (eagle_w8_wanted(ctx, np)) {
+                // W on the int8 engine (csrc/eagle_w8.hip): its configuration is chosen from statistics of ALL of V, so V is uploaded
+                // whole (loader stream; S's statistics and slices do not wait for it) and the products follow; a call that declines
+                // runs the fp64 products on the resident operands
+                if ((e = hipMemsetAsync(Va, 0, sq, ctx->load_stream)) != hipSuccess) rc = eagle_fail_hip(ctx, e, "V memset");
+                if (!rc && (e = hipMemcpy2DAsync(Va, sizeof(double) * np, dim_reduced_vara, sizeof(double) * n, sizeof(double) * n, (size_t)n,
+                                                 hipMemcpyHostToDevice, ctx->load_stream)) != hipSuccess) rc = eagle_fail_hip(ctx, e, "upload of V");
+                hipEvent_t ev = nullptr;
+                if (!rc && (e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) rc = eagle_fail_hip(ctx, e, "hipEventCreate");
+                if (!rc && ((e = hipEventRecord(ev, ctx->load_stream)) != hipSuccess || (e = hipStreamWaitEvent(ctx->stream, ev, 0)) != hipSuccess))
+                    rc = eagle_fail_hip(ctx, e, "V upload event");
+                if (!rc) rc = eagle_dev_scan_operands(ctx, Sa, Va, ah, n, np, v, Wu, tmp, ctx->stream);
+                if (rc) (void)hipStreamSynchronize(ctx->load_stream);
+                if (ev) (void)hipEventDestroy(ev);
+            } else {
+            ctx->w8_active = false;
+            ctx->w8_info = W8Info();
+            ctx->w8_info.declined = 7;
             rc = eagle_dev_scan_operands_begin(ctx, Sa, ah, n, np, v, tmp, ctx->stream);
             if (!rc && (e = hipMemsetAsync(Va, 0, sq, ctx->load_stream)) != hipSuccess) rc = eagle_fail_hip(ctx, e, "V memset");
             std::vector<hipEvent_t> landed;
@@ -1291,6 +1317,7 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
             if (!rc) rc = eagle_dev_scan_operands_finish(ctx, Sa, Va, np, Wu, tmp, ctx->stream);
             if (rc) (void)hipStreamSynchronize(ctx->load_stream);  // nothing of the caller's V may still be in flight when we return
             for (hipEvent_t ev : landed) (void)hipEventDestroy(ev);
+            }
         }
         if (!rc && s_from_cache) {
             // under the product: the caller's S to the scratch copy (loader stream), compared with the cached one.  One resident block
@@ -1423,7 +1450,10 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
             }
             if (!rc && hd.overflow) {
                 // more candidates than the re-evaluation buffer holds (degenerate operands): all of the shard in fp64
-                if (!streamed) {
+                // (on the fp64 products, should W have come from the int8 engine)
+                rc = eagle_w8_redo_f64(ctx, np, ctx->stream);
+                if (rc) {
+                } else if (!streamed) {
                     rc = eagle_dev_vara_f64(ctx, g->dev, Lp, np, g->ld, Wu, ctx->d_vara, ctx->stream);
                 } else {
                     ChunkRing again;
@@ -1638,6 +1668,22 @@ extern "C" int eagle_last_scan_certificate(eagle_ctx* ctx, long* n_reevaluated, 
     return EAGLE_OK;
 }
 
+extern "C" int eagle_set_w_mode(eagle_ctx* ctx, int mode) {
+    if (!ctx || mode < 0 || mode > 2) return EAGLE_ERR_ARG;
+    ctx->w_mode = mode;
+    for (eagle_ctx* p : ctx->peers) p->w_mode = mode;
+    return EAGLE_OK;
+}
+extern "C" int eagle_last_w_info(eagle_ctx* ctx, eagle_w_info* out) {
+    if (!ctx || !out) return EAGLE_ERR_ARG;
+    const W8Info& i = ctx->w8_info;
+    out->int8 = ctx->w8_active ? 1 : 0;
+    out->declined = i.declined;
+    out->k1 = i.k1; out->T1 = i.T1; out->pairs1 = i.pairs1;
+    out->k2 = i.k2; out->T2 = i.T2; out->pairs2 = i.pairs2;
+    out->eta = i.eta; out->eta_x = i.eta_x; out->target = i.target; out->mean_diag = i.mean_diag; out->asym_term = i.asym_term;
+    return EAGLE_OK;
+}
 extern "C" int eagle_last_scan_digits(eagle_ctx* ctx, int* digits_used, int* digits_cut, double* spectral_bound) {
     if (!ctx) return EAGLE_ERR_ARG;
     if (digits_used) *digits_used = ctx->scan_digits_used;

@@ -18,6 +18,7 @@
 #include "../../include/eagle_hip.h"
 #include "eagle_internal.h"
 #include "eagle_host.h"
+#include "eagle_w8.h"
 
 struct GenoEntry {
     std::string path;
@@ -82,6 +83,15 @@ struct eagle_ctx {
     // experiment switch of tools/bench_i8_engine.py (0 = shipped)
     bool attr_vara_i8 = false, attr_vara_i8w = false, attr_vara_i8p = false, attr_vara_i8pp = false, attr_vara_i8px = false, attr_syrk_f4w = false, attr_zbuild_i8 = false, attr_vara_f6 = false, attr_gemv = false;
     int tune = 0;
+    // W = S (V S) on the int8 engine (eagle_w8.hip): workspace, and what the last call left for the scan that follows it
+    int w_mode = 1;            // 0 = always the fp64 GEMM, 1 = int8 digit slices from 4,096 padded individuals up, 2 = int8 at any size (tests)
+    void* w8_ws = nullptr; size_t w8_ws_cap = 0; void* w8_host = nullptr;
+    bool w8_active = false;    // Wu of the last scan_operands call came from the int8 engine:
+    double w8_eta = 0.0;       //   || folded image - truth ||_F <= w8_eta (the per-marker certificate adds w8_eta sum_j m'_j^2)
+    const double* w8_r = nullptr;   //   r = S (V (S 1)) in fp64 (the correction vector of the re-centred markers comes from it)
+    const double* w8_Wu = nullptr; const double* w8_Sa = nullptr; const double* w8_Va = nullptr; long w8_n = 0;   //   the image it describes, and the operands
+    double* w8_tmp = nullptr; void* w8_true_ws = nullptr; size_t w8_true_cap = 0;
+    W8Info w8_info;
     char arch[64] = {0};
     int cu_count = 0;
     int64_t hbm_bytes = 0;

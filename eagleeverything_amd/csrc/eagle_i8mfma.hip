@@ -20,117 +20,7 @@
 #include "eagle_ctx.h"
 #include "eagle_internal.h"
 
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x16 __attribute__((ext_vector_type(16)));
-typedef int i32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-
-#define T8 256          /* block tile (rows of A, rows of B) */
-#define BK8 128         /* K bytes per stage */
-#define TILE_BYTES (T8 * BK8)
-
-// Per-lane constants of the tile engine.
-//  DMA source: group g = 4w+i covers rows 8g .. 8g+7; lane l writes LDS bytes [1024 g + 16 l, +16) = row 8g + (l>>3),
-//  physical chunk l&7, which must hold logical chunk (l&7) ^ ((row>>1)&7) = (l&7) ^ ((l>>4) + 4(i&1)).  So the per-lane
-//  byte offset is voffE for even i and voffE ^ 64 for odd i (ld % 128 == 0), everything else is wave-uniform and goes
-//  into the scalar offset of a buffer_load ... lds.
-//  Fragment read: lane (r = l&31, h = l>>5) reads logical chunk 2ks+h of row R+r at physical chunk (2ks+h) ^ ((r>>1)&7).
-struct T8Lane {
-    int voffE, voffO;  // DMA source offsets (bytes) for even / odd row groups
-};
-__device__ __forceinline__ T8Lane t8_lane(int lane, int ld) {
-    T8Lane x;
-    x.voffE = (lane >> 3) * ld + (((lane & 7) ^ (lane >> 4)) << 4);
-    x.voffO = x.voffE ^ 64;
-    return x;
-}
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t t8_rsrc(const int8_t* base, int ld) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, T8 * ld, 0x00020000);
-}
-// One operand tile (256 rows x 128 B at byte column k0): 32 groups of 8 rows; wave w issues groups 4w .. 4w+3.
-__device__ __forceinline__ void t8_stage(__amdgpu_buffer_rsrc_t rs, const T8Lane& ln, int ld, int k0, int8_t* ldsTile, int w) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int grp = w * 4 + i;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(ldsTile + grp * 1024), 16,
-                                                 (i & 1) ? ln.voffO : ln.voffE, grp * 8 * ld + k0, 0, 0);
-    }
-}
-
-// One k-step (32 bytes of K) of the wave tile: 6 fragment reads + 8 MFMAs.
-__device__ __forceinline__ void t8_kstep(i32x16 (&acc)[4][2], const int8_t* pa, const int8_t* pb, int ch) {
-    i32x4 a[4], b[2];
-#pragma unroll
-    for (int m = 0; m < 4; m++) a[m] = *(const i32x4*)(pa + m * (32 * BK8) + ch);
-#pragma unroll
-    for (int n = 0; n < 2; n++) b[n] = *(const i32x4*)(pb + n * (32 * BK8) + ch);
-#pragma unroll
-    for (int m = 0; m < 4; m++)
-#pragma unroll
-        for (int n = 0; n < 2; n++) acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b[n], acc[m][n], 0, 0, 0);
-}
-struct T8Read {  // per-lane LDS read bases and the 4 swizzled chunk offsets of a stage
-    int offA, offB, ch[4];
-};
-__device__ __forceinline__ T8Read t8_read_init(int wr, int wc, int lane) {
-    const int r = lane & 31, h = lane >> 5, swz = (r >> 1) & 7;
-    T8Read x;
-    x.offA = wr * (128 * BK8) + r * BK8;
-    x.offB = wc * (64 * BK8) + r * BK8;
-#pragma unroll
-    for (int ks = 0; ks < 4; ks++) x.ch[ks] = ((2 * ks + h) ^ swz) << 4;
-    return x;
-}
-__device__ __forceinline__ void t8_compute(i32x16 (&acc)[4][2], const int8_t* ldsA, const int8_t* ldsB, int wr, int wc,
-                                           int lane) {
-    const T8Read rd = t8_read_init(wr, wc, lane);
-#pragma unroll
-    for (int ks = 0; ks < 4; ks++) t8_kstep(acc, ldsA + rd.offA, ldsB + rd.offB, rd.ch[ks]);
-}
-
-// One pipeline stage: DMA the next stage into (nA, nB) if `more`, then the 4 k-steps of the current stage.
-// TUNE 3 / 4 are ablations for tools/bench_i8_engine.py (3: no DMA, 4: DMA + one k-step); results are wrong there.
-// Measured on the MM^T SYRK (n = 5000, L = 262144, same process, interleaved): full 2.93 ms, no-DMA 2.32 ms, DMA-only
-// 2.78 ms: the kernel is bound by the L2 -> LDS fill rate (~40 GB/s per CU at a 70-80 % L2 hit rate), not by MFMA issue.
-// Tried and NOT faster (kept out of the code): staggering the DMA issue of waves 4-7 by half a stage (-13 %), spreading
-// the DMA pieces over the k-steps (+-2 %), software-pipelined fragment reads pinned with sched_group_barrier (-3 %),
-// a 10-slot 160 KiB LDS ring with 96 KiB in flight and counted vmcnt (-3 %; DMA-only 2.55 ms), a 4-deep ring of 64-byte
-// K stages (-9 %), tile-major pre-swizzled operand copies so that every DMA instruction reads 1 KiB of consecutive
-// bytes (+-1 %), odd leading dimensions against channel aliasing (+-1 %), a descending K order for every second tile so
-// that each sweep of the genotype panel starts on the lines the previous sweep left in L2 (0 %), and L2 prefetch of the
-// stage wanted 3 stages ahead by one designated leader per sharing group (-10 %: the leader's in-order vmcnt wait now
-// includes its own HBM-latency loads and it becomes the straggler of its group), and the v_mfma_i32_16x16x64_i8 shape
-// (8 x 4 tiles per wave; +7 % in the stand-alone tools/ubench/tile_geom.hip where the chip gives the clock back, -2.5 %
-// here: 5.66 vs 5.52 ms on the C2 SYRK).  Last, 2-bit packed genotype operands expanded in registers (perm LUT, 11 VALU
-// per 16 genotypes) and written to the same LDS image by ds_write_b128, which cuts the L2 -> CU bytes of the SYRK 4x:
-// 5.39 vs 5.41 ms, bit-identical result.  With the fill bytes quartered and the time unchanged the fill rate is not the
-// whole story either: every variant lands on the same ~2.5 POP/s, where MFMA-busy x clock is what the chip sustains on
-// random int8 operands (1.9 GHz at 55 % busy here; the guide's LDS-read + MFMA loops hold 1.5-1.7 GHz when denser).
-// Splitting a worker's column-tile pairs over 2 / 5 workgroups (fewer marker tiles resident per XCD, so that their genotype
-// panels stay in L2 across the column tiles): -1 % / -7 % (22.6 -> 22.9 / 24.2 ms), the W-digit tiles then have fewer sharers.
-// tools/ubench/fill_rate.hip measures what bounds it: filling 64 KiB of LDS takes 1.15-1.2 us per CU when every line
-// is an L2 hit and 3.1 us when every line comes from HBM, by LDS-DMA and by register staging alike; at the 72-82 %
-// hit rate of these kernels (rocprofv3 TCC_HIT/TCC_REQ) that is 1.5-1.7 us per stage against 0.9-1.1 us of MFMA work.
-template <int TUNE>
-__device__ __forceinline__ void t8_stage_compute(i32x16 (&acc)[4][2], const int8_t* ldsA, const int8_t* ldsB, const T8Read& rd,
-                                                 bool more, __amdgpu_buffer_rsrc_t rsA, const T8Lane& lnA, int ldA, int kA,
-                                                 int8_t* nA, __amdgpu_buffer_rsrc_t rsB, const T8Lane& lnB, int ldB, int kB,
-                                                 int8_t* nB, int w) {
-    const int8_t* pa = ldsA + rd.offA;
-    const int8_t* pb = ldsB + rd.offB;
-    if (TUNE != 3 && more) { t8_stage(rsA, lnA, ldA, kA, nA, w); t8_stage(rsB, lnB, ldB, kB, nB, w); }
-#pragma unroll
-    for (int ks = 0; ks < (TUNE == 4 ? 1 : 4); ks++) t8_kstep(acc, pa, pb, rd.ch[ks]);
-}
-
-__device__ __forceinline__ void t8_zero(i32x16 (&acc)[4][2]) {
-#pragma unroll
-    for (int m = 0; m < 4; m++)
-#pragma unroll
-        for (int n = 0; n < 2; n++)
-#pragma unroll
-            for (int q = 0; q < 16; q++) acc[m][n][q] = 0;
-}
+#include "eagle_t8.h"
 
 // ------------------------------------------------------------------------------------------------
 // MM^T: grid.x = upper-triangular 256-tile pairs, grid.y = K splits.  Integer atomics: exact, any order.
@@ -301,20 +191,10 @@ struct VaraHdr {        // head of the workspace, written on the device, never r
     // whether a high part left int8, whether level 1 declined and level 2 is to run, and the level that took the digit off (0: none)
     unsigned long long lo_sumsq;
     int maxdiag, hi_overflow, spec_try2, level;
+    // W itself came from int8 digit slices (eagle_w8.hip): || Wu - truth ||_F <= wErr, i.e. |error of marker i| <= wErr sum_j m'_ij^2 on top
+    // of the digit terms (0: the fp64 products)
+    double wErr;
 };
-// Scale exponent of the digits: max|Wu_jk| (j != k) < 2^e, lowered by one when the mantissa leaves room (round 3) -- a balanced S-digit
-// number reaches 127 (256^S - 1)/255 = 0.498 * 256^S, and |Q| <= max|Wu| 2^(8S-e-2) + 1 stays below 0.49 * 256^S + 1 for a mantissa up
-// to 0.98: one more bit of resolution for the same digits on 96 % of all scales (rounds 1-2 always kept the leading digit inside
-// [-65, 65]).  A power of two, so that Wu * 2^(8S-e-2) is exact and llrint rounds the true value.
-__device__ __forceinline__ int w_scale_exp(double mx) {
-    int e = 0;
-    if (mx > 0.0) {
-        const double f = frexp(mx, &e);
-        if (f <= 0.98) e -= 1;
-    }
-    return e;
-}
-
 __global__ __launch_bounds__(256) void k_absmax_offdiag(const double* __restrict__ x, long np, unsigned long long* __restrict__ bits) {
     double m = 0.0;
     const long n = np * np;
@@ -356,7 +236,7 @@ __global__ __launch_bounds__(256) void k_absmax_offdiag(const double* __restrict
 #define VARA_HOEFFDING_K 8.355  /* sqrt(ln(2 / 1e-30)) */
 // One block: dW[k] = Wu[k][k] (contiguous copy), sumdiag in a fixed order, then the slice count (forced = 1..8: that S).
 __global__ __launch_bounds__(256) void k_vara_prep(const double* __restrict__ Wu, long n_pad, int forced_arg, VaraHdr* __restrict__ hdr,
-                                                   double* __restrict__ dW, double budget) {
+                                                   double* __restrict__ dW, double budget, double wErr) {
     const int forced = forced_arg & 0xff, stochastic = (forced_arg & EAGLE_SLICES_STOCHASTIC) ? 1 : 0;
     double s = 0.0;
     for (long k = threadIdx.x; k < n_pad; k += 256) {
@@ -382,7 +262,7 @@ __global__ __launch_bounds__(256) void k_vara_prep(const double* __restrict__ Wu
             for (int c = stochastic ? 2 : 3; c <= 7; c++) {
                 // worst case over markers: every entry non-zero (nearest: errors aligned; stochastic: q2 = n, the Hoeffding radius)
                 const double b = stochastic ? VARA_HOEFFDING_K * (double)n_pad * ldexp(1.0, e + 1 - 8 * c) : ldexp(nn, e + 1 - 8 * c);
-                if (b <= target) { S = c; break; }
+                if (b + wErr * (double)n_pad <= target) { S = c; break; }   // (wErr: the marker with q2 = n_pad again)
             }
         }
         if (mx == 0.0) S = 1;
@@ -390,6 +270,7 @@ __global__ __launch_bounds__(256) void k_vara_prep(const double* __restrict__ Wu
         hdr->S_sliced = S;
         hdr->specH = 0.0;
         hdr->budget = budget;
+        hdr->wErr = wErr;
         hdr->e = e;
         hdr->pad = stochastic;
         hdr->sumdiag = red[0];
@@ -600,7 +481,7 @@ __global__ __launch_bounds__(256) void k_spectral_decide(const unsigned long lon
                 normsq = ((double)hdr->maxdiag + ldexp(sqrt(normsq) * up, shift) + sqrt((double)hdr->lo_sumsq * up) * up) * up;
             const double normDs = sqrt(normsq) * up;
             const double H = 0.5 * u * (normDs + 0.5 * (double)(n_pad - 1)) * up;
-            if (H * (double)n_pad <= budget * 0.5 * hdr->sumdiag) {
+            if ((H + hdr->wErr) * (double)n_pad <= budget * 0.5 * hdr->sumdiag) {
                 hdr->S = S - 1;
                 hdr->specH = H;
                 hdr->level = level;
@@ -1492,13 +1373,14 @@ __global__ __launch_bounds__(256) void k_vara_i8_finish(const long long* __restr
 #define CERT_CAP 2048
 struct CertHdr { unsigned long long lb_bits; int count; int overflow; int flagged; int pad; };  // = eagle_cert_info of the public header
 
-struct CertCtx { double delta, absR, sumdiag, specH, flag_rel; int stochastic; };
+struct CertCtx { double delta, absR, sumdiag, specH, flag_rel, wErr; int stochastic; };
 __device__ __forceinline__ CertCtx cert_ctx(const VaraHdr* hdr) {
     CertCtx c;
     const double mx = hdr->maxabs_off;
     const int e = hdr->e;
     c.delta = mx > 0.0 ? ldexp(1.0, e + 1 - 8 * hdr->S) : 0.0;
     c.specH = hdr->specH;
+    c.wErr = hdr->wErr;
     if (c.specH > 0.0) c.delta *= 1.0 + 0x1p-8;   // the leading S digits of an (S+1)-digit rounding: |R_jk| <= (128 + 1/2) u
     c.absR = fabs(hdr->R);
     c.flag_rel = VARA_FLAG_FACTOR * hdr->budget;
@@ -1512,7 +1394,7 @@ __device__ __forceinline__ double cert_bound(const CertCtx& cc, const int32_t* l
     if (ext && cc.specH > 0.0) {   // a marker that got the dropped digit back (eagle_dev_vara_i8_extend): all digits cut, rounding only
         double mag = fabs(vdiag) + fabs(vara - vdiag);
         if (c != 0) mag += 2.0 * (fabs(mrho) + cc.absR);
-        return 0.5 * l * l * (cc.delta * (0x1p-8 / (1.0 + 0x1p-8))) + 0x1p-48 * mag + 0x1p-50 * cc.sumdiag;
+        return 0.5 * l * l * (cc.delta * (0x1p-8 / (1.0 + 0x1p-8))) + cc.wErr * (double)l1q2[2 * i + 1] + 0x1p-48 * mag + 0x1p-50 * cc.sumdiag;
     }
     // round to nearest: guaranteed; stochastic rounding: exceeded with probability below 1e-30 per marker (and never above
     // the guaranteed l1^2 * delta of an interval of twice the width)
@@ -1520,7 +1402,7 @@ __device__ __forceinline__ double cert_bound(const CertCtx& cc, const int32_t* l
     if (cc.specH > 0.0) b = fmin(b, cc.specH * (double)l1q2[2 * i + 1]);   // the spectral bound of k_spectral_decide
     double mag = fabs(vdiag) + fabs(vara - vdiag);
     if (c != 0) mag += 2.0 * (fabs(mrho) + cc.absR);
-    return b + 0x1p-48 * mag + 0x1p-50 * cc.sumdiag;
+    return b + cc.wErr * (double)l1q2[2 * i + 1] + 0x1p-48 * mag + 0x1p-50 * cc.sumdiag;
 }
 __global__ __launch_bounds__(256) void k_cert_lb(const double* __restrict__ a, const double* __restrict__ vara, long L,
                                                  const int32_t* __restrict__ l1, const int8_t* __restrict__ cshift,
@@ -1647,6 +1529,18 @@ extern "C" int eagle_dev_scan_certify_apply(eagle_ctx* ctx, const int8_t* Mt8, l
     hipLaunchKernelGGL(k_cert_gather, dim3(CERT_CAP), dim3(256), 0, s, Mt8, ld, n_pad, ch, idx, rows);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "scan_certify");
+    if (ctx->w8_active && ctx->w8_Wu == Wu) {
+        // W from the int8 engine carries its own error: the candidates are re-evaluated against the TRUE W, (S m)^T V (S m) in fp64
+        // (the host reads the count: one small round trip); an overflowing certificate first replaces W by the fp64 products
+        CertHdr h;
+        e = hipMemcpyAsync(&h, ch, sizeof h, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return eagle_fail_hip(ctx, e, "candidate count");
+        if (!h.overflow) return eagle_w8_true_vara(ctx, rows, h.count, n_pad, n_pad, idx, vara, stream);
+        int r8 = eagle_w8_redo_f64(ctx, n_pad, stream);
+        if (r8) return r8;
+        return eagle_dev_vara_f64_gated(ctx, Mt8, L_pad, n_pad, ld, Wu, vara, &ch->overflow, stream);
+    }
     int rc = eagle_dev_vara_f64_split(ctx, rows, CERT_CAP, n_pad, n_pad, Wu, &ch->count, idx, partial, vara, stream);
     if (rc) return rc;
     // more than CERT_CAP markers qualified: the whole block in fp64 (dropped on the device otherwise)
@@ -1773,6 +1667,13 @@ extern "C" int eagle_dev_cert_reevaluate(eagle_ctx* ctx, const int8_t* Mt8, long
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return eagle_fail_hip(ctx, e, "k_cert_gather");
     }
+    if (ctx->w8_active && ctx->w8_Wu == Wu) {   // (see eagle_dev_scan_certify_apply)
+        CertHdr h;
+        hipError_t e = hipMemcpyAsync(&h, ch, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream);
+        if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+        if (e != hipSuccess) return eagle_fail_hip(ctx, e, "candidate count");
+        return eagle_w8_true_vara(ctx, rows, h.count < CERT_CAP ? h.count : CERT_CAP, n_pad, n_pad, idx, vara, stream);
+    }
     return eagle_dev_vara_f64_split(ctx, rows, CERT_CAP, n_pad, n_pad, Wu, &ch->count, idx, partial, vara, stream);
 }
 
@@ -1853,12 +1754,20 @@ extern "C" int eagle_dev_vara_i8_prepare_part(eagle_ctx* ctx, const int8_t* Mt8,
     }
     if (part != 2) {
         hipLaunchKernelGGL(k_absmax_offdiag, dim3(1024), dim3(256), 0, s, Wu, n_pad, (unsigned long long*)&hdr->maxabs_off);
-        hipLaunchKernelGGL(k_vara_prep, dim3(1), dim3(256), 0, s, Wu, n_pad, nslices, hdr, dW, ctx->scan_budget);
+        // W from the int8 engine (eagle_w8.hip, the image it left is the one being prepared): its error bound rides in the header, and
+        // the correction vector of the re-centred markers comes from r = S (V (S 1)) instead of the row sums of this image
+        const bool w8 = ctx->w8_active && ctx->w8_Wu == Wu;
+        hipLaunchKernelGGL(k_vara_prep, dim3(1), dim3(256), 0, s, Wu, n_pad, nslices, hdr, dW, ctx->scan_budget, w8 ? ctx->w8_eta : 0.0);
         // correction terms of the re-centred markers: rho and R from Wu, m^T rho from the genotype pass
         double* colpart = (double*)((char*)ws + ws_cp_off(n_pad, L_pad, smax));
-        hipLaunchKernelGGL(k_rho_rows, dim3((unsigned)n_pad), dim3(256), 0, s, Wu, n_pad, rho);
-        hipLaunchKernelGGL(k_rho_cols, dim3((unsigned)(n_pad / 256), (unsigned)(n_pad / 256)), dim3(256), 0, s, Wu, n_pad, colpart);
-        hipLaunchKernelGGL(k_rho_colsum, dim3((unsigned)(n_pad / 256)), dim3(256), 0, s, colpart, n_pad, rho);
+        if (w8) {
+            rc = eagle_w8_rho(ctx, Wu, n_pad, rho, stream);
+            if (rc) return rc;
+        } else {
+            hipLaunchKernelGGL(k_rho_rows, dim3((unsigned)n_pad), dim3(256), 0, s, Wu, n_pad, rho);
+            hipLaunchKernelGGL(k_rho_cols, dim3((unsigned)(n_pad / 256), (unsigned)(n_pad / 256)), dim3(256), 0, s, Wu, n_pad, colpart);
+            hipLaunchKernelGGL(k_rho_colsum, dim3((unsigned)(n_pad / 256)), dim3(256), 0, s, colpart, n_pad, rho);
+        }
         hipLaunchKernelGGL(k_rho_final, dim3(1), dim3(1024), 0, s, n_pad, rho, hdr);
     }
     if (part != 1) {
@@ -2003,7 +1912,7 @@ __global__ __launch_bounds__(256) void k_ext_select(const double* __restrict__ v
         const double v = vara[i];
         if (!isfinite(v)) continue;
         const double l = (double)l1q2[2 * i];
-        const double b = fmin(H * (double)l1q2[2 * i + 1], 0.5 * l * l * delta);
+        const double b = fmin(H * (double)l1q2[2 * i + 1], 0.5 * l * l * delta) + hdr->wErr * (double)l1q2[2 * i + 1];
         if (b > thr * fabs(v)) {
             const int k = atomicAdd(&xh->count, 1);
             if (k < cap) { idx[k] = (int)i; flag[i] = 1; } else xh->overflow = 1;

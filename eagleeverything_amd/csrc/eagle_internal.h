@@ -17,6 +17,14 @@ int eagle_dev_gemm_f64(eagle_ctx* ctx, const double* A, const double* B, double*
 int eagle_dev_scan_operands_begin(eagle_ctx* ctx, const double* Sa, const double* ahat, long n, long n_pad, double* v_out, double* tmp, void* stream);
 int eagle_dev_scan_operands_vrows(eagle_ctx* ctx, const double* Sa, const double* Va, long n_pad, long row0, long row1, double* tmp, void* stream);
 int eagle_dev_scan_operands_finish(eagle_ctx* ctx, const double* Sa, const double* Va, long n_pad, double* Wu_out, double* tmp, void* stream);
+// the two n^3 products alone (v is made by _begin): W's folded image from resident operands on the fp64 GEMM
+int eagle_dev_scan_operands_w_f64(eagle_ctx* ctx, const double* Sa, const double* Va, long n_pad, double* Wu_out, double* tmp, void* stream);
+// W = S (V S) from int8 digit slices (eagle_w8.hip): EAGLE_OK, 1 = declined (run the fp64 products), < 0 error
+int eagle_dev_scan_operands_w8(eagle_ctx* ctx, const double* Sa, const double* Va, const double* ahat, long n, long n_pad, double* v_out, double* Wu_out,
+                               double* tmp, void* stream);
+int eagle_w8_rho(eagle_ctx* ctx, const double* Wu, long n_pad, double* rho, void* stream);
+int eagle_w8_true_vara(eagle_ctx* ctx, const int8_t* rows8, long count, long n_pad, long ld, const long* dst_dev, double* out, void* stream);
+int eagle_w8_redo_f64(eagle_ctx* ctx, long n_pad, void* stream);
 // out = A x where At is the row-major image of A^T (i.e. the column-major R matrix), n_pad % 64 == 0
 int eagle_dev_colgemv(eagle_ctx* ctx, const double* At, long n, long n_pad, const double* x, double* out, void* stream);
 // 4 KiB of ctx-owned device scratch (flags, small reductions); stream-ordered use only
@@ -62,5 +70,7 @@ int eagle_spectral_scan_range(eagle_ctx* ctx, const double* d, const double* G, 
 int eagle_dev_extract_col(eagle_ctx* ctx, const int8_t* M8, long n, long ld, long col, int* out, void* stream);
 #ifdef __cplusplus
 }
+struct eagle_ctx;
+bool eagle_w8_wanted(const eagle_ctx* ctx, long n_pad);
 #endif
 #endif

@@ -1492,14 +1492,32 @@ extern "C" int eagle_dev_scan_operands_finish(eagle_ctx* ctx, const double* Sa, 
     LAUNCH_CHECK(ctx);
     return EAGLE_OK;
 }
-extern "C" int eagle_dev_scan_operands(eagle_ctx* ctx, const double* Sa, const double* Va, const double* ahat, long n,
-                                       long n_pad, double* v_out, double* Wu_out, double* tmp, void* stream) {
-    int rc = eagle_dev_scan_operands_begin(ctx, Sa, ahat, n, n_pad, v_out, tmp, stream);
+extern "C" int eagle_dev_scan_operands_w_f64(eagle_ctx* ctx, const double* Sa, const double* Va, long n_pad, double* Wu_out, double* tmp, void* stream) {
+    int rc = EAGLE_OK;
     // the same 1024-row blocks the reference-shaped call uses while V arrives: each launch cuts its own split-K tail, so only
     // the same blocking gives the same sums
     for (long b0 = 0; b0 < n_pad && !rc; b0 += EAGLE_VROWS_BLOCK)
         rc = eagle_dev_scan_operands_vrows(ctx, Sa, Va, n_pad, b0, b0 + EAGLE_VROWS_BLOCK < n_pad ? b0 + EAGLE_VROWS_BLOCK : n_pad, tmp, stream);
     if (!rc) rc = eagle_dev_scan_operands_finish(ctx, Sa, Va, n_pad, Wu_out, tmp, stream);
+    return rc;
+}
+// Which engine forms W: the int8 digit-slice products (eagle_w8.hip) for a digit-slice scan from 4,096 padded individuals up
+// (eagle_set_w_mode: 0 = never, 2 = at any size), unless they decline; the fp64 GEMM otherwise.
+bool eagle_w8_wanted(const eagle_ctx* ctx, long n_pad) {
+    return ctx->scan_mode == 1 && (ctx->w_mode == 2 || (ctx->w_mode == 1 && n_pad >= 4096));
+}
+extern "C" int eagle_dev_scan_operands(eagle_ctx* ctx, const double* Sa, const double* Va, const double* ahat, long n,
+                                       long n_pad, double* v_out, double* Wu_out, double* tmp, void* stream) {
+    if (eagle_w8_wanted(ctx, n_pad)) {
+        const int r8 = eagle_dev_scan_operands_w8(ctx, Sa, Va, ahat, n, n_pad, v_out, Wu_out, tmp, stream);
+        if (r8 != 1) return r8;   // done, or failed; 1: declined -- the fp64 products below
+    } else {
+        ctx->w8_info = W8Info();
+        ctx->w8_info.declined = 7;
+    }
+    ctx->w8_active = false;
+    int rc = eagle_dev_scan_operands_begin(ctx, Sa, ahat, n, n_pad, v_out, tmp, stream);
+    if (!rc) rc = eagle_dev_scan_operands_w_f64(ctx, Sa, Va, n_pad, Wu_out, tmp, stream);
     return rc;
 }
 
@@ -1509,6 +1527,7 @@ extern "C" int eagle_dev_scan_operands(eagle_ctx* ctx, const double* Sa, const d
 // complete image with eagle_dev_fold_upper.
 extern "C" int eagle_dev_scan_operands_rows(eagle_ctx* ctx, const double* Sa, const double* Va, const double* ahat, long n, long n_pad,
                                             long row0, long row1, double* v_out, double* Wt_out, double* tmp, void* stream) {
+    ctx->w8_active = false;
     if (n_pad % GF_T || n > n_pad || row0 % GF_T || row1 % GF_T || row0 < 0 || row1 > n_pad || row0 >= row1)
         return eagle_fail(ctx, EAGLE_ERR_ARG, "scan_operands_rows: bad padding or row block");
     hipStream_t s = (hipStream_t)stream;
@@ -1525,6 +1544,7 @@ extern "C" int eagle_dev_scan_operands_rows(eagle_ctx* ctx, const double* Sa, co
 }
 // In-place fold of a COMPLETE W image: Wu[j][k] = W[j][k] + W[k][j] (j<k), W[k][k], 0 below.
 extern "C" int eagle_dev_fold_upper(eagle_ctx* ctx, double* W, long n_pad, void* stream) {
+    if (ctx->w8_Wu == W) ctx->w8_active = false;
     if (n_pad % 32) return eagle_fail(ctx, EAGLE_ERR_ARG, "fold_upper: bad padding");
     int* sym = (int*)((char*)eagle_ctx_scratch(ctx) + EAGLE_SCR_SYM);
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, (hipStream_t)stream, sym, 0);

@@ -1,0 +1,775 @@
+// eagle_w8.hip -- W = S (V S) of the marker scan on the int8 MFMA tile engine       (E/src/calculate_a_and_vara_rcpp.cpp:97-98, :197-198)
+//
+// The digit-slice scan keeps 24 bits of W's off-diagonal and certifies every vara_i a posteriori -- and until round 3 it formed that W
+// on the 78.6 TFLOP/s fp64 pipe (30 % of the step at 10,000 individuals, 74 % at 50,000) next to a 5 POP/s int8 engine.  Here the two
+// n^3 products run on the int8 engine from exact base-256 digit slices (an Ozaki-type splitting), with a RIGOROUS Frobenius-norm
+// bound of the error of the W they deliver, which the scan's per-marker certificate carries next to its truncation term.
+//
+// Splitting.  S = D + F, V = Dv + Fv (diagonal + off-diagonal part of the row-major images Sa, Va).  MMt^-1/2 and a variance
+// matrix are diagonally dominant: the diagonal parts are handled exactly, element by element, in fp64 --
+//     X[j][k] = (S V)[j][k] = D_j Dv_j [j = k]  +  D_j Fv[j][k]  +  F[j][k] Dv_k  +  G1[j][k],      G1 = F Fv^T   (NT product),
+//     W[i][j] = (S X^T)[i][j] = D_i Dx_i [i = j]  +  D_i Fx[j][i]  +  F[i][j] Dx_j  +  G2[i][j],    G2 = F Fx^T,  X = Dx + Fx,
+// and only G1, G2 are matrix products.  Their operands are flat (no dominant entry), so a per-ROW power-of-two scale wastes no bits:
+//     F[i][l] = 2^(e_i+2) ( sum_{p=1..6} 256^-p a_p[i][l]  +  r ),   a_p in [-128, 127] balanced digits,  |r| <= 256^-6 / 2,
+//     G[i][j] = 2^(e_i+f_j+4) sum_{p,q} 256^-(p+q) (a_p b_q^T)[i][j],   every a_p b_q^T an EXACT int32 product on v_mfma_i32_32x32x32_i8.
+// Products of equal weight p + q = t share an accumulator (level t); a configuration (k, T) computes the pairs p, q <= k, p + q <= T.
+// Level sums are exact integers, so the result does not depend on tiling, panel cuts or which device formed which rows: a row-sharded
+// multi-GPU evaluation returns the single-device bits.  The levels are combined in fp64 in a fixed order.
+//
+// Error bound (everything in the Frobenius norm, which survives taking the upper triangle: the scan works on the folded image).
+// For a product G = A B^T with A = sum_p 2^(e+2) 256^-p A_p + dA,  B likewise:
+//     || G - G_computed ||_F  <=  sum_{(p,q) not computed} 256^-(p+q) Phi_p(A) Phi_q(B)  +  T_A (||B||_F + T_B)  +  ||A||_F T_B,
+//     Phi_p(A)^2 = sum_i 4^(e_i+2) sum_l a_p[i][l]^2   (exact integer row sums, scaled),     T_A = sqrt(n_pad) 2^(-8*6-1) sqrt(sum_i 4^(e_i+2)),
+// then  ||X_c - X||_F <= eta_1 + rounding,  ||W_c - W||_F <= (max|D| + ||F||_F) ||X_c - X||_F + eta_2 + rounding + asymmetry terms
+// (the images are used where their transposes are meant; the measured max |M - M^T| pays for it), and the folded image built from the
+// upper triangle of W_c is within sqrt(2) of that.  For a re-centred marker row m':  | m'^T (W_c - W) m' | <= eta_W sum_j m'_j^2.
+// The host picks, for each product, the cheapest configuration that keeps eta_W below W8_TARGET x budget x mean|W_kk|; if none of the
+// configurations does (wild scaling, cancelling V, non-finite or visibly asymmetric operands) the call DECLINES and the caller runs the
+// fp64 GEMM as before.  Terms that must not carry eta_W at all are taken from elsewhere: the correction vector of the re-centred
+// markers from r = S (V (S 1)) (three fp64 matrix-vector products), and the markers the certificate re-evaluates from
+// (S m)^T V (S m) in fp64 (k_w8_mgemv below) -- so the selected marker is still decided on fp64 values.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+#include <algorithm>
+#include <functional>
+#include <string.h>
+
+#include "../../include/eagle_hip.h"
+#include "eagle_ctx.h"
+#include "eagle_internal.h"
+#include "eagle_t8.h"
+#include "eagle_w8.h"
+
+// ------------------------------------------------------------------------------------------------
+// Row statistics of an n_pad x n_pad fp64 image: diagonal, largest off-diagonal magnitude, off-diagonal sum of squares.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_w8_rowstats(const double* __restrict__ M, long np, double* __restrict__ d, double* __restrict__ mx,
+                                                     double* __restrict__ ssq, int* __restrict__ bad) {
+    const long i = blockIdx.x;
+    const double* row = M + i * np;
+    double m = 0.0, s = 0.0;
+    int nf = 0;
+    for (long l = threadIdx.x; l < np; l += 256) {
+        const double v = row[l];
+        if (!isfinite(v)) nf = 1;
+        if (l != i) {
+            const double a = fabs(v);
+            m = a > m ? a : m;
+            s += v * v;
+        }
+    }
+    __shared__ double rm[256], rs[256];
+    __shared__ int rb[256];
+    rm[threadIdx.x] = m; rs[threadIdx.x] = s; rb[threadIdx.x] = nf;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            rm[threadIdx.x] = rm[threadIdx.x + o] > rm[threadIdx.x] ? rm[threadIdx.x + o] : rm[threadIdx.x];
+            rs[threadIdx.x] += rs[threadIdx.x + o];
+            rb[threadIdx.x] |= rb[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        d[i] = row[i];
+        mx[i] = rm[0];
+        ssq[i] = rs[0];
+        if (rb[0]) *bad = 1;
+    }
+}
+
+// out = (M + M^T) / 2 and max |M[i][j] - M[j][i]| (bits of a non-negative double order like the double); one block per pair of
+// mirrored 32 x 32 tiles.  The products below are formed from the symmetrised operands: the symmetric part of S V S -- all a quadratic
+// form sees -- does not depend on the antisymmetric parts of S and V to first order, the upper triangle of (S_s V_s S_s) is all of it,
+// and what is left is second order in the measured asymmetry (a term of the bound).
+__global__ __launch_bounds__(256) void k_w8_symmetrize(const double* __restrict__ M, long np, double* __restrict__ out, unsigned long long* __restrict__ maxbits) {
+    const long bj = (long)blockIdx.y * 32, bk = (long)blockIdx.x * 32;
+    if (bk < bj) return;
+    __shared__ double t1[32][33], t2[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        t1[r][tx] = M[(bj + r) * np + bk + tx];   // t1[a][b] = M[bj + a][bk + b]
+        t2[r][tx] = M[(bk + r) * np + bj + tx];   // t2[a][b] = M[bk + a][bj + b]
+    }
+    __syncthreads();
+    double m = 0.0;
+    for (int r = ty; r < 32; r += 8) {
+        const double a = t1[r][tx], at = t2[tx][r];
+        const double df = fabs(a - at);
+        m = df > m ? df : m;   // (a NaN never wins; k_w8_rowstats reports non-finite entries)
+        out[(bj + r) * np + bk + tx] = 0.5 * (a + at);
+        if (bk != bj) out[(bk + r) * np + bj + tx] = 0.5 * (t2[r][tx] + t1[tx][r]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_down(m, o); m = y > m ? y : m; }
+    if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(maxbits, (unsigned long long)__double_as_longlong(m));
+}
+
+// Digit slices of the off-diagonal part of one row: D[p][i][l] = digit p (0 = most significant) of round(M[i][l] 2^(8*6 - e_i - 2)),
+// balanced, peeled least significant first with a carry (as k_slice_w); dssq[p][i] = sum_l D[p][i][l]^2 (exact).
+__global__ __launch_bounds__(256) void k_w8_slice(const double* __restrict__ M, long np, const double* __restrict__ mx, int8_t* __restrict__ D,
+                                                  long sstride, unsigned long long* __restrict__ dssq, int* __restrict__ eout) {
+    const long i = blockIdx.x;
+    const double* row = M + i * np;
+    const double mxi = mx[i];
+    const int e = w_scale_exp(mxi);
+    const int sh = 8 * W8_KMAX - e - 2;
+    unsigned long long sq[W8_KMAX];
+#pragma unroll
+    for (int p = 0; p < W8_KMAX; p++) sq[p] = 0;
+    for (long l0 = (long)threadIdx.x * 16; l0 < np; l0 += 256 * 16) {
+        union { i32x4 v; int8_t b[16]; } dg[W8_KMAX];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const long l = l0 + u;
+            long long Q = 0;
+            if (l != i && mxi > 0.0) Q = llrint(ldexp(row[l], sh));
+#pragma unroll
+            for (int p = W8_KMAX - 1; p >= 0; p--) {
+                const long long dd = ((Q + 128) & 255) - 128;
+                Q = (Q - dd) >> 8;
+                dg[p].b[u] = (int8_t)dd;
+                sq[p] += (unsigned long long)(dd * dd);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < W8_KMAX; p++) *(i32x4*)(D + (long)p * sstride + i * np + l0) = dg[p].v;
+    }
+    __shared__ unsigned long long red[W8_KMAX][256];
+#pragma unroll
+    for (int p = 0; p < W8_KMAX; p++) red[p][threadIdx.x] = sq[p];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+#pragma unroll
+            for (int p = 0; p < W8_KMAX; p++) red[p][threadIdx.x] += red[p][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x < W8_KMAX) dssq[(long)threadIdx.x * np + i] = red[threadIdx.x][0];
+    if (threadIdx.x == 0) eout[i] = e;
+}
+
+// One block: the numbers the host's configuration choice needs (fixed summation order).  d2: optional second diagonal for the
+// estimate sum_i d2_i^2 |d_i| of sum_k |W_kk|.
+__global__ __launch_bounds__(1024) void k_w8_reduce(long np, const double* __restrict__ d, const double* __restrict__ mx, const double* __restrict__ ssq,
+                                                    const int* __restrict__ e, const unsigned long long* __restrict__ dssq, const double* __restrict__ d2,
+                                                    const int* __restrict__ bad, const unsigned long long* __restrict__ asymbits, W8Stats* __restrict__ out) {
+    double maxd = 0.0, fro2 = 0.0, es2 = 0.0, wd = 0.0, phi2[W8_KMAX];
+#pragma unroll
+    for (int p = 0; p < W8_KMAX; p++) phi2[p] = 0.0;
+    for (long i = threadIdx.x; i < np; i += 1024) {
+        const double a = fabs(d[i]);
+        maxd = a > maxd ? a : maxd;
+        fro2 += ssq[i];
+        if (mx[i] > 0.0) {
+            const double sc = ldexp(1.0, 2 * (e[i] + 2));
+            es2 += sc;
+#pragma unroll
+            for (int p = 0; p < W8_KMAX; p++) phi2[p] += sc * (double)dssq[(long)p * np + i];
+        }
+        if (d2) wd += d2[i] * d2[i] * a;
+    }
+    __shared__ double red[1024];
+    auto sum = [&](double x) -> double {
+        __syncthreads();
+        red[threadIdx.x] = x;
+        __syncthreads();
+        for (int o = 512; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        return red[0];
+    };
+    __syncthreads();
+    red[threadIdx.x] = maxd;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = red[threadIdx.x + o] > red[threadIdx.x] ? red[threadIdx.x + o] : red[threadIdx.x];
+        __syncthreads();
+    }
+    const double gmaxd = red[0];
+    const double gfro2 = sum(fro2), ges2 = sum(es2), gwd = sum(wd);
+    double gphi2[W8_KMAX];
+#pragma unroll
+    for (int p = 0; p < W8_KMAX; p++) gphi2[p] = sum(phi2[p]);
+    if (threadIdx.x == 0) {
+        out->maxd = gmaxd; out->fro2 = gfro2; out->es2 = ges2; out->wdsum = gwd;
+#pragma unroll
+        for (int p = 0; p < W8_KMAX; p++) out->phi2[p] = gphi2[p];
+        out->bad = bad ? *bad : 0;
+        out->asym = asymbits ? __longlong_as_double((long long)*asymbits) : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The products.  One workgroup = one 256 x 256 output tile of ONE accumulation group: the (at most 8) digit pairs of one level whose
+// worst-case sum fits an int32 (n_pad x pairs x 2^14 < 2^31), streamed through the double-buffered LDS-DMA pipeline of the tile
+// engine as one long K loop.  Work list per XCD (workgroup b runs on XCD b % 8, positions in order): units of up to 4 x 8 tiles of one
+// group, dealt to the XCDs by cost, so that the ~32 workgroups an XCD runs at a time stream the same few digit panels.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void k_w8_gemm(const int8_t* __restrict__ As, const int8_t* __restrict__ Bs, long sstride, long ld,
+                                                    const unsigned* __restrict__ work, int maxlen, const W8Group* __restrict__ groups,
+                                                    int32_t* __restrict__ L, long img_elems, long ldc, int row_tile0, int nstages) {
+    __shared__ __attribute__((aligned(1024))) int8_t lds[2][2][TILE_BYTES];
+    const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
+    if (pos >= maxlen) return;
+    const unsigned wk = work[(long)xcd * maxlen + pos];
+    if (wk == 0xFFFFFFFFu) return;
+    const int ti = (int)(wk >> 20), tj = (int)((wk >> 8) & 0xfffu), g = (int)(wk & 0xffu);
+    const W8Group* gp = groups + g;
+    const int gnp = gp->npairs;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = w >> 2, wc = w & 3;
+    const int ldi = (int)ld;
+    const T8Lane ln = t8_lane(lane, ldi);
+    const int8_t* Arow = As + (long)ti * T8 * ld;
+    const int8_t* Brow = Bs + (long)tj * T8 * ld;
+    __amdgpu_buffer_rsrc_t rsA = t8_rsrc(Arow + (long)gp->p[0] * sstride, ldi);
+    __amdgpu_buffer_rsrc_t rsB = t8_rsrc(Brow + (long)gp->q[0] * sstride, ldi);
+    i32x16 acc[4][2];
+    t8_zero(acc);
+    t8_stage(rsA, ln, ldi, 0, lds[0][0], w);
+    t8_stage(rsB, ln, ldi, 0, lds[0][1], w);
+    __syncthreads();
+    int cur = 0;
+    const T8Read rd = t8_read_init(wr, wc, lane);
+    const int total = gnp * nstages;
+    int s = 0, pr = 0;
+    for (int it = 0; it < total; it++) {
+        int s1 = s + 1, pr1 = pr;
+        if (s1 == nstages) { s1 = 0; pr1 = pr + 1; }
+        const bool more = it + 1 < total;
+        if (more && pr1 != pr) {
+            rsA = t8_rsrc(Arow + (long)gp->p[pr1] * sstride, ldi);
+            rsB = t8_rsrc(Brow + (long)gp->q[pr1] * sstride, ldi);
+        }
+        t8_stage_compute<0>(acc, lds[cur][0], lds[cur][1], rd, more, rsA, ln, ldi, s1 * BK8, lds[cur ^ 1][0], rsB, ln, ldi, s1 * BK8,
+                            lds[cur ^ 1][1], w);
+        __syncthreads();
+        cur ^= 1;
+        s = s1; pr = pr1;
+    }
+    // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    int32_t* Lg = L + (long)g * img_elems + ((long)(ti - row_tile0) * T8 + wr * 128 + 4 * (lane >> 5)) * ldc + (long)tj * T8 + wc * 64 + (lane & 31);
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < 2; n++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) Lg[(long)(m * 32 + (q & 3) + 8 * (q >> 2)) * ldc + n * 32] = acc[m][n][q];
+}
+
+// sum_g 256^-level_g L_g[.] in fp64: groups are listed by ascending level; the smallest terms are added first (fixed order)
+__device__ __forceinline__ double w8_levels(const int32_t* __restrict__ L, long img_elems, long off, const W8Group* __restrict__ groups, int ngroups) {
+    double s = 0.0;
+    for (int g = ngroups - 1; g >= 0; g--) s += ldexp((double)L[(long)g * img_elems + off], -8 * groups[g].level);
+    return s;
+}
+
+// X[j][k] for the rows [row0, row0 + gridDim.y) of X's image (see the head of the file)
+// (Va and X may be the same buffer: every element is read, then written, by one thread)
+__global__ __launch_bounds__(256) void k_w8_combine1(const double* __restrict__ Sa, const double* Va, long np, const double* __restrict__ dS,
+                                                     const double* __restrict__ dV, const int* __restrict__ eS, const int* __restrict__ eV,
+                                                     const int32_t* __restrict__ L, long img_elems, const W8Group* __restrict__ groups, int ngroups,
+                                                     long row0, double* X) {
+    const long k = (long)blockIdx.x * 256 + threadIdx.x, j = row0 + blockIdx.y;
+    const double g = ldexp(w8_levels(L, img_elems, (long)blockIdx.y * np + k, groups, ngroups), eS[j] + eV[k] + 4);
+    double x;
+    if (j == k) x = dS[j] * dV[j] + g;
+    else x = (dS[j] * Va[j * np + k] + Sa[j * np + k] * dV[k]) + g;
+    X[j * np + k] = x;
+}
+
+// The folded image of W from its upper triangle: Wu[i][j] = 2 W[i][j] (i < j), W[i][i], 0 below; one block per 32 x 32 tile.
+// (Sa and Wu may be the same buffer: an element above the diagonal is read, then written, by one thread; nothing below it is read)
+__global__ __launch_bounds__(256) void k_w8_combine2(const double* Sa, const double* __restrict__ X, long np, const double* __restrict__ dS,
+                                                     const double* __restrict__ dX, const int* __restrict__ eS, const int* __restrict__ eX,
+                                                     const int32_t* __restrict__ L, long img_elems, const W8Group* __restrict__ groups, int ngroups,
+                                                     long row0, double* Wu) {
+    const long bi = (long)blockIdx.y + row0 / 32, bj = blockIdx.x;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    if (bj < bi) {
+        for (int r = ty; r < 32; r += 8) Wu[(bi * 32 + r) * np + bj * 32 + tx] = 0.0;
+        return;
+    }
+    __shared__ double xt[32][33];   // xt[a][b] = X[32 bj + a][32 bi + b]
+    for (int r = ty; r < 32; r += 8) xt[r][tx] = X[(bj * 32 + r) * np + bi * 32 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const long i = bi * 32 + r, j = bj * 32 + tx;
+        double v = 0.0;
+        if (i <= j) {
+            const double g = ldexp(w8_levels(L, img_elems, (i - row0) * np + j, groups, ngroups), eS[i] + eX[j] + 4);
+            if (i == j) v = dS[i] * dX[i] + g;
+            else v = 2.0 * ((dS[i] * xt[tx][r] + Sa[i * np + j] * dX[j]) + g);
+        }
+        Wu[i * np + j] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_w8_fill_ones(double* __restrict__ x, long n, long np) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < np) x[i] = i < n ? 1.0 : 0.0;
+}
+// sum_k |Wu[k][k]| in a fixed order (one block)
+__global__ __launch_bounds__(1024) void k_w8_sumdiag(const double* __restrict__ Wu, long np, double* __restrict__ out) {
+    double s = 0.0;
+    for (long k = threadIdx.x; k < np; k += 1024) s += fabs(Wu[k * np + k]);
+    __shared__ double red[1024];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = red[0];
+}
+// rho_j = 2 (r_j - W_jj): the off-diagonal row sums of the folded image from r = W 1 (see k_marker_shift in eagle_i8mfma.hip)
+__global__ __launch_bounds__(256) void k_w8_rho_from_r(const double* __restrict__ r, const double* __restrict__ Wu, long np, double* __restrict__ rho) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j < np) rho[j] = 2.0 * (r[j] - Wu[j * np + j]);
+}
+extern "C" int eagle_w8_rho(eagle_ctx* ctx, const double* Wu, long n_pad, double* rho, void* stream) {
+    hipLaunchKernelGGL(k_w8_rho_from_r, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const double*)ctx->w8_r, Wu, n_pad, rho);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "k_w8_rho_from_r");
+    return EAGLE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Re-evaluation of single markers against the TRUE W: vara = (S m)^T V (S m) in fp64, 16 markers per pass over a matrix.
+//   out[c][i] = sum_j At[j][i] x[c][j]  (At = row-major image of A^T: out_c = A x_c).  Every (c, i) is summed in a fixed order
+//   (wave w takes j = w, w+4, ..., then the four partial sums in order), whatever else is in the batch.
+// ------------------------------------------------------------------------------------------------
+#define W8_MG 16
+#define W8_TRUE_CHUNK 256
+__global__ __launch_bounds__(256) void k_w8_mgemv(const double* __restrict__ At, long n, long np, const double* __restrict__ X, double* __restrict__ out) {
+    const int c0 = blockIdx.y * W8_MG;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + lane;
+    __shared__ double xs[W8_MG][256];
+    __shared__ double red[4][W8_MG][64];
+    double acc[W8_MG];
+#pragma unroll
+    for (int c = 0; c < W8_MG; c++) acc[c] = 0.0;
+    for (long j0 = 0; j0 < n; j0 += 256) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < W8_MG; c++) xs[c][threadIdx.x] = j0 + threadIdx.x < n ? X[(long)(c0 + c) * np + j0 + threadIdx.x] : 0.0;
+        __syncthreads();
+        const long jend = n - j0 < 256 ? n - j0 : 256;
+        for (long jj = w; jj < jend; jj += 4) {
+            const double a = At[(j0 + jj) * np + i];
+#pragma unroll
+            for (int c = 0; c < W8_MG; c++) acc[c] += a * xs[c][jj];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < W8_MG; c++) red[w][c][lane] = acc[c];
+    __syncthreads();
+    if (w == 0)
+#pragma unroll
+        for (int c = 0; c < W8_MG; c++) out[(long)(c0 + c) * np + i] = (red[0][c][lane] + red[1][c][lane]) + (red[2][c][lane] + red[3][c][lane]);
+}
+// The transposed product: out[c][i] = sum_j At[i][j] x[c][j] (one wave per row i, lanes strided over j, fixed order)
+__global__ __launch_bounds__(256) void k_w8_mgemv_row(const double* __restrict__ At, long n, long np, const double* __restrict__ X, double* __restrict__ out) {
+    const int c0 = blockIdx.y * W8_MG;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 4 + w;
+    double acc[W8_MG];
+#pragma unroll
+    for (int c = 0; c < W8_MG; c++) acc[c] = 0.0;
+    if (i < n)
+        for (long j = lane; j < n; j += 64) {
+            const double a = At[i * np + j];
+#pragma unroll
+            for (int c = 0; c < W8_MG; c++) acc[c] += a * X[(long)(c0 + c) * np + j];
+        }
+#pragma unroll
+    for (int c = 0; c < W8_MG; c++) {
+        double v = acc[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if (lane == 0 && i < np) out[(long)(c0 + c) * np + i] = v;
+    }
+}
+// x[c][j] = (double) rows8[c][j] for c < count, zero rows up to the next multiple of 16
+__global__ __launch_bounds__(256) void k_w8_rows_f64(const int8_t* __restrict__ rows8, long ld, long np, int count, double* __restrict__ X) {
+    const int c = blockIdx.y;
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j < np) X[(long)c * np + j] = c < count ? (double)rows8[(long)c * ld + j] : 0.0;
+}
+// out[dst[c]] = sum_i T[c][i] U[c][i] (one block per marker, fixed order)
+__global__ __launch_bounds__(256) void k_w8_rowdot(const double* __restrict__ T, const double* __restrict__ U, long np, const long* __restrict__ dst,
+                                                   double* __restrict__ out) {
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (long i = threadIdx.x; i < np; i += 256) s += T[(long)c * np + i] * U[(long)c * np + i];
+    __shared__ double red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[dst ? dst[c] : c] = red[0];
+}
+
+// out[dst[c]] = m_c^T S V S m_c = (S^T m_c)^T V (S m_c) for the `count` rows of rows8 (host count), 256 rows at a time through a
+// ctx-owned buffer (images: S m = Sa^T m is the column-type product, S^T m = Sa m the row-type one).
+// S, V: the operands of the last eagle_dev_scan_operands_w8 (still alive: it is the caller's scan).
+extern "C" int eagle_w8_true_vara(eagle_ctx* ctx, const int8_t* rows8, long count, long n_pad, long ld, const long* dst_dev, double* out, void* stream) {
+    if (!ctx->w8_Sa || !ctx->w8_Va || ctx->w8_n <= 0) return eagle_fail(ctx, EAGLE_ERR_ARG, "w8_true_vara: no operands on record");
+    if (count <= 0) return EAGLE_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t need = (size_t)4 * W8_TRUE_CHUNK * n_pad * sizeof(double);
+    if (need > ctx->w8_true_cap) {
+        if (ctx->w8_true_ws) { (void)hipStreamSynchronize(s); (void)hipFree(ctx->w8_true_ws); ctx->w8_true_ws = nullptr; ctx->w8_true_cap = 0; }
+        hipError_t e = hipMalloc(&ctx->w8_true_ws, need);
+        if (e != hipSuccess) return eagle_fail_hip(ctx, e, "w8 re-evaluation buffer");
+        ctx->w8_true_cap = need;
+    }
+    double* X = (double*)ctx->w8_true_ws;
+    double* T = X + (size_t)W8_TRUE_CHUNK * n_pad;
+    double* U = T + (size_t)W8_TRUE_CHUNK * n_pad;
+    double* Tt = U + (size_t)W8_TRUE_CHUNK * n_pad;
+    const long n = ctx->w8_n;
+    for (long c0 = 0; c0 < count; c0 += W8_TRUE_CHUNK) {
+        const int cnt = (int)std::min<long>(W8_TRUE_CHUNK, count - c0);
+        const int capr = (cnt + W8_MG - 1) / W8_MG * W8_MG;
+        hipLaunchKernelGGL(k_w8_rows_f64, dim3((unsigned)((n_pad + 255) / 256), (unsigned)capr), dim3(256), 0, s, rows8 + c0 * ld, ld, n_pad, cnt, X);
+        hipLaunchKernelGGL(k_w8_mgemv, dim3((unsigned)(n_pad / 64), (unsigned)(capr / W8_MG)), dim3(256), 0, s, ctx->w8_Sa, n, n_pad, (const double*)X, T);
+        hipLaunchKernelGGL(k_w8_mgemv, dim3((unsigned)(n_pad / 64), (unsigned)(capr / W8_MG)), dim3(256), 0, s, ctx->w8_Va, n, n_pad, (const double*)T, U);
+        hipLaunchKernelGGL(k_w8_mgemv_row, dim3((unsigned)(n_pad / 4), (unsigned)(capr / W8_MG)), dim3(256), 0, s, ctx->w8_Sa, n, n_pad, (const double*)X, Tt);
+        hipLaunchKernelGGL(k_w8_rowdot, dim3((unsigned)cnt), dim3(256), 0, s, (const double*)Tt, (const double*)U, n_pad, dst_dev ? dst_dev + c0 : nullptr,
+                           dst_dev ? out : out + c0);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "w8_true_vara");
+    return EAGLE_OK;
+}
+// The scan found its certificate overflowing on a W from the int8 engine (degenerate operands): the fp64 products replace the image
+// in place, from the operands on record, and the context forgets the int8 result.
+extern "C" int eagle_w8_redo_f64(eagle_ctx* ctx, long n_pad, void* stream) {
+    if (!ctx->w8_active) return EAGLE_OK;
+    ctx->w8_active = false;
+    ctx->w8_info.declined = 8;
+    return eagle_dev_scan_operands_w_f64(ctx, ctx->w8_Sa, ctx->w8_Va, n_pad, (double*)ctx->w8_Wu, ctx->w8_tmp, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host side: configurations, work lists, the bound, the pipeline.
+// ------------------------------------------------------------------------------------------------
+int w8_config_pairs(const W8Config& c) {
+    int np = 0;
+    for (int p = 1; p <= c.k; p++)
+        for (int q = 1; q <= c.k; q++) np += (p + q <= c.T);
+    return np;
+}
+// accumulation groups of a configuration: pairs of one level, at most maxp per group, levels ascending
+std::vector<W8Group> w8_groups(const W8Config& c, int maxp) {
+    std::vector<W8Group> gs;
+    if (maxp > 8) maxp = 8;
+    for (int t = 2; t <= c.T; t++) {
+        W8Group g = {};
+        g.level = t;
+        for (int p = 1; p <= c.k; p++) {
+            const int q = t - p;
+            if (q < 1 || q > c.k) continue;
+            if (g.npairs == maxp) { gs.push_back(g); g = {}; g.level = t; }
+            g.p[g.npairs] = (unsigned char)(p - 1);
+            g.q[g.npairs] = (unsigned char)(q - 1);
+            g.npairs++;
+        }
+        if (g.npairs) gs.push_back(g);
+    }
+    return gs;
+}
+// The work list of one product over the row tiles [rt0, rt1): per XCD `maxlen` entries (ti << 20 | tj << 8 | group, 0xFFFFFFFF = none).
+// upper: only tiles with tj >= ti.  Units = (4 x 8 super-tile, group), dealt longest first to the XCD with the least work so far.
+void w8_work_list(int nt, int rt0, int rt1, bool upper, const std::vector<W8Group>& gs, std::vector<unsigned>& out, int* maxlen_out) {
+    struct Unit { int cost; std::vector<unsigned> items; };
+    std::vector<Unit> units;
+    for (int si = rt0; si < rt1; si += 4)
+        for (int sj = 0; sj < nt; sj += 8)
+            for (size_t g = 0; g < gs.size(); g++) {
+                Unit u;
+                for (int i = si; i < si + 4 && i < rt1; i++)
+                    for (int j = sj; j < sj + 8 && j < nt; j++)
+                        if (!upper || j >= i) u.items.push_back(((unsigned)i << 20) | ((unsigned)j << 8) | (unsigned)g);
+                if (u.items.empty()) continue;
+                u.cost = (int)u.items.size() * gs[g].npairs;
+                units.push_back(std::move(u));
+            }
+    std::stable_sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.cost > b.cost; });
+    std::vector<unsigned> lists[8];
+    long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (const Unit& u : units) {
+        int best = 0;
+        for (int x = 1; x < 8; x++) if (load[x] < load[best]) best = x;
+        load[best] += u.cost;
+        lists[best].insert(lists[best].end(), u.items.begin(), u.items.end());
+    }
+    size_t maxlen = 0;
+    for (int x = 0; x < 8; x++) maxlen = std::max(maxlen, lists[x].size());
+    out.assign(8 * maxlen, 0xFFFFFFFFu);
+    for (int x = 0; x < 8; x++) std::copy(lists[x].begin(), lists[x].end(), out.begin() + x * maxlen);
+    *maxlen_out = (int)maxlen;
+}
+
+// || G - G_computed ||_F of a product A B^T under configuration c (see the head of the file); every step rounded up
+double w8_product_bound(const W8Stats& A, const W8Stats& B, const W8Config& c, long np) {
+    const double up = 1.0 + 1e-9;
+    double phiA[W8_KMAX], phiB[W8_KMAX];
+    for (int p = 0; p < W8_KMAX; p++) { phiA[p] = sqrt(A.phi2[p] * up) * up; phiB[p] = sqrt(B.phi2[p] * up) * up; }
+    double drop = 0.0;
+    for (int p = 1; p <= W8_KMAX; p++)
+        for (int q = 1; q <= W8_KMAX; q++)
+            if (!(p <= c.k && q <= c.k && p + q <= c.T)) drop += ldexp(phiA[p - 1] * phiB[q - 1], -8 * (p + q)) * up;
+    const double TA = sqrt((double)np * A.es2 * up) * ldexp(1.0, -8 * W8_KMAX - 1) * up;
+    const double TB = sqrt((double)np * B.es2 * up) * ldexp(1.0, -8 * W8_KMAX - 1) * up;
+    const double fA = sqrt(A.fro2 * up) * up, fB = sqrt(B.fro2 * up) * up;
+    return (drop + TA * (fB + TB) + fA * TB) * up;
+}
+
+static const W8Config W8_CONFIGS[] = {{3, 4}, {3, 5}, {4, 5}, {4, 6}, {5, 6}, {5, 7}, {6, 7}, {6, 8}, {6, 9}, {6, 12}};
+static const int W8_NCONFIGS = (int)(sizeof(W8_CONFIGS) / sizeof(W8_CONFIGS[0]));
+// cheapest configuration whose bound is <= limit (-1: none)
+static int w8_choose(const W8Stats& A, const W8Stats& B, long np, double limit, double* bound_out) {
+    int best = -1, best_pairs = 1 << 30;
+    double best_b = 0.0;
+    for (int c = 0; c < W8_NCONFIGS; c++) {
+        const double b = w8_product_bound(A, B, W8_CONFIGS[c], np);
+        const int pairs = w8_config_pairs(W8_CONFIGS[c]);
+        if (getenv("EAGLE_HIP_W8_DEBUG")) fprintf(stderr, "[eaglehip w8] config (%d,%d) %d pairs: bound %.3e (limit %.3e)\n", W8_CONFIGS[c].k, W8_CONFIGS[c].T, pairs, b, limit);
+        if (b <= limit && pairs < best_pairs) { best = c; best_pairs = pairs; best_b = b; }
+    }
+    if (bound_out) *bound_out = best_b;
+    return best;
+}
+
+struct W8List { unsigned* work = nullptr; W8Group* groups = nullptr; int maxlen = 0, ngroups = 0; };
+static std::map<std::tuple<int, int, int, int, int, int, int>, W8List> g_w8_lists;   // (device, nt, rt0, rt1, upper, config, maxp)
+static std::mutex g_w8_mutex;
+static int w8_get_list(eagle_ctx* ctx, int nt, int rt0, int rt1, bool upper, int cfg, int maxp, W8List* out) {
+    std::lock_guard<std::mutex> lock(g_w8_mutex);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    auto key = std::make_tuple(dev, nt, rt0, rt1, upper ? 1 : 0, cfg, maxp);
+    auto it = g_w8_lists.find(key);
+    if (it != g_w8_lists.end()) { *out = it->second; return EAGLE_OK; }
+    const std::vector<W8Group> gs = w8_groups(W8_CONFIGS[cfg], maxp);
+    std::vector<unsigned> wl;
+    W8List l;
+    w8_work_list(nt, rt0, rt1, upper, gs, wl, &l.maxlen);
+    l.ngroups = (int)gs.size();
+    hipError_t e = hipMalloc((void**)&l.work, wl.size() * sizeof(unsigned) + 16);
+    if (e == hipSuccess) e = hipMalloc((void**)&l.groups, gs.size() * sizeof(W8Group));
+    if (e == hipSuccess) e = hipMemcpy(l.work, wl.data(), wl.size() * sizeof(unsigned), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(l.groups, gs.data(), gs.size() * sizeof(W8Group), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (l.work) (void)hipFree(l.work);
+        if (l.groups) (void)hipFree(l.groups);
+        return eagle_fail_hip(ctx, e, "w8 work list");
+    }
+    g_w8_lists[key] = l;
+    *out = l;
+    return EAGLE_OK;
+}
+
+// workspace: [ slices A: 6 n^2 | slices B: 6 n^2 | levels | per-matrix vectors ... ]
+struct W8Ws {
+    int8_t *sA, *sB;
+    int32_t* levels; size_t level_bytes;
+    double *dS, *mxS, *ssqS, *dV, *mxV, *ssqV, *dX, *mxX, *ssqX, *r, *r1, *r2, *sumdiag;
+    int *eS, *eV, *eX, *bad;
+    unsigned long long *dssqS, *dssqV, *dssqX, *asym;
+    W8Stats* stats;  // [3] device
+};
+static size_t r256(size_t x) { return (x + 255) / 256 * 256; }
+#define W8_LEVEL_CAP ((size_t)3500 << 20)
+static int w8_workspace(eagle_ctx* ctx, long np, W8Ws* w) {
+    const size_t nn = (size_t)np * np;
+    const size_t full_levels = 12 * nn * sizeof(int32_t);   // the largest configuration: 11 levels (+ splits at very large n)
+    const size_t level_bytes = full_levels < W8_LEVEL_CAP ? full_levels : W8_LEVEL_CAP;
+    const size_t vec = r256(sizeof(double) * (size_t)np), dss = r256(sizeof(unsigned long long) * W8_KMAX * (size_t)np);
+    const size_t need = 2 * r256(W8_KMAX * nn) + r256(level_bytes) + 13 * vec + 4 * vec + 3 * dss + 4096;
+    if (need > ctx->w8_ws_cap) {
+        if (ctx->w8_ws) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->w8_ws); ctx->w8_ws = nullptr; ctx->w8_ws_cap = 0; }
+        if (hipMalloc(&ctx->w8_ws, need) != hipSuccess) { (void)hipGetLastError(); ctx->w8_ws = nullptr; return 1; }   // no room: decline
+        ctx->w8_ws_cap = need;
+    }
+    char* p = (char*)ctx->w8_ws;
+    auto take = [&](size_t b) { char* q = p; p += r256(b); return q; };
+    w->sA = (int8_t*)take(W8_KMAX * nn);
+    w->sB = (int8_t*)take(W8_KMAX * nn);
+    w->levels = (int32_t*)take(level_bytes);
+    w->level_bytes = level_bytes;
+    double** dv[] = {&w->dS, &w->mxS, &w->ssqS, &w->dV, &w->mxV, &w->ssqV, &w->dX, &w->mxX, &w->ssqX, &w->r, &w->r1, &w->r2, &w->sumdiag};
+    for (double** x : dv) *x = (double*)take(vec);
+    int** iv[] = {&w->eS, &w->eV, &w->eX, &w->bad};
+    for (int** x : iv) *x = (int*)take(vec);
+    unsigned long long** uv[] = {&w->dssqS, &w->dssqV, &w->dssqX};
+    for (unsigned long long** x : uv) *x = (unsigned long long*)take(dss);
+    w->asym = (unsigned long long*)take(256);
+    w->stats = (W8Stats*)take(3 * sizeof(W8Stats));
+    return 0;
+}
+
+// statistics + digit slices of one operand; sym_out != NULL: of its symmetrised copy, made here first (max |M - M^T| into the statistics)
+static int w8_stats_of(eagle_ctx* ctx, const double* M, long np, double* d, double* mx, double* ssq, int* e, unsigned long long* dssq, int8_t* slices,
+                       const double* d2, double* sym_out, W8Ws& w, W8Stats* out_dev, hipStream_t s) {
+    hipError_t er = hipMemsetAsync(w.bad, 0, sizeof(int), s);
+    if (er == hipSuccess) er = hipMemsetAsync(w.asym, 0, sizeof(unsigned long long), s);
+    if (er != hipSuccess) return eagle_fail_hip(ctx, er, "w8 memset");
+    if (sym_out) {
+        hipLaunchKernelGGL(k_w8_symmetrize, dim3((unsigned)(np / 32), (unsigned)(np / 32)), dim3(256), 0, s, M, np, sym_out, w.asym);
+        M = sym_out;
+    }
+    hipLaunchKernelGGL(k_w8_rowstats, dim3((unsigned)np), dim3(256), 0, s, M, np, d, mx, ssq, w.bad);
+    hipLaunchKernelGGL(k_w8_slice, dim3((unsigned)np), dim3(256), 0, s, M, np, mx, slices, np * np, dssq, e);
+    hipLaunchKernelGGL(k_w8_reduce, dim3(1), dim3(1024), 0, s, np, d, mx, ssq, e, dssq, d2, w.bad, sym_out ? w.asym : nullptr, out_dev);
+    er = hipGetLastError();
+    if (er != hipSuccess) return eagle_fail_hip(ctx, er, "w8 statistics");
+    return EAGLE_OK;
+}
+
+static int w8_product(eagle_ctx* ctx, int cfg, bool upper, long np, const int8_t* sA, const int8_t* sB, W8Ws& w, hipStream_t s,
+                      const std::function<void(const W8List&, long, long, long)>& combine) {
+    const int nt = (int)(np / T8);
+    int maxp = (int)(131071 / np);
+    if (maxp < 1) return 1;
+    if (maxp > 8) maxp = 8;
+    const int ngroups = (int)w8_groups(W8_CONFIGS[cfg], maxp).size();
+    // rows per panel so that the level images of all groups fit
+    long rt_per_panel = (long)(w.level_bytes / ((size_t)ngroups * T8 * np * sizeof(int32_t)));
+    if (rt_per_panel < 1) return 1;
+    if (rt_per_panel >= nt) rt_per_panel = nt;
+    else if (rt_per_panel > 4) rt_per_panel = rt_per_panel / 4 * 4;   // whole super-tile rows
+    for (int rt0 = 0; rt0 < nt; rt0 += (int)rt_per_panel) {
+        const int rt1 = (int)std::min<long>(nt, rt0 + rt_per_panel);
+        W8List l;
+        int rc = w8_get_list(ctx, nt, rt0, rt1, upper, cfg, maxp, &l);
+        if (rc) return rc;
+        const long img_elems = (long)(rt1 - rt0) * T8 * np;
+        hipLaunchKernelGGL(k_w8_gemm, dim3((unsigned)(8 * l.maxlen)), dim3(512), 0, s, sA, sB, np * np, np, (const unsigned*)l.work, l.maxlen,
+                           (const W8Group*)l.groups, w.levels, img_elems, np, rt0, (int)(np / BK8));
+        combine(l, img_elems, (long)rt0 * T8, (long)(rt1 - rt0) * T8);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "w8 product");
+    return EAGLE_OK;
+}
+
+static int w8_fetch(eagle_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t s) {
+    if (!ctx->w8_host) {
+        hipError_t e = hipHostMalloc((void**)&ctx->w8_host, 4096, hipHostMallocDefault);
+        if (e != hipSuccess) return eagle_fail_hip(ctx, e, "w8 pinned block");
+    }
+    hipError_t e = hipMemcpyAsync(ctx->w8_host, src, bytes, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return eagle_fail_hip(ctx, e, "w8 statistics to the host");
+    memcpy(dst, ctx->w8_host, bytes);
+    return EAGLE_OK;
+}
+
+// Returns EAGLE_OK (Wu_out, v_out written; ctx->w8_* describe the result), 1 = declined (nothing of value written: run the fp64
+// products), or an error.
+extern "C" int eagle_dev_scan_operands_w8(eagle_ctx* ctx, const double* Sa, const double* Va, const double* ahat, long n, long np, double* v_out,
+                                          double* Wu_out, double* tmp, void* stream) {
+    ctx->w8_active = false;
+    ctx->w8_eta = 0.0;
+    ctx->w8_info = W8Info();
+    if (np % T8 || n > np || n <= 0 || (double)np * T8 >= 2147483648.0 || np / T8 > 4095) return 1;
+    hipStream_t s = (hipStream_t)stream;
+    W8Ws w;
+    if (w8_workspace(ctx, np, &w)) { ctx->w8_info.declined = 5; return 1; }
+    int rc = eagle_dev_scan_operands_begin(ctx, Sa, ahat, n, np, v_out, tmp, stream);
+    if (rc) return rc;
+    // symmetrised copies: S_s in the output buffer (its upper part is overwritten element by element when the folded W is written),
+    // V_s in tmp (overwritten the same way by X); statistics + digit slices of their off-diagonal parts F, Fv
+    double* Ss = Wu_out;
+    double* Vs = tmp;
+    rc = w8_stats_of(ctx, Sa, np, w.dS, w.mxS, w.ssqS, w.eS, w.dssqS, w.sA, nullptr, Ss, w, w.stats + 0, s);
+    if (!rc) rc = w8_stats_of(ctx, Va, np, w.dV, w.mxV, w.ssqV, w.eV, w.dssqV, w.sB, w.dS, Vs, w, w.stats + 1, s);
+    if (rc) return rc;
+    // r = S_s (V_s (S_s 1)): the row sums of W in fp64, while the symmetrised copies are whole
+    hipLaunchKernelGGL(k_w8_fill_ones, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, w.r2, n, np);
+    rc = eagle_dev_colgemv(ctx, Ss, n, np, w.r2, w.r1, stream);
+    if (!rc) rc = eagle_dev_colgemv(ctx, Vs, n, np, w.r1, w.r2, stream);
+    if (!rc) rc = eagle_dev_colgemv(ctx, Ss, n, np, w.r2, w.r, stream);
+    if (rc) return rc;
+    W8Stats st[3];
+    if ((rc = w8_fetch(ctx, st, w.stats, 2 * sizeof(W8Stats), s))) return rc;
+    W8Info info;
+    if (st[0].bad || st[1].bad) { info.declined = 1; ctx->w8_info = info; return 1; }
+    const double up = 1.0 + 1e-9;
+    const double normS = (st[0].maxd + sqrt(st[0].fro2 * up)) * up, normV = (st[1].maxd + sqrt(st[1].fro2 * up)) * up;
+    const double wd_est = st[1].wdsum / (double)n;               // mean_k |W_kk| ~ mean_k D_k^2 |Dv_k|
+    const double target = W8_TARGET * ctx->scan_budget * wd_est;
+    // operands symmetric to rounding only (as the fp64 path asks of its symmetric pipeline); what the antisymmetric parts
+    // A = (S - S^T)/2, B = (V - V^T)/2 still change in the symmetric part of S V S is second order: A V A + A B S + S B A + A B A
+    if (!(st[0].asym <= 1e-12 * st[0].maxd) || !(st[1].asym <= 1e-12 * st[1].maxd)) { info.declined = 2; ctx->w8_info = info; return 1; }
+    const double nA = 0.5 * (double)np * st[0].asym, nB = 0.5 * (double)np * st[1].asym;
+    const double asym = (nA * nA * normV + 2.0 * nA * nB * normS + nA * nA * nB) * up;
+    info.asym_term = asym;
+    if (!(target > 0.0) || !(asym <= 0.25 * target)) { info.declined = 2; ctx->w8_info = info; return 1; }
+    double b1 = 0.0;
+    const int c1 = w8_choose(st[0], st[1], np, 0.4 * (target - asym) / (normS * M_SQRT2), &b1);
+    if (c1 < 0) { info.declined = 3; ctx->w8_info = info; return 1; }
+    const W8Group* groups_dev = nullptr;
+    rc = w8_product(ctx, c1, false, np, w.sA, w.sB, w, s, [&](const W8List& l, long img, long row0, long rows) {
+        hipLaunchKernelGGL(k_w8_combine1, dim3((unsigned)(np / 256), (unsigned)rows), dim3(256), 0, s, (const double*)Ss, (const double*)Vs, np, (const double*)w.dS, (const double*)w.dV,
+                           (const int*)w.eS, (const int*)w.eV, (const int32_t*)w.levels, img, (const W8Group*)l.groups, l.ngroups, row0, tmp);
+    });
+    (void)groups_dev;
+    if (rc) { if (rc == 1) { info.declined = 5; ctx->w8_info = info; } return rc; }
+    // X = tmp: statistics + slices (over Fv's)
+    rc = w8_stats_of(ctx, tmp, np, w.dX, w.mxX, w.ssqX, w.eX, w.dssqX, w.sB, nullptr, nullptr, w, w.stats + 2, s);
+    if (rc) return rc;
+    if ((rc = w8_fetch(ctx, st + 2, w.stats + 2, sizeof(W8Stats), s))) return rc;
+    if (st[2].bad) { info.declined = 1; ctx->w8_info = info; return 1; }
+    // rounding of the element-wise terms and the level sums of X: a handful of roundings on terms of these sizes
+    const double fS = sqrt(st[0].fro2 * up) * up, fV = sqrt(st[1].fro2 * up) * up, fX = sqrt(st[2].fro2 * up) * up;
+    const double round1 = ldexp(st[0].maxd * fV + fS * st[1].maxd + fS * fV + st[0].maxd * st[1].maxd * sqrt((double)np), -49);
+    const double etaX = (b1 + round1) * up;
+    const double used = (normS * etaX * M_SQRT2 + asym) * up;
+    double b2 = 0.0;
+    const int c2 = w8_choose(st[0], st[2], np, (target - used) / M_SQRT2 * 0.98, &b2);
+    if (c2 < 0) { info.declined = 4; ctx->w8_info = info; return 1; }
+    rc = w8_product(ctx, c2, true, np, w.sA, w.sB, w, s, [&](const W8List& l, long img, long row0, long rows) {
+        hipLaunchKernelGGL(k_w8_combine2, dim3((unsigned)(np / 32), (unsigned)(rows / 32)), dim3(256), 0, s, (const double*)Ss, (const double*)tmp, np, (const double*)w.dS,
+                           (const double*)w.dX, (const int*)w.eS, (const int*)w.eX, (const int32_t*)w.levels, img, (const W8Group*)l.groups, l.ngroups, row0,
+                           Wu_out);
+    });
+    if (rc) { if (rc == 1) { info.declined = 5; ctx->w8_info = info; } return rc; }
+    const double round2 = ldexp(st[0].maxd * fX + fS * st[2].maxd + fS * fX + st[0].maxd * st[2].maxd * sqrt((double)np), -49);
+    const double eta = ((normS * etaX + b2 + round2) * M_SQRT2 + asym) * up;
+    // the a-posteriori check against the diagonal of the W just made
+    hipLaunchKernelGGL(k_w8_sumdiag, dim3(1), dim3(1024), 0, s, (const double*)Wu_out, np, w.sumdiag);
+    double sumdiag = 0.0;
+    if ((rc = w8_fetch(ctx, &sumdiag, w.sumdiag, sizeof(double), s))) return rc;
+    info.config1 = c1; info.config2 = c2;
+    info.k1 = W8_CONFIGS[c1].k; info.T1 = W8_CONFIGS[c1].T; info.k2 = W8_CONFIGS[c2].k; info.T2 = W8_CONFIGS[c2].T;
+    info.pairs1 = w8_config_pairs(W8_CONFIGS[c1]); info.pairs2 = w8_config_pairs(W8_CONFIGS[c2]);
+    info.eta = eta; info.eta_x = etaX; info.bound1 = b1; info.bound2 = b2; info.norm_s = normS; info.target = target;
+    info.mean_diag = sumdiag / (double)n;
+    if (!(eta <= W8_ACCEPT * ctx->scan_budget * info.mean_diag)) { info.declined = 6; ctx->w8_info = info; return 1; }
+    ctx->w8_info = info;
+    ctx->w8_active = true;
+    ctx->w8_eta = eta;
+    ctx->w8_r = w.r;
+    ctx->w8_Wu = Wu_out;
+    ctx->w8_Sa = Sa;
+    ctx->w8_Va = Va;
+    ctx->w8_n = n;
+    ctx->w8_tmp = tmp;
+    return EAGLE_OK;
+}

@@ -151,6 +151,7 @@ class DeviceShard:
         self.nslices = 0  # 0 = chosen by the library from its error bound
         self.stochastic = False  # digits of W rounded at random (eagle_set_scan_rounding): probabilistic certificate, one digit fewer
         self.extend = True       # eagle_dev_vara_i8_extend after the vara kernel (tests switch it off to see the raw values)
+        self.w_mode = 1          # eagle_set_w_mode for the digit-slice scan: 1 = W on the int8 engine from 4,096 padded individuals up, 0 = fp64 GEMM, 2 = int8 always
 
     # ---- plumbing -------------------------------------------------------------------------------
     def _stream(self):
@@ -296,9 +297,23 @@ class DeviceShard:
             coll.all_gather_rows(self.Wu, mine)
             self._check(self.L.eagle_dev_fold_upper(self.ctx, self.Wu.data_ptr(), self.np_, self._stream()))
             return
+        # W from int8 digit slices only feeds the digit-slice scan, whose certificate carries its error bound (csrc/eagle_w8.hip)
+        self._check(self.L.eagle_set_w_mode(self.ctx, int(self.w_mode) if self.mode == 1 else 0))
         self._check(self.L.eagle_dev_scan_operands(self.ctx, self.Sa.data_ptr(), self.Va.data_ptr(), self.ahat.data_ptr(),
                                                    self.n, self.np_, self.v.data_ptr(), self.Wu.data_ptr(),
                                                    self.tmp.data_ptr(), self._stream()))
+
+    def w_info(self):
+        """eagle_last_w_info as a dict: which engine formed the last W, its configuration and error bound."""
+        import ctypes as C
+
+        class Info(C.Structure):
+            _fields_ = [("int8", C.c_int), ("declined", C.c_int), ("k1", C.c_int), ("T1", C.c_int), ("pairs1", C.c_int), ("k2", C.c_int),
+                        ("T2", C.c_int), ("pairs2", C.c_int), ("eta", C.c_double), ("eta_x", C.c_double), ("target", C.c_double),
+                        ("mean_diag", C.c_double), ("asym_term", C.c_double)]
+        i = Info()
+        self._check(self.L.eagle_last_w_info(self.ctx, C.byref(i)))
+        return {k: getattr(i, k) for k, _ in Info._fields_}
 
     def gemv_a(self):
         self._check(self.L.eagle_dev_gemv_i8(self.ctx, self.Mt8.data_ptr(), self.Lp, self.np_, self.np_, self.v.data_ptr(),

@@ -100,6 +100,29 @@ int eagle_set_scan_budget(eagle_ctx* ctx, double relative_budget);
  * device-resident entry points the same switch is bit 8 of the `nslices` argument (EAGLE_SLICES_STOCHASTIC). */
 #define EAGLE_SLICES_STOCHASTIC 0x100
 int eagle_set_scan_rounding(eagle_ctx* ctx, int stochastic);
+/* Round 4.  Which engine forms W = S (V S) for a digit-slice scan (calculate_a_and_vara_rcpp.cpp:97-98).  1 (default): from 4,096
+ * padded individuals up, the two n^3 products run on the int8 MFMA from exact base-256 digit slices of the off-diagonal parts of S, V
+ * and X = V S (diagonal parts exactly, in fp64), under a rigorous Frobenius-norm bound eta of the error of the W delivered; the scan's
+ * per-marker certificate adds eta * sum_j m'_ij^2 to its bound, the correction vector of the re-centred markers comes from
+ * r = S (V (S 1)) in fp64, and the markers the certificate re-evaluates are computed as (S m)^T V (S m) in fp64.  A call whose
+ * operands the configurations on offer cannot certify to 2 % of the digit budget (wild scaling, cancelling V, non-finite or visibly
+ * asymmetric matrices, no workspace) DECLINES and the fp64 GEMM runs as before.  0: always the fp64 GEMM.  2: the int8 engine at any
+ * size (tests).  eagle_set_scan_mode(0) never uses it.  csrc/eagle_w8.hip. */
+int eagle_set_w_mode(eagle_ctx* ctx, int mode);
+typedef struct eagle_w_info {
+    int int8;            /* 1: the W of the last scan_operands call came from the int8 engine */
+    int declined;        /* else why not: 1 non-finite, 2 asymmetric / no yardstick, 3 / 4 no configuration for V S / S X, 5 no workspace,
+                            6 the finished W failed the check against its own diagonal, 7 switched off or too small, 8 replaced by the fp64
+                            products after the certificate overflowed */
+    int k1, T1, pairs1;  /* V S: digits per operand, highest level p + q, int8 products (n_pad^3 MACs each) */
+    int k2, T2, pairs2;  /* S X (upper triangle only) */
+    double eta;          /* || folded W - truth ||_F bound; a marker's vara carries eta * sum_j m'_j^2 of it */
+    double eta_x;        /* || X computed - V S ||_F bound */
+    double target;       /* what the configurations were chosen for (0.02 x budget x estimate of mean |W_kk|) */
+    double mean_diag;    /* mean |W_kk| of the W delivered */
+    double asym_term;    /* share of eta that pays for max |S - S^T|, max |V - V^T| */
+} eagle_w_info;
+int eagle_last_w_info(eagle_ctx* ctx, eagle_w_info* out);
 
 /* ---------------------------------------------------------------------------------------------
  * 1. Reference-shaped entry points (host pointers, files on disk)

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""W = S (V S) on the int8 engine (csrc/eagle_w8.hip) against the fp64 GEMM, on operands from the model algebra on an actual MM^T:
+error of the folded image against its bound, timings of both engines, and the scan that follows (vara, selected marker)."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import bench
+from eagleeverything_amd import _lib
+from eagleeverything_amd.sharded import DeviceShard
+
+n = int(os.environ.get("N", 4096))
+L = int(os.environ.get("L", 65536))
+reps = int(os.environ.get("REPS", 3))
+budget = float(os.environ.get("BUDGET", 5e-7))
+lib = _lib.load()
+sh = DeviceShard(n, L)
+sh.fill_synthetic()
+c32 = sh.mmt_partial()
+MMt, mx = sh.mmt_finish(c32, normalise=True)
+del c32
+gen = torch.Generator(device=sh.dev); gen.manual_seed(7)
+y = torch.randn(n, generator=gen, device=sh.dev, dtype=torch.float64)
+X = torch.ones((n, 1), dtype=torch.float64, device=sh.dev)
+S, V, ahat, P, _ = bench.host_operands_torch(torch, MMt, X, y, 1.0, 0.5)
+del MMt, P
+sh.set_operands(S, V, ahat)
+sh._check(lib.eagle_set_scan_budget(sh.ctx, budget))
+sh.mode = 1
+out = {"n": n, "L": L, "budget": budget}
+
+def timed(fn, reps):
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return ts
+
+res = {}
+for wm in (0, 2):
+    sh.w_mode = wm
+    ts = timed(sh.scan_operands, reps + 1)
+    info = sh.w_info()
+    Wu = sh.Wu.clone()
+    sh.scan()
+    bi = sh.best()
+    res[wm] = {"Wu": Wu, "vara": sh.vara[:L].clone(), "a": sh.a[:L].clone(), "best": bi, "ms": ts, "info": info}
+    out["w_mode_%d" % wm] = {"ms": [round(t, 3) for t in ts], "info": info, "best": [float(bi[0]), int(bi[1])]}
+    again = timed(sh.scan_operands, 1)
+    assert torch.equal(Wu, sh.Wu), "W is not reproducible"
+d = res[2]["Wu"] - res[0]["Wu"]
+# the folded image holds 2 W_jk above the diagonal: the symmetric matrix it stands for has || . ||_F^2 = sum diag^2 + 2 sum_{j<k} (d_jk/2)^2
+dd = torch.diagonal(d)
+fro = float(torch.sqrt((dd * dd).sum() + 0.5 * ((d * d).sum() - (dd * dd).sum())))
+spec = None
+out["err_fro"] = fro
+out["err_spec"] = spec
+out["eta"] = res[2]["info"]["eta"]
+out["mean_diag"] = res[2]["info"]["mean_diag"]
+out["err_fro_over_eta"] = fro / res[2]["info"]["eta"] if res[2]["info"]["eta"] else None
+v0, v2 = res[0]["vara"], res[2]["vara"]
+out["vara_max_rel_diff"] = float(((v2 - v0).abs() / v0.abs().clamp_min(1e-300)).max())
+out["a_equal"] = bool(torch.equal(res[0]["a"], res[2]["a"]))
+out["same_marker"] = res[0]["best"][1] == res[2]["best"][1]
+print(json.dumps(out))
