@@ -128,6 +128,9 @@ SIGNATURES = {
                                        C.c_void_p]),
     # internal helpers exported for tests / the sharded driver
     "eagle_dev_set_tune": (None, [C.c_void_p, C.c_int]),
+    "eagle_w8_host_work_list": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_long,
+                                          C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_int)]),
+    "eagle_w8_host_bound": (C.c_double, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long]),
     "eagle_dev_set_spectral": (None, [C.c_void_p, C.c_int]),
     "eagle_dev_gemm_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]),
     "eagle_dev_colgemv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p]),

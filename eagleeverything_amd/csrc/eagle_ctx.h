@@ -81,7 +81,7 @@ struct eagle_ctx {
     void* stage_pin[2] = {nullptr, nullptr}; void* stage_raw[2] = {nullptr, nullptr}; size_t stage_cap = 0;  // tile streamer
     // per-device launch state (a process may hold one ctx per GPU): dynamic-LDS attributes set on this device, schedule
     // experiment switch of tools/bench_i8_engine.py (0 = shipped)
-    bool attr_vara_i8 = false, attr_vara_i8w = false, attr_vara_i8p = false, attr_vara_i8pp = false, attr_vara_i8px = false, attr_syrk_f4w = false, attr_zbuild_i8 = false, attr_vara_f6 = false, attr_gemv = false;
+    bool attr_vara_i8 = false, attr_vara_i8w = false, attr_vara_i8p = false, attr_vara_i8pp = false, attr_vara_i8px = false, attr_syrk_f4w = false, attr_zbuild_i8 = false, attr_vara_f6 = false, attr_gemv = false, attr_w8_gemm = false;
     int tune = 0;
     // W = S (V S) on the int8 engine (eagle_w8.hip): workspace, and what the last call left for the scan that follows it
     int w_mode = 1;            // 0 = always the fp64 GEMM, 1 = int8 digit slices from 4,096 padded individuals up, 2 = int8 at any size (tests)

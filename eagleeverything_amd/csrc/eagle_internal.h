@@ -22,6 +22,7 @@ int eagle_dev_scan_operands_w_f64(eagle_ctx* ctx, const double* Sa, const double
 // W = S (V S) from int8 digit slices (eagle_w8.hip): EAGLE_OK, 1 = declined (run the fp64 products), < 0 error
 int eagle_dev_scan_operands_w8(eagle_ctx* ctx, const double* Sa, const double* Va, const double* ahat, long n, long n_pad, double* v_out, double* Wu_out,
                                double* tmp, void* stream);
+int eagle_dev_colgemv_parts(eagle_ctx* ctx, const double* At, long n, long n_pad, const double* x, double* out, double* part, void* stream);
 int eagle_w8_rho(eagle_ctx* ctx, const double* Wu, long n_pad, double* rho, void* stream);
 int eagle_w8_true_vara(eagle_ctx* ctx, const int8_t* rows8, long count, long n_pad, long ld, const long* dst_dev, double* out, void* stream);
 int eagle_w8_redo_f64(eagle_ctx* ctx, long n_pad, void* stream);

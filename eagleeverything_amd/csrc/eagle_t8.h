@@ -128,4 +128,116 @@ __device__ __forceinline__ int w_scale_exp(double mx) {
     return e;
 }
 
+
+// ---- the 384 x 256 tile and its asm-pipelined k-step (k_vara_i8p, k_syrk_f4w, k_w8_gemm) ----
+#define TW_M 384
+#define TW_ABYTES (TW_M * BK8)
+__device__ __forceinline__ void tw_kstep(i32x16 (&acc)[3][4], const int8_t* pa, const int8_t* pb, int ch) {
+    i32x4 a[3], b[4];
+#pragma unroll
+    for (int m = 0; m < 3; m++) a[m] = *(const i32x4*)(pa + m * (32 * BK8) + ch);
+#pragma unroll
+    for (int n = 0; n < 4; n++) b[n] = *(const i32x4*)(pb + n * (32 * BK8) + ch);
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+#pragma unroll
+        for (int n = 0; n < 4; n++) acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], b[n], acc[m][n], 0, 0, 0);
+}
+// vara_tail_pieces (pieces per worker of an XCD's last, partly filled round): eagle_host.h
+// `groups` row groups (8 rows each) of an operand tile per wave: wave w issues groups w*groups .. (groups is even)
+template <int GROUPS>
+__device__ __forceinline__ void tw_stage(__amdgpu_buffer_rsrc_t rs, const T8Lane& ln, int ld, int k0, int8_t* ldsTile, int w) {
+#pragma unroll
+    for (int i = 0; i < GROUPS; i++) {
+        const int grp = w * GROUPS + i;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(ldsTile + grp * 1024), 16,
+                                                 (i & 1) ? ln.voffO : ln.voffE, grp * 8 * ld + k0, 0, 0);
+    }
+}
+// SrcA = the W-digit fragment b, SrcB = the genotype fragment a: the matrix unit draws far less power when its SrcB operand is the
+// low-entropy one (tools/ubench/mfma_ceiling.hip: a bare loop on these operand statistics holds 3.75 POP/s this way round,
+// 3.29 POP/s the other), and this kernel runs against the power limit.  The 32 x 32 result tiles come out transposed: lane =
+// marker, register = W column.
+#define X_MF(c, a, b) "v_mfma_i32_32x32x32_i8 %[" #c "], %[" #b "], %[" #a "], %[" #c "]\n\t"
+#define X_MZ(c, a, b) "v_mfma_i32_32x32x32_i8 %[" #c "], %[" #b "], %[" #a "], 0\n\t"
+#define X_LD(d, p, off) "ds_read_b128 %[" #d "], %[" #p "] offset:" #off "\n\t"
+#define X_WT(n) "s_waitcnt lgkmcnt(" #n ")\n\t"
+// one LDS-DMA load of the stage being fetched, operand set s (a = genotype rows, b = W-digit rows): next row group
+// (LDS +1 KiB, source + 8 rows), even / odd group lane offsets
+// (the asm statements that use it declare the "scc" clobber: s_add_u32 writes SCC, and hipcc keeps compare results live across asm)
+#define X_DM(vo, s) "s_add_u32 %[m0" #s "], %[m0" #s "], 0x400\n\ts_mov_b32 m0, %[m0" #s "]\n\ts_add_u32 %[so" #s "], %[so" #s "], %[st" #s "]\n\t" \
+                    "buffer_load_dwordx4 %[" #vo #s "], %[rs" #s "], %[so" #s "] offen lds\n\t"
+#define X_NO(vo, s)
+// k-steps 0-2 (M = X_MF or X_MZ; D1-D6: DMA slots behind every second MFMA): queue on entry an0 an1 b0 an2 b1 b2 b3
+// (as a0-a2 here), loads x0-x2, b0-b3
+#define X_KSTEP(M, D1, D2, D3, D4, D5, D6)                                                                  \
+    X_WT(4) M(c00, a0, b0) X_LD(x0, pa, 0) M(c10, a1, b0) X_LD(x1, pa, 4096) D1                             \
+    X_WT(5) M(c20, a2, b0) X_LD(b0, pb, 0)                                                                  \
+    X_WT(5) M(c01, a0, b1) X_LD(x2, pa, 8192) D2 M(c11, a1, b1) M(c21, a2, b1) X_LD(b1, pb, 4096) D3        \
+    X_WT(6) M(c02, a0, b2) M(c12, a1, b2) D4 M(c22, a2, b2) X_LD(b2, pb, 8192)                              \
+    X_WT(6) M(c03, a0, b3) D5 M(c13, a1, b3) M(c23, a2, b3) X_LD(b3, pb, 12288) D6
+// the stage's last k-step: no loads before the barrier; behind it the loads of the next stage's first k-step in queue order
+// and the first three DMA loads of the stage after next
+#define X_KLAST_G(M, DA1, DA2, DA3)                                                                          \
+    X_WT(4) M(c00, a0, b0) M(c10, a1, b0) X_WT(3) M(c20, a2, b0)                                            \
+    X_WT(2) M(c01, a0, b1) M(c11, a1, b1) M(c21, a2, b1)                                                    \
+    "s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier\n\t"                                                        \
+    X_LD(x0, pa, 0) X_LD(x1, pa, 4096) X_LD(b0, pb, 0) X_LD(x2, pa, 8192) X_LD(b1, pb, 4096)                \
+    M(c02, a0, b2) M(c12, a1, b2) DA1 M(c22, a2, b2) X_LD(b2, pb, 8192)                                     \
+    M(c03, a0, b3) DA2 M(c13, a1, b3) M(c23, a2, b3) X_LD(b3, pb, 12288) DA3
+#define X_KLAST X_KLAST_G(X_MF, X_DM(vE, a), X_DM(vO, a), X_DM(vE, a))
+#define X_ACC_RW(m) [c##m##0] "+v"(c[m][0]), [c##m##1] "+v"(c[m][1]), [c##m##2] "+v"(c[m][2]), [c##m##3] "+v"(c[m][3])
+#define X_ACC_W(m) [c##m##0] "=&v"(c[m][0]), [c##m##1] "=&v"(c[m][1]), [c##m##2] "=&v"(c[m][2]), [c##m##3] "=&v"(c[m][3])
+#define X_FRAGS [a0] "+v"(a[0]), [a1] "+v"(a[1]), [a2] "+v"(a[2]), [x0] "=&v"(an[0]), [x1] "=&v"(an[1]), [x2] "=&v"(an[2]), \
+                [b0] "+v"(b[0]), [b1] "+v"(b[1]), [b2] "+v"(b[2]), [b3] "+v"(b[3])
+#define X_DMA_OUT(s, d) [m0##s] "+s"(d.m0), [so##s] "+s"(d.so)
+#define X_DMA_IN(s, d) [st##s] "s"(d.st), [rs##s] "s"(d.rs), [vE##s] "v"(d.vE), [vO##s] "v"(d.vO)
+typedef i32x16 TxAcc[3][4];
+// state of one operand's DMA sequence: LDS address of the last issued row group (m0), its source offset (so), the stride of a
+// row group in the source (st = 8 rows), the buffer descriptor (num_records = 0 when there is nothing left to fetch: the loads
+// then write zeros into a buffer nobody reads again) and the even / odd lane offsets
+struct XDma { unsigned m0, so, st; i32x4 rs; int vE, vO; };
+__device__ __forceinline__ i32x4 x_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long p = (unsigned long long)base;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(p >> 32) & 0xffffu));
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void tx_prologue(i32x4 (&an)[3], i32x4 (&b)[4], unsigned pa, unsigned pb) {
+    asm volatile(X_LD(x0, pa, 0) X_LD(x1, pa, 4096) X_LD(b0, pb, 0) X_LD(x2, pa, 8192) X_LD(b1, pb, 4096) X_LD(b2, pb, 8192) X_LD(b3, pb, 12288) X_WT(0)
+                 : [x0] "=&v"(an[0]), [x1] "=&v"(an[1]), [x2] "=&v"(an[2]), [b0] "=&v"(b[0]), [b1] "=&v"(b[1]), [b2] "=&v"(b[2]), [b3] "=&v"(b[3])
+                 : [pa] "v"(pa), [pb] "v"(pb) : "memory");
+}
+__device__ __forceinline__ void tx_dma3(XDma& da) {  // three loads on their own (pipeline fill)
+    asm volatile(X_DM(vE, a) X_DM(vO, a) X_DM(vE, a) : X_DMA_OUT(a, da) : X_DMA_IN(a, da) : "memory", "scc");
+}
+// k-step on fragments a (genotype rows) / b, loading an / b for the next k-step from LDS byte addresses pa / pb.
+// DMA: 0 = none; 1 = the stage's first k-step: loads 3-5 of the genotype sequence, 0-2 of the W-digit one; 2 = the second: the last
+template <bool FIRST, int DMA>
+__device__ __forceinline__ void tx_kstep(TxAcc& c, i32x4 (&a)[3], i32x4 (&an)[3], i32x4 (&b)[4], unsigned pa, unsigned pb, XDma& da, XDma& db) {
+    if (DMA == 1 && FIRST)
+        asm volatile(X_KSTEP(X_MZ, X_DM(vO, a), X_DM(vE, a), X_DM(vO, a), X_DM(vE, b), X_DM(vO, b), X_DM(vE, b))
+                     : X_ACC_W(0), X_ACC_W(1), X_ACC_W(2), X_FRAGS, X_DMA_OUT(a, da), X_DMA_OUT(b, db) : [pa] "v"(pa), [pb] "v"(pb), X_DMA_IN(a, da), X_DMA_IN(b, db) : "memory", "scc");
+    else if (DMA == 1)
+        asm volatile(X_KSTEP(X_MF, X_DM(vO, a), X_DM(vE, a), X_DM(vO, a), X_DM(vE, b), X_DM(vO, b), X_DM(vE, b))
+                     : X_ACC_RW(0), X_ACC_RW(1), X_ACC_RW(2), X_FRAGS, X_DMA_OUT(a, da), X_DMA_OUT(b, db) : [pa] "v"(pa), [pb] "v"(pb), X_DMA_IN(a, da), X_DMA_IN(b, db) : "memory", "scc");
+    else if (DMA == 2)
+        asm volatile(X_KSTEP(X_MF, X_DM(vO, b), , , , , )
+                     : X_ACC_RW(0), X_ACC_RW(1), X_ACC_RW(2), X_FRAGS, X_DMA_OUT(b, db) : [pa] "v"(pa), [pb] "v"(pb), X_DMA_IN(b, db) : "memory", "scc");
+    else
+        asm volatile(X_KSTEP(X_MF, , , , , , ) : X_ACC_RW(0), X_ACC_RW(1), X_ACC_RW(2), X_FRAGS : [pa] "v"(pa), [pb] "v"(pb) : "memory");
+}
+// last k-step of a stage; da: the genotype DMA sequence of the stage after next (armed before the call), three of its loads go out here
+__device__ __forceinline__ void tx_klast(TxAcc& c, i32x4 (&a)[3], i32x4 (&an)[3], i32x4 (&b)[4], unsigned pa, unsigned pb, XDma& da) {
+    asm volatile(X_KLAST : X_ACC_RW(0), X_ACC_RW(1), X_ACC_RW(2), X_FRAGS, X_DMA_OUT(a, da) : [pa] "v"(pa), [pb] "v"(pb), X_DMA_IN(a, da) : "memory", "scc");
+}
+// hipcc's uniformity analysis calls the scalar outputs of these asm blocks divergent in this kernel (not in k_vara_i8p), puts their
+// loop-carried copies into VGPRs and then cannot feed them to the next block's "s" operands: say it explicitly
+__device__ __forceinline__ void sx_uniform(XDma& d) {
+    d.m0 = __builtin_amdgcn_readfirstlane(d.m0);
+    d.so = __builtin_amdgcn_readfirstlane(d.so);
+}
 #endif

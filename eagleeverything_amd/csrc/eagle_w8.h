@@ -30,7 +30,8 @@ struct W8Info {           // what the last eagle_dev_scan_operands_w8 did (eagle
 #ifdef __cplusplus
 int w8_config_pairs(const W8Config& c);
 std::vector<W8Group> w8_groups(const W8Config& c, int maxp);
-void w8_work_list(int nt, int rt0, int rt1, bool upper, const std::vector<W8Group>& gs, std::vector<unsigned>& out, int* maxlen_out);
+void w8_work_list(int rt0, int rt1, int ntj, int ti_rows, int tj_rows, int ui, int uj, bool upper, const std::vector<W8Group>& gs,
+                  std::vector<unsigned>& out, int* maxlen_out);
 double w8_product_bound(const W8Stats& A, const W8Stats& B, const W8Config& c, long np);
 #endif
 #endif

@@ -84,31 +84,30 @@ __global__ __launch_bounds__(256) void k_w8_rowstats(const double* __restrict__ 
     }
 }
 
-// out = (M + M^T) / 2 and max |M[i][j] - M[j][i]| (bits of a non-negative double order like the double); one block per pair of
-// mirrored 32 x 32 tiles.  The products below are formed from the symmetrised operands: the symmetric part of S V S -- all a quadratic
-// form sees -- does not depend on the antisymmetric parts of S and V to first order, the upper triangle of (S_s V_s S_s) is all of it,
-// and what is left is second order in the measured asymmetry (a term of the bound).
-__global__ __launch_bounds__(256) void k_w8_symmetrize(const double* __restrict__ M, long np, double* __restrict__ out, unsigned long long* __restrict__ maxbits) {
+// part[block] = this block's share of || M - M^T ||_F^2 (one block per pair of mirrored 32 x 32 tiles, every block writes: a fixed-order
+// sum of `part` in k_w8_reduce is deterministic).  The products below use the images where their transposes are meant; what that
+// changes in the symmetric part of S V S is bounded with these two numbers (eagle_dev_scan_operands_w8).
+__global__ __launch_bounds__(256) void k_w8_asymsq(const double* __restrict__ M, long np, double* __restrict__ part) {
     const long bj = (long)blockIdx.y * 32, bk = (long)blockIdx.x * 32;
-    if (bk < bj) return;
-    __shared__ double t1[32][33], t2[32][33];
+    const long pid = (long)blockIdx.y * gridDim.x + blockIdx.x;
+    if (bk < bj) { if (threadIdx.x == 0) part[pid] = 0.0; return; }
+    __shared__ double t2[32][33];
+    __shared__ double red[256];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int r = ty; r < 32; r += 8) {
-        t1[r][tx] = M[(bj + r) * np + bk + tx];   // t1[a][b] = M[bj + a][bk + b]
-        t2[r][tx] = M[(bk + r) * np + bj + tx];   // t2[a][b] = M[bk + a][bj + b]
-    }
+    for (int r = ty; r < 32; r += 8) t2[r][tx] = M[(bk + r) * np + bj + tx];
     __syncthreads();
-    double m = 0.0;
+    double s = 0.0;
     for (int r = ty; r < 32; r += 8) {
-        const double a = t1[r][tx], at = t2[tx][r];
-        const double df = fabs(a - at);
-        m = df > m ? df : m;   // (a NaN never wins; k_w8_rowstats reports non-finite entries)
-        out[(bj + r) * np + bk + tx] = 0.5 * (a + at);
-        if (bk != bj) out[(bk + r) * np + bj + tx] = 0.5 * (t2[r][tx] + t1[tx][r]);
+        const double df = M[(bj + r) * np + bk + tx] - t2[tx][r];
+        s += df * df;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_down(m, o); m = y > m ? y : m; }
-    if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(maxbits, (unsigned long long)__double_as_longlong(m));
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[pid] = bk == bj ? red[0] : 2.0 * red[0];
 }
 
 // Digit slices of the off-diagonal part of one row: D[p][i][l] = digit p (0 = most significant) of round(M[i][l] 2^(8*6 - e_i - 2)),
@@ -159,7 +158,7 @@ __global__ __launch_bounds__(256) void k_w8_slice(const double* __restrict__ M, 
 // estimate sum_i d2_i^2 |d_i| of sum_k |W_kk|.
 __global__ __launch_bounds__(1024) void k_w8_reduce(long np, const double* __restrict__ d, const double* __restrict__ mx, const double* __restrict__ ssq,
                                                     const int* __restrict__ e, const unsigned long long* __restrict__ dssq, const double* __restrict__ d2,
-                                                    const int* __restrict__ bad, const unsigned long long* __restrict__ asymbits, W8Stats* __restrict__ out) {
+                                                    const int* __restrict__ bad, const double* __restrict__ asympart, long nasym, W8Stats* __restrict__ out) {
     double maxd = 0.0, fro2 = 0.0, es2 = 0.0, wd = 0.0, phi2[W8_KMAX];
 #pragma unroll
     for (int p = 0; p < W8_KMAX; p++) phi2[p] = 0.0;
@@ -195,6 +194,10 @@ __global__ __launch_bounds__(1024) void k_w8_reduce(long np, const double* __res
     }
     const double gmaxd = red[0];
     const double gfro2 = sum(fro2), ges2 = sum(es2), gwd = sum(wd);
+    double as = 0.0;
+    if (asympart)
+        for (long i = threadIdx.x; i < nasym; i += 1024) as += asympart[i];
+    const double gas = sum(as);
     double gphi2[W8_KMAX];
 #pragma unroll
     for (int p = 0; p < W8_KMAX; p++) gphi2[p] = sum(phi2[p]);
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(1024) void k_w8_reduce(long np, const double* __res
 #pragma unroll
         for (int p = 0; p < W8_KMAX; p++) out->phi2[p] = gphi2[p];
         out->bad = bad ? *bad : 0;
-        out->asym = asymbits ? __longlong_as_double((long long)*asymbits) : 0.0;
+        out->asym = asympart ? sqrt(gas) : 0.0;   // || M - M^T ||_F
     }
 }
 
@@ -266,6 +269,116 @@ __global__ __launch_bounds__(512, 2) void k_w8_gemm(const int8_t* __restrict__ A
             for (int q = 0; q < 16; q++) Lg[(long)(m * 32 + (q & 3) + 8 * (q >> 2)) * ldc + n * 32] = acc[m][n][q];
 }
 
+// The same product on the 384 x 256 tile with the asm-pipelined k-step of k_vara_i8p (eagle_t8.h): LDS reads, LDS-DMA and MFMAs of one wave
+// overlap.  Engine operand "a" (384-row tiles; the LANES of the transposed 32 x 32 result tiles) = the operand whose rows are the
+// output COLUMNS j (digit slices of V / X), operand "b" (256-row tiles; the registers) = the one whose rows are the output ROWS i
+// (slices of S): a result register is 32 consecutive j of one row i, stored as one 128-byte run.  Work entry: ti = 256-row tile of S,
+// tj = 384-row tile of the column operand (the last one may be short: rows beyond n_pad read as zero and are not stored).
+__global__ __launch_bounds__(512, 2) void k_w8_gemm_p(const int8_t* __restrict__ Ss, const int8_t* __restrict__ Cs, long sstride, long ld,
+                                                      const unsigned* __restrict__ work, int maxlen, const W8Group* __restrict__ groups,
+                                                      int32_t* __restrict__ L, long img_elems, long ldc, int row_tile0, int nstages, long np) {
+    extern __shared__ __attribute__((aligned(1024))) int8_t ldsv[];  // [2][A 48 KiB | B 32 KiB]
+    const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
+    if (pos >= maxlen) return;
+    const unsigned wk = __builtin_amdgcn_readfirstlane(work[(long)xcd * maxlen + pos]);
+    if (wk == 0xFFFFFFFFu) return;
+    const int ti = (int)(wk >> 20), tj = (int)((wk >> 8) & 0xfffu), g = (int)(wk & 0xffu);
+    const W8Group* gp = groups + g;
+    const int gnp = __builtin_amdgcn_readfirstlane(gp->npairs);
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = w >> 1, wc = w & 1;   // 4 x 2 waves, wave tile 96 (a) x 128 (b)
+    const int ldi = (int)ld;
+    const T8Lane ln = t8_lane(lane, ldi);
+    const int8_t* Acol = Cs + (long)tj * TW_M * ld;
+    const int8_t* Brow = Ss + (long)ti * T8 * ld;
+    const long rows_left = np - (long)tj * TW_M;
+    const int rows_here = __builtin_amdgcn_readfirstlane((int)(rows_left < TW_M ? rows_left : TW_M));
+    const int8_t* baseA = Acol + (long)gp->q[0] * sstride;
+    const int8_t* baseB = Brow + (long)gp->p[0] * sstride;
+    tw_stage<6>(__builtin_amdgcn_make_buffer_rsrc((void*)baseA, 0, rows_here * ldi, 0x00020000), ln, ldi, 0, ldsv, w);
+    tw_stage<4>(t8_rsrc(baseB, ldi), ln, ldi, 0, ldsv + TW_ABYTES, w);
+    __syncthreads();
+    const int r = lane & 31, h = lane >> 5, swz = (r >> 1) & 7;
+    constexpr int STG = TW_ABYTES + TILE_BYTES;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) int8_t*)ldsv;
+    const unsigned offA = lds0 + wr * (96 * BK8) + r * BK8, offB = lds0 + TW_ABYTES + wc * (128 * BK8) + r * BK8;
+    unsigned ch[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) ch[ks] = ((2 * ks + h) ^ swz) << 4;
+    XDma dA, dB;
+    dA.st = dB.st = __builtin_amdgcn_readfirstlane(8 * ldi);
+    dA.vE = dB.vE = ln.voffE; dA.vO = dB.vO = ln.voffO;
+    const int total = gnp * nstages;   // the flattened (pair, K stage) sequence of this accumulation group
+    int snext = 1, nkt = 1, npr = 0;   // the next stage to fetch: global index, K stage, pair   (nstages >= 2)
+    unsigned nrecA = 0, nrecB = 0;
+    // (the descriptors are rebuilt from scalars at each use: a loop-carried SGPR vector ends up in VGPRs)
+    auto rs_fresh = [&] { dA.rs = x_rsrc(baseA, nrecA); dB.rs = x_rsrc(baseB, nrecB); };
+    auto dma_arm = [&](int into) {
+        const unsigned base = lds0 + into * STG;
+        if (nkt == nstages) { nkt = 0; npr++; }
+        const int left = __builtin_amdgcn_readfirstlane(total - snext);
+        const unsigned on = (unsigned)max(min(left, 1), 0);
+        if (on && nkt == 0) {   // the first stage of the next digit pair: other slices of the same row ranges
+            baseA = Acol + (long)gp->q[npr] * sstride;
+            baseB = Brow + (long)gp->p[npr] * sstride;
+        }
+        dA.m0 = __builtin_amdgcn_readfirstlane(base + (w * 6) * 1024 - 1024);
+        dB.m0 = __builtin_amdgcn_readfirstlane(base + TW_ABYTES + (w * 4) * 1024 - 1024);
+        dA.so = __builtin_amdgcn_readfirstlane((unsigned)((w * 6) * 8 * ldi + nkt * BK8 - 8 * ldi));
+        dB.so = __builtin_amdgcn_readfirstlane((unsigned)((w * 4) * 8 * ldi + nkt * BK8 - 8 * ldi));
+        // num_records = 0 when nothing is left to fetch: the loads then write zeros nobody reads
+        nrecA = __builtin_amdgcn_readfirstlane((unsigned)(rows_here * ldi) * on);
+        nrecB = __builtin_amdgcn_readfirstlane((unsigned)(T8 * ldi) * on);
+        snext++; nkt++;
+    };
+    dma_arm(1);
+    rs_fresh();
+    tx_dma3(dA);
+    sx_uniform(dA);
+    int buf = 0;
+    i32x4 fa[2][3], fb[4];
+    TxAcc c;
+    tx_prologue(fa[0], fb, offA + ch[0], offB + ch[0]);
+    auto stage_rest = [&] {
+        const unsigned sa = offA + buf * STG, sb = offB + buf * STG;
+        rs_fresh();
+        tx_kstep<false, 2>(c, fa[1], fa[0], fb, sa + ch[2], sb + ch[2], dA, dB);
+        sx_uniform(dB);
+        tx_kstep<false, 0>(c, fa[0], fa[1], fb, sa + ch[3], sb + ch[3], dA, dB);
+        dma_arm(buf);
+        rs_fresh();
+        buf ^= 1;
+        tx_klast(c, fa[1], fa[0], fb, offA + buf * STG + ch[0], offB + buf * STG + ch[0], dA);
+        sx_uniform(dA);
+    };
+    rs_fresh();
+    tx_kstep<true, 1>(c, fa[0], fa[1], fb, offA + ch[1], offB + ch[1], dA, dB);
+    sx_uniform(dA); sx_uniform(dB);
+    stage_rest();
+    for (int s = 1; s < total; s++) {
+        rs_fresh();
+        tx_kstep<false, 1>(c, fa[0], fa[1], fb, offA + buf * STG + ch[1], offB + buf * STG + ch[1], dA, dB);
+        sx_uniform(dA); sx_uniform(dB);
+        stage_rest();
+    }
+    // the MFMAs are opaque to the compiler's hazard recogniser: let the last ones retire; the stale re-loads have to land too
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    // c[m][n][x]: lane r = row wr*96 + m*32 + r of the a tile (output column j), register = row wc*128 + n*32 + (x&3) + 8(x>>2) + 4h of the b tile (row i)
+    int32_t* Lg = L + (long)g * img_elems + ((long)(ti - row_tile0) * T8 + wc * 128 + 4 * h) * ldc;
+    const long j0 = (long)tj * TW_M + wr * 96 + r;
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+        const long j = j0 + m * 32;
+        if (j < np) {
+#pragma unroll
+            for (int n = 0; n < 4; n++)
+#pragma unroll
+                for (int x = 0; x < 16; x++) Lg[(long)(n * 32 + (x & 3) + 8 * (x >> 2)) * ldc + j] = c[m][n][x];
+        }
+    }
+}
+
 // sum_g 256^-level_g L_g[.] in fp64: groups are listed by ascending level; the smallest terms are added first (fixed order)
 __device__ __forceinline__ double w8_levels(const int32_t* __restrict__ L, long img_elems, long off, const W8Group* __restrict__ groups, int ngroups) {
     double s = 0.0;
@@ -314,6 +427,23 @@ __global__ __launch_bounds__(256) void k_w8_combine2(const double* Sa, const dou
     }
 }
 
+// out_i = sum_j At[i][j] x_j (the transposed product of k_colgemv: one wave per row, fixed order)
+__global__ __launch_bounds__(256) void k_w8_rowgemv(const double* __restrict__ At, long n, long np, const double* __restrict__ x, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    double s0 = 0.0, s1 = 0.0;
+    long j = lane;
+    for (; j + 64 < n; j += 128) { s0 += At[i * np + j] * x[j]; s1 += At[i * np + j + 64] * x[j + 64]; }
+    if (j < n) s0 += At[i * np + j] * x[j];
+    double v = s0 + s1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if (lane == 0) out[i] = v;
+}
+__global__ __launch_bounds__(256) void k_w8_mean2(const double* __restrict__ a, const double* __restrict__ b, long np, double* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < np) out[i] = 0.5 * (a[i] + b[i]);
+}
 __global__ __launch_bounds__(256) void k_w8_fill_ones(double* __restrict__ x, long n, long np) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < np) x[i] = i < n ? 1.0 : 0.0;
@@ -348,23 +478,28 @@ extern "C" int eagle_w8_rho(eagle_ctx* ctx, const double* Wu, long n_pad, double
 //   out[c][i] = sum_j At[j][i] x[c][j]  (At = row-major image of A^T: out_c = A x_c).  Every (c, i) is summed in a fixed order
 //   (wave w takes j = w, w+4, ..., then the four partial sums in order), whatever else is in the batch.
 // ------------------------------------------------------------------------------------------------
-#define W8_MG 16
+#define W8_MG 8
+#define W8_JS 16
 #define W8_TRUE_CHUNK 256
-__global__ __launch_bounds__(256) void k_w8_mgemv(const double* __restrict__ At, long n, long np, const double* __restrict__ X, double* __restrict__ out) {
-    const int c0 = blockIdx.y * W8_MG;
+// part[js][c][i] = sum over the js-th sixteenth of j of At[j][i] x[c][j]
+__global__ __launch_bounds__(256) void k_w8_mgemv_part(const double* __restrict__ At, long n, long np, const double* __restrict__ X, double* __restrict__ part,
+                                                       int capr) {
+    const int c0 = blockIdx.z * W8_MG, js = blockIdx.y;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long i = (long)blockIdx.x * 64 + lane;
+    const long per = ((n + W8_JS - 1) / W8_JS + 3) / 4 * 4;
+    const long ja = (long)js * per, jb = ja + per < n ? ja + per : n;
     __shared__ double xs[W8_MG][256];
     __shared__ double red[4][W8_MG][64];
     double acc[W8_MG];
 #pragma unroll
     for (int c = 0; c < W8_MG; c++) acc[c] = 0.0;
-    for (long j0 = 0; j0 < n; j0 += 256) {
+    for (long j0 = ja; j0 < jb; j0 += 256) {
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < W8_MG; c++) xs[c][threadIdx.x] = j0 + threadIdx.x < n ? X[(long)(c0 + c) * np + j0 + threadIdx.x] : 0.0;
+        for (int c = 0; c < W8_MG; c++) xs[c][threadIdx.x] = j0 + threadIdx.x < jb ? X[(long)(c0 + c) * np + j0 + threadIdx.x] : 0.0;
         __syncthreads();
-        const long jend = n - j0 < 256 ? n - j0 : 256;
+        const long jend = jb - j0 < 256 ? jb - j0 : 256;
         for (long jj = w; jj < jend; jj += 4) {
             const double a = At[(j0 + jj) * np + i];
 #pragma unroll
@@ -376,29 +511,47 @@ __global__ __launch_bounds__(256) void k_w8_mgemv(const double* __restrict__ At,
     __syncthreads();
     if (w == 0)
 #pragma unroll
-        for (int c = 0; c < W8_MG; c++) out[(long)(c0 + c) * np + i] = (red[0][c][lane] + red[1][c][lane]) + (red[2][c][lane] + red[3][c][lane]);
+        for (int c = 0; c < W8_MG; c++)
+            part[((long)js * capr + c0 + c) * np + i] = (red[0][c][lane] + red[1][c][lane]) + (red[2][c][lane] + red[3][c][lane]);
 }
-// The transposed product: out[c][i] = sum_j At[i][j] x[c][j] (one wave per row i, lanes strided over j, fixed order)
+__global__ __launch_bounds__(256) void k_w8_mgemv_sum(const double* __restrict__ part, long np, int capr, double* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y;
+    if (i >= np) return;
+    double s = 0.0;
+    for (int js = 0; js < W8_JS; js++) s += part[((long)js * capr + c) * np + i];
+    out[(long)c * np + i] = s;
+}
+// The transposed product: out[c][i] = sum_j At[i][j] x[c][j] (a wave takes four rows i, lanes strided over j, fixed order)
 __global__ __launch_bounds__(256) void k_w8_mgemv_row(const double* __restrict__ At, long n, long np, const double* __restrict__ X, double* __restrict__ out) {
     const int c0 = blockIdx.y * W8_MG;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const long i = (long)blockIdx.x * 4 + w;
-    double acc[W8_MG];
+    const long i0 = (long)blockIdx.x * 16 + w * 4;
+    double acc[4][W8_MG];
 #pragma unroll
-    for (int c = 0; c < W8_MG; c++) acc[c] = 0.0;
-    if (i < n)
-        for (long j = lane; j < n; j += 64) {
-            const double a = At[i * np + j];
+    for (int q = 0; q < 4; q++)
 #pragma unroll
-            for (int c = 0; c < W8_MG; c++) acc[c] += a * X[(long)(c0 + c) * np + j];
-        }
+        for (int c = 0; c < W8_MG; c++) acc[q][c] = 0.0;
+    for (long j = lane; j < n; j += 64) {
+        double x[W8_MG], a[4];
 #pragma unroll
-    for (int c = 0; c < W8_MG; c++) {
-        double v = acc[c];
+        for (int c = 0; c < W8_MG; c++) x[c] = X[(long)(c0 + c) * np + j];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-        if (lane == 0 && i < np) out[(long)(c0 + c) * np + i] = v;
+        for (int q = 0; q < 4; q++) a[q] = At[(i0 + q) * np + j];   // (rows beyond n are zero padding)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int c = 0; c < W8_MG; c++) acc[q][c] += a[q] * x[c];
     }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int c = 0; c < W8_MG; c++) {
+            double v = acc[q][c];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+            if (lane == 0) out[(long)(c0 + c) * np + i0 + q] = v;
+        }
 }
 // x[c][j] = (double) rows8[c][j] for c < count, zero rows up to the next multiple of 16
 __global__ __launch_bounds__(256) void k_w8_rows_f64(const int8_t* __restrict__ rows8, long ld, long np, int count, double* __restrict__ X) {
@@ -429,7 +582,7 @@ extern "C" int eagle_w8_true_vara(eagle_ctx* ctx, const int8_t* rows8, long coun
     if (!ctx->w8_Sa || !ctx->w8_Va || ctx->w8_n <= 0) return eagle_fail(ctx, EAGLE_ERR_ARG, "w8_true_vara: no operands on record");
     if (count <= 0) return EAGLE_OK;
     hipStream_t s = (hipStream_t)stream;
-    const size_t need = (size_t)4 * W8_TRUE_CHUNK * n_pad * sizeof(double);
+    const size_t need = (size_t)(4 + W8_JS) * W8_TRUE_CHUNK * n_pad * sizeof(double);
     if (need > ctx->w8_true_cap) {
         if (ctx->w8_true_ws) { (void)hipStreamSynchronize(s); (void)hipFree(ctx->w8_true_ws); ctx->w8_true_ws = nullptr; ctx->w8_true_cap = 0; }
         hipError_t e = hipMalloc(&ctx->w8_true_ws, need);
@@ -440,14 +593,18 @@ extern "C" int eagle_w8_true_vara(eagle_ctx* ctx, const int8_t* rows8, long coun
     double* T = X + (size_t)W8_TRUE_CHUNK * n_pad;
     double* U = T + (size_t)W8_TRUE_CHUNK * n_pad;
     double* Tt = U + (size_t)W8_TRUE_CHUNK * n_pad;
+    double* part = Tt + (size_t)W8_TRUE_CHUNK * n_pad;
     const long n = ctx->w8_n;
     for (long c0 = 0; c0 < count; c0 += W8_TRUE_CHUNK) {
         const int cnt = (int)std::min<long>(W8_TRUE_CHUNK, count - c0);
         const int capr = (cnt + W8_MG - 1) / W8_MG * W8_MG;
         hipLaunchKernelGGL(k_w8_rows_f64, dim3((unsigned)((n_pad + 255) / 256), (unsigned)capr), dim3(256), 0, s, rows8 + c0 * ld, ld, n_pad, cnt, X);
-        hipLaunchKernelGGL(k_w8_mgemv, dim3((unsigned)(n_pad / 64), (unsigned)(capr / W8_MG)), dim3(256), 0, s, ctx->w8_Sa, n, n_pad, (const double*)X, T);
-        hipLaunchKernelGGL(k_w8_mgemv, dim3((unsigned)(n_pad / 64), (unsigned)(capr / W8_MG)), dim3(256), 0, s, ctx->w8_Va, n, n_pad, (const double*)T, U);
-        hipLaunchKernelGGL(k_w8_mgemv_row, dim3((unsigned)(n_pad / 4), (unsigned)(capr / W8_MG)), dim3(256), 0, s, ctx->w8_Sa, n, n_pad, (const double*)X, Tt);
+        const dim3 gp((unsigned)(n_pad / 64), W8_JS, (unsigned)(capr / W8_MG)), gs((unsigned)((n_pad + 255) / 256), (unsigned)capr);
+        hipLaunchKernelGGL(k_w8_mgemv_part, gp, dim3(256), 0, s, ctx->w8_Sa, n, n_pad, (const double*)X, part, capr);
+        hipLaunchKernelGGL(k_w8_mgemv_sum, gs, dim3(256), 0, s, (const double*)part, n_pad, capr, T);
+        hipLaunchKernelGGL(k_w8_mgemv_part, gp, dim3(256), 0, s, ctx->w8_Va, n, n_pad, (const double*)T, part, capr);
+        hipLaunchKernelGGL(k_w8_mgemv_sum, gs, dim3(256), 0, s, (const double*)part, n_pad, capr, U);
+        hipLaunchKernelGGL(k_w8_mgemv_row, dim3((unsigned)(n_pad / 16), (unsigned)(capr / W8_MG)), dim3(256), 0, s, ctx->w8_Sa, n, n_pad, (const double*)X, Tt);
         hipLaunchKernelGGL(k_w8_rowdot, dim3((unsigned)cnt), dim3(256), 0, s, (const double*)Tt, (const double*)U, n_pad, dst_dev ? dst_dev + c0 : nullptr,
                            dst_dev ? out : out + c0);
     }
@@ -493,17 +650,20 @@ std::vector<W8Group> w8_groups(const W8Config& c, int maxp) {
     return gs;
 }
 // The work list of one product over the row tiles [rt0, rt1): per XCD `maxlen` entries (ti << 20 | tj << 8 | group, 0xFFFFFFFF = none).
-// upper: only tiles with tj >= ti.  Units = (4 x 8 super-tile, group), dealt longest first to the XCD with the least work so far.
-void w8_work_list(int nt, int rt0, int rt1, bool upper, const std::vector<W8Group>& gs, std::vector<unsigned>& out, int* maxlen_out) {
+// Row tiles of ti_rows rows (i), column tiles of tj_rows rows (j), ntj of them; upper: only tiles that hold an element with j >= i.
+// Units = (ui x uj super-tile, group) -- what an XCD's 32 workgroups run at a time -- dealt longest first to the XCD with the least
+// work so far.
+void w8_work_list(int rt0, int rt1, int ntj, int ti_rows, int tj_rows, int ui, int uj, bool upper, const std::vector<W8Group>& gs,
+                  std::vector<unsigned>& out, int* maxlen_out) {
     struct Unit { int cost; std::vector<unsigned> items; };
     std::vector<Unit> units;
-    for (int si = rt0; si < rt1; si += 4)
-        for (int sj = 0; sj < nt; sj += 8)
+    for (int si = rt0; si < rt1; si += ui)
+        for (int sj = 0; sj < ntj; sj += uj)
             for (size_t g = 0; g < gs.size(); g++) {
                 Unit u;
-                for (int i = si; i < si + 4 && i < rt1; i++)
-                    for (int j = sj; j < sj + 8 && j < nt; j++)
-                        if (!upper || j >= i) u.items.push_back(((unsigned)i << 20) | ((unsigned)j << 8) | (unsigned)g);
+                for (int i = si; i < si + ui && i < rt1; i++)
+                    for (int j = sj; j < sj + uj && j < ntj; j++)
+                        if (!upper || (long)j * tj_rows + tj_rows - 1 >= (long)i * ti_rows) u.items.push_back(((unsigned)i << 20) | ((unsigned)j << 8) | (unsigned)g);
                 if (u.items.empty()) continue;
                 u.cost = (int)u.items.size() * gs[g].npairs;
                 units.push_back(std::move(u));
@@ -539,6 +699,27 @@ double w8_product_bound(const W8Stats& A, const W8Stats& B, const W8Config& c, l
     return (drop + TA * (fB + TB) + fA * TB) * up;
 }
 
+// Host-only hooks for the CPU tests (tests/test_w8_host.py): the work list and the bound exactly as the pipeline uses them.
+extern "C" int eagle_w8_host_work_list(int nt, int rt0, int rt1, int upper, int piped, int k, int T, int maxp, unsigned* out, long cap, int* maxlen,
+                                       W8Group* groups_out, int* ngroups) {
+    const W8Config c = {k, T};
+    const std::vector<W8Group> gs = w8_groups(c, maxp);
+    std::vector<unsigned> wl;
+    int ml = 0;
+    if (piped) w8_work_list(rt0, rt1, (int)(((long)nt * T8 + TW_M - 1) / TW_M), T8, TW_M, 8, 4, upper != 0, gs, wl, &ml);
+    else w8_work_list(rt0, rt1, nt, T8, T8, 4, 8, upper != 0, gs, wl, &ml);
+    if ((long)wl.size() > cap || gs.size() > 64) return -1;
+    std::copy(wl.begin(), wl.end(), out);
+    std::copy(gs.begin(), gs.end(), groups_out);
+    *maxlen = ml;
+    *ngroups = (int)gs.size();
+    return 0;
+}
+extern "C" double eagle_w8_host_bound(const W8Stats* A, const W8Stats* B, int k, int T, long np) {
+    const W8Config c = {k, T};
+    return w8_product_bound(*A, *B, c, np);
+}
+
 static const W8Config W8_CONFIGS[] = {{3, 4}, {3, 5}, {4, 5}, {4, 6}, {5, 6}, {5, 7}, {6, 7}, {6, 8}, {6, 9}, {6, 12}};
 static const int W8_NCONFIGS = (int)(sizeof(W8_CONFIGS) / sizeof(W8_CONFIGS[0]));
 // cheapest configuration whose bound is <= limit (-1: none)
@@ -556,19 +737,20 @@ static int w8_choose(const W8Stats& A, const W8Stats& B, long np, double limit, 
 }
 
 struct W8List { unsigned* work = nullptr; W8Group* groups = nullptr; int maxlen = 0, ngroups = 0; };
-static std::map<std::tuple<int, int, int, int, int, int, int>, W8List> g_w8_lists;   // (device, nt, rt0, rt1, upper, config, maxp)
+static std::map<std::tuple<int, int, int, int, int, int, int>, W8List> g_w8_lists;   // (device, nt, rt0, rt1, upper | engine, config, maxp)
 static std::mutex g_w8_mutex;
-static int w8_get_list(eagle_ctx* ctx, int nt, int rt0, int rt1, bool upper, int cfg, int maxp, W8List* out) {
+static int w8_get_list(eagle_ctx* ctx, int nt, int rt0, int rt1, bool upper, bool piped, int cfg, int maxp, W8List* out) {
     std::lock_guard<std::mutex> lock(g_w8_mutex);
     int dev = 0;
     (void)hipGetDevice(&dev);
-    auto key = std::make_tuple(dev, nt, rt0, rt1, upper ? 1 : 0, cfg, maxp);
+    auto key = std::make_tuple(dev, nt, rt0, rt1, (upper ? 1 : 0) | (piped ? 2 : 0), cfg, maxp);
     auto it = g_w8_lists.find(key);
     if (it != g_w8_lists.end()) { *out = it->second; return EAGLE_OK; }
     const std::vector<W8Group> gs = w8_groups(W8_CONFIGS[cfg], maxp);
     std::vector<unsigned> wl;
     W8List l;
-    w8_work_list(nt, rt0, rt1, upper, gs, wl, &l.maxlen);
+    if (piped) w8_work_list(rt0, rt1, (int)(((long)nt * T8 + TW_M - 1) / TW_M), T8, TW_M, 8, 4, upper, gs, wl, &l.maxlen);
+    else w8_work_list(rt0, rt1, nt, T8, T8, 4, 8, upper, gs, wl, &l.maxlen);
     l.ngroups = (int)gs.size();
     hipError_t e = hipMalloc((void**)&l.work, wl.size() * sizeof(unsigned) + 16);
     if (e == hipSuccess) e = hipMalloc((void**)&l.groups, gs.size() * sizeof(W8Group));
@@ -588,9 +770,10 @@ static int w8_get_list(eagle_ctx* ctx, int nt, int rt0, int rt1, bool upper, int
 struct W8Ws {
     int8_t *sA, *sB;
     int32_t* levels; size_t level_bytes;
-    double *dS, *mxS, *ssqS, *dV, *mxV, *ssqV, *dX, *mxX, *ssqX, *r, *r1, *r2, *sumdiag;
+    double *dS, *mxS, *ssqS, *dV, *mxV, *ssqV, *dX, *mxX, *ssqX, *r, *r1, *r2, *sumdiag, *gvpart;
     int *eS, *eV, *eX, *bad;
-    unsigned long long *dssqS, *dssqV, *dssqX, *asym;
+    unsigned long long *dssqS, *dssqV, *dssqX;
+    double* asympart;
     W8Stats* stats;  // [3] device
 };
 static size_t r256(size_t x) { return (x + 255) / 256 * 256; }
@@ -598,10 +781,16 @@ static size_t r256(size_t x) { return (x + 255) / 256 * 256; }
 static int w8_workspace(eagle_ctx* ctx, long np, W8Ws* w) {
     const size_t nn = (size_t)np * np;
     const size_t full_levels = 12 * nn * sizeof(int32_t);   // the largest configuration: 11 levels (+ splits at very large n)
-    const size_t level_bytes = full_levels < W8_LEVEL_CAP ? full_levels : W8_LEVEL_CAP;
+    size_t cap = W8_LEVEL_CAP;
+    if (const char* e = getenv("EAGLE_HIP_W8_LEVEL_MB")) {   // tests: small level images force the products through several row panels
+        const long mb = atol(e);
+        if (mb >= 1) cap = (size_t)mb << 20;
+    }
+    const size_t level_bytes = full_levels < cap ? full_levels : cap;
     const size_t vec = r256(sizeof(double) * (size_t)np), dss = r256(sizeof(unsigned long long) * W8_KMAX * (size_t)np);
-    const size_t need = 2 * r256(W8_KMAX * nn) + r256(level_bytes) + 13 * vec + 4 * vec + 3 * dss + 4096;
-    if (need > ctx->w8_ws_cap) {
+    const size_t asymb = r256(sizeof(double) * (size_t)(np / 32) * (size_t)(np / 32));
+    const size_t need = 2 * r256(W8_KMAX * nn) + r256(level_bytes) + 13 * vec + 8 * vec + 4 * vec + 3 * dss + asymb + 4096;
+    if (need > ctx->w8_ws_cap || (getenv("EAGLE_HIP_W8_LEVEL_MB") && need != ctx->w8_ws_cap)) {
         if (ctx->w8_ws) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->w8_ws); ctx->w8_ws = nullptr; ctx->w8_ws_cap = 0; }
         if (hipMalloc(&ctx->w8_ws, need) != hipSuccess) { (void)hipGetLastError(); ctx->w8_ws = nullptr; return 1; }   // no room: decline
         ctx->w8_ws_cap = need;
@@ -614,28 +803,26 @@ static int w8_workspace(eagle_ctx* ctx, long np, W8Ws* w) {
     w->level_bytes = level_bytes;
     double** dv[] = {&w->dS, &w->mxS, &w->ssqS, &w->dV, &w->mxV, &w->ssqV, &w->dX, &w->mxX, &w->ssqX, &w->r, &w->r1, &w->r2, &w->sumdiag};
     for (double** x : dv) *x = (double*)take(vec);
+    w->gvpart = (double*)take(8 * vec);
     int** iv[] = {&w->eS, &w->eV, &w->eX, &w->bad};
     for (int** x : iv) *x = (int*)take(vec);
     unsigned long long** uv[] = {&w->dssqS, &w->dssqV, &w->dssqX};
     for (unsigned long long** x : uv) *x = (unsigned long long*)take(dss);
-    w->asym = (unsigned long long*)take(256);
+    w->asympart = (double*)take(asymb);
     w->stats = (W8Stats*)take(3 * sizeof(W8Stats));
     return 0;
 }
 
-// statistics + digit slices of one operand; sym_out != NULL: of its symmetrised copy, made here first (max |M - M^T| into the statistics)
+// statistics + digit slices of one operand; asym: also || M - M^T ||_F
 static int w8_stats_of(eagle_ctx* ctx, const double* M, long np, double* d, double* mx, double* ssq, int* e, unsigned long long* dssq, int8_t* slices,
-                       const double* d2, double* sym_out, W8Ws& w, W8Stats* out_dev, hipStream_t s) {
+                       const double* d2, bool asym, W8Ws& w, W8Stats* out_dev, hipStream_t s) {
     hipError_t er = hipMemsetAsync(w.bad, 0, sizeof(int), s);
-    if (er == hipSuccess) er = hipMemsetAsync(w.asym, 0, sizeof(unsigned long long), s);
     if (er != hipSuccess) return eagle_fail_hip(ctx, er, "w8 memset");
-    if (sym_out) {
-        hipLaunchKernelGGL(k_w8_symmetrize, dim3((unsigned)(np / 32), (unsigned)(np / 32)), dim3(256), 0, s, M, np, sym_out, w.asym);
-        M = sym_out;
-    }
+    const long nb = np / 32;
+    if (asym) hipLaunchKernelGGL(k_w8_asymsq, dim3((unsigned)nb, (unsigned)nb), dim3(256), 0, s, M, np, w.asympart);
     hipLaunchKernelGGL(k_w8_rowstats, dim3((unsigned)np), dim3(256), 0, s, M, np, d, mx, ssq, w.bad);
     hipLaunchKernelGGL(k_w8_slice, dim3((unsigned)np), dim3(256), 0, s, M, np, mx, slices, np * np, dssq, e);
-    hipLaunchKernelGGL(k_w8_reduce, dim3(1), dim3(1024), 0, s, np, d, mx, ssq, e, dssq, d2, w.bad, sym_out ? w.asym : nullptr, out_dev);
+    hipLaunchKernelGGL(k_w8_reduce, dim3(1), dim3(1024), 0, s, np, d, mx, ssq, e, dssq, d2, w.bad, asym ? (const double*)w.asympart : nullptr, nb * nb, out_dev);
     er = hipGetLastError();
     if (er != hipSuccess) return eagle_fail_hip(ctx, er, "w8 statistics");
     return EAGLE_OK;
@@ -656,9 +843,19 @@ static int w8_product(eagle_ctx* ctx, int cfg, bool upper, long np, const int8_t
     for (int rt0 = 0; rt0 < nt; rt0 += (int)rt_per_panel) {
         const int rt1 = (int)std::min<long>(nt, rt0 + rt_per_panel);
         W8List l;
-        int rc = w8_get_list(ctx, nt, rt0, rt1, upper, cfg, maxp, &l);
+        const bool piped = ctx->tune != 31 && (double)np * TW_M < 2147483648.0;   // tune 31: the compiler-scheduled 256 x 256 form (A/B runs)
+        int rc = w8_get_list(ctx, nt, rt0, rt1, upper, piped, cfg, maxp, &l);
         if (rc) return rc;
         const long img_elems = (long)(rt1 - rt0) * T8 * np;
+        if (piped) {
+            if (!ctx->attr_w8_gemm) {
+                hipError_t ea = hipFuncSetAttribute((const void*)k_w8_gemm_p, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TW_ABYTES + TILE_BYTES));
+                if (ea != hipSuccess) return eagle_fail_hip(ctx, ea, "hipFuncSetAttribute(k_w8_gemm_p)");
+                ctx->attr_w8_gemm = true;
+            }
+            hipLaunchKernelGGL(k_w8_gemm_p, dim3((unsigned)(8 * l.maxlen)), dim3(512), 2 * (TW_ABYTES + TILE_BYTES), s, sA, sB, np * np, np, (const unsigned*)l.work,
+                               l.maxlen, (const W8Group*)l.groups, w.levels, img_elems, np, rt0, (int)(np / BK8), np);
+        } else
         hipLaunchKernelGGL(k_w8_gemm, dim3((unsigned)(8 * l.maxlen)), dim3(512), 0, s, sA, sB, np * np, np, (const unsigned*)l.work, l.maxlen,
                            (const W8Group*)l.groups, w.levels, img_elems, np, rt0, (int)(np / BK8));
         combine(l, img_elems, (long)rt0 * T8, (long)(rt1 - rt0) * T8);
@@ -693,19 +890,20 @@ extern "C" int eagle_dev_scan_operands_w8(eagle_ctx* ctx, const double* Sa, cons
     if (w8_workspace(ctx, np, &w)) { ctx->w8_info.declined = 5; return 1; }
     int rc = eagle_dev_scan_operands_begin(ctx, Sa, ahat, n, np, v_out, tmp, stream);
     if (rc) return rc;
-    // symmetrised copies: S_s in the output buffer (its upper part is overwritten element by element when the folded W is written),
-    // V_s in tmp (overwritten the same way by X); statistics + digit slices of their off-diagonal parts F, Fv
-    double* Ss = Wu_out;
-    double* Vs = tmp;
-    rc = w8_stats_of(ctx, Sa, np, w.dS, w.mxS, w.ssqS, w.eS, w.dssqS, w.sA, nullptr, Ss, w, w.stats + 0, s);
-    if (!rc) rc = w8_stats_of(ctx, Va, np, w.dV, w.mxV, w.ssqV, w.eV, w.dssqV, w.sB, w.dS, Vs, w, w.stats + 1, s);
+    // statistics + digit slices of the off-diagonal parts F (of S) and Fv (of V)
+    rc = w8_stats_of(ctx, Sa, np, w.dS, w.mxS, w.ssqS, w.eS, w.dssqS, w.sA, nullptr, true, w, w.stats + 0, s);
+    if (!rc) rc = w8_stats_of(ctx, Va, np, w.dV, w.mxV, w.ssqV, w.eV, w.dssqV, w.sB, w.dS, true, w, w.stats + 1, s);
     if (rc) return rc;
-    // r = S_s (V_s (S_s 1)): the row sums of W in fp64, while the symmetrised copies are whole
+    // r = the row sums of sym(S V S) in fp64: the mean of (Sa Va Sa) 1 (row-type products) and (Sa Va Sa)^T 1 (column-type)
     hipLaunchKernelGGL(k_w8_fill_ones, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, w.r2, n, np);
-    rc = eagle_dev_colgemv(ctx, Ss, n, np, w.r2, w.r1, stream);
-    if (!rc) rc = eagle_dev_colgemv(ctx, Vs, n, np, w.r1, w.r2, stream);
-    if (!rc) rc = eagle_dev_colgemv(ctx, Ss, n, np, w.r2, w.r, stream);
+    rc = eagle_dev_colgemv_parts(ctx, Sa, n, np, w.r2, w.r1, w.gvpart, stream);
+    if (!rc) rc = eagle_dev_colgemv_parts(ctx, Va, n, np, w.r1, w.r, w.gvpart, stream);
+    if (!rc) rc = eagle_dev_colgemv_parts(ctx, Sa, n, np, w.r, w.r1, w.gvpart, stream);     // r1 = (Sa Va Sa)^T 1
     if (rc) return rc;
+    hipLaunchKernelGGL(k_w8_rowgemv, dim3((unsigned)(np / 4)), dim3(256), 0, s, Sa, n, np, (const double*)w.r2, w.r);
+    hipLaunchKernelGGL(k_w8_rowgemv, dim3((unsigned)(np / 4)), dim3(256), 0, s, Va, n, np, (const double*)w.r, w.gvpart);
+    hipLaunchKernelGGL(k_w8_rowgemv, dim3((unsigned)(np / 4)), dim3(256), 0, s, Sa, n, np, (const double*)w.gvpart, w.r);   // r = (Sa Va Sa) 1
+    hipLaunchKernelGGL(k_w8_mean2, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, (const double*)w.r, (const double*)w.r1, np, w.r);
     W8Stats st[3];
     if ((rc = w8_fetch(ctx, st, w.stats, 2 * sizeof(W8Stats), s))) return rc;
     W8Info info;
@@ -714,25 +912,29 @@ extern "C" int eagle_dev_scan_operands_w8(eagle_ctx* ctx, const double* Sa, cons
     const double normS = (st[0].maxd + sqrt(st[0].fro2 * up)) * up, normV = (st[1].maxd + sqrt(st[1].fro2 * up)) * up;
     const double wd_est = st[1].wdsum / (double)n;               // mean_k |W_kk| ~ mean_k D_k^2 |Dv_k|
     const double target = W8_TARGET * ctx->scan_budget * wd_est;
-    // operands symmetric to rounding only (as the fp64 path asks of its symmetric pipeline); what the antisymmetric parts
-    // A = (S - S^T)/2, B = (V - V^T)/2 still change in the symmetric part of S V S is second order: A V A + A B S + S B A + A B A
-    if (!(st[0].asym <= 1e-12 * st[0].maxd) || !(st[1].asym <= 1e-12 * st[1].maxd)) { info.declined = 2; ctx->w8_info = info; return 1; }
-    const double nA = 0.5 * (double)np * st[0].asym, nB = 0.5 * (double)np * st[1].asym;
-    const double asym = (nA * nA * normV + 2.0 * nA * nB * normS + nA * nA * nB) * up;
+    // The images stand in for their transposes (NT products, upper triangle only).  With A = (Sa - Sa^T)/2, B = (Va - Va^T)/2:
+    // computed W' = Sa Vs Sa^T + Sa B Sa^T - 2 Sa B D against T' = Sa Va Sa, whose symmetric part is what the scan's quadratic
+    // forms see:  || W' - T' ||_F <= 2 ||S|| (||V|| ||A||_F + (||A|| + max|D|) ||B||_F),  and folding the upper triangle of T' instead of
+    // symmetrising it costs || antisym(T') ||_F <= 2 ||A||_F ||V|| ||S|| + ||S||^2 ||B||_F (+ second order).  Visibly asymmetric
+    // operands make this term large and the call declines (the fp64 path then takes its general products).
+    const double nA = 0.5 * st[0].asym * up, nB = 0.5 * st[1].asym * up;
+    const double asym = (M_SQRT2 * 2.0 * normS * (normV * nA + (nA + st[0].maxd) * nB) + 2.0 * nA * normV * normS + normS * normS * nB +
+                         2.0 * (nA * nA * normV + 2.0 * nA * nB * normS)) * up;
     info.asym_term = asym;
     if (!(target > 0.0) || !(asym <= 0.25 * target)) { info.declined = 2; ctx->w8_info = info; return 1; }
     double b1 = 0.0;
-    const int c1 = w8_choose(st[0], st[1], np, 0.4 * (target - asym) / (normS * M_SQRT2), &b1);
+    // (the bounds fall ~13x per configuration step: the second product is left with at least 30 % of the target, rarely one step's worth)
+    const int c1 = w8_choose(st[0], st[1], np, 0.7 * (target - asym) / (normS * M_SQRT2), &b1);
     if (c1 < 0) { info.declined = 3; ctx->w8_info = info; return 1; }
     const W8Group* groups_dev = nullptr;
     rc = w8_product(ctx, c1, false, np, w.sA, w.sB, w, s, [&](const W8List& l, long img, long row0, long rows) {
-        hipLaunchKernelGGL(k_w8_combine1, dim3((unsigned)(np / 256), (unsigned)rows), dim3(256), 0, s, (const double*)Ss, (const double*)Vs, np, (const double*)w.dS, (const double*)w.dV,
+        hipLaunchKernelGGL(k_w8_combine1, dim3((unsigned)(np / 256), (unsigned)rows), dim3(256), 0, s, Sa, Va, np, (const double*)w.dS, (const double*)w.dV,
                            (const int*)w.eS, (const int*)w.eV, (const int32_t*)w.levels, img, (const W8Group*)l.groups, l.ngroups, row0, tmp);
     });
     (void)groups_dev;
     if (rc) { if (rc == 1) { info.declined = 5; ctx->w8_info = info; } return rc; }
     // X = tmp: statistics + slices (over Fv's)
-    rc = w8_stats_of(ctx, tmp, np, w.dX, w.mxX, w.ssqX, w.eX, w.dssqX, w.sB, nullptr, nullptr, w, w.stats + 2, s);
+    rc = w8_stats_of(ctx, tmp, np, w.dX, w.mxX, w.ssqX, w.eX, w.dssqX, w.sB, nullptr, false, w, w.stats + 2, s);
     if (rc) return rc;
     if ((rc = w8_fetch(ctx, st + 2, w.stats + 2, sizeof(W8Stats), s))) return rc;
     if (st[2].bad) { info.declined = 1; ctx->w8_info = info; return 1; }
@@ -745,7 +947,7 @@ extern "C" int eagle_dev_scan_operands_w8(eagle_ctx* ctx, const double* Sa, cons
     const int c2 = w8_choose(st[0], st[2], np, (target - used) / M_SQRT2 * 0.98, &b2);
     if (c2 < 0) { info.declined = 4; ctx->w8_info = info; return 1; }
     rc = w8_product(ctx, c2, true, np, w.sA, w.sB, w, s, [&](const W8List& l, long img, long row0, long rows) {
-        hipLaunchKernelGGL(k_w8_combine2, dim3((unsigned)(np / 32), (unsigned)(rows / 32)), dim3(256), 0, s, (const double*)Ss, (const double*)tmp, np, (const double*)w.dS,
+        hipLaunchKernelGGL(k_w8_combine2, dim3((unsigned)(np / 32), (unsigned)(rows / 32)), dim3(256), 0, s, Sa, (const double*)tmp, np, (const double*)w.dS,
                            (const double*)w.dX, (const int*)w.eS, (const int*)w.eX, (const int32_t*)w.levels, img, (const W8Group*)l.groups, l.ngroups, row0,
                            Wu_out);
     });

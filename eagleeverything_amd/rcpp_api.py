@@ -122,6 +122,27 @@ def set_scan_budget(relative_budget, device=0):
     _check(ctx, _lib.load().eagle_set_scan_budget(ctx, float(relative_budget)))
 
 
+def set_w_mode(mode, device=0):
+    """Which engine forms W = S (V S) for a digit-slice scan: 1 (default) = int8 digit slices from 4,096 padded individuals up, 0 = always
+    the fp64 GEMM, 2 = int8 at any size (eagle_set_w_mode, csrc/eagle_w8.hip)."""
+    ctx = context(device)
+    _check(ctx, _lib.load().eagle_set_w_mode(ctx, int(mode)))
+
+
+class _WInfo(C.Structure):
+    _fields_ = [("int8", C.c_int), ("declined", C.c_int), ("k1", C.c_int), ("T1", C.c_int), ("pairs1", C.c_int), ("k2", C.c_int), ("T2", C.c_int),
+                ("pairs2", C.c_int), ("eta", C.c_double), ("eta_x", C.c_double), ("target", C.c_double), ("mean_diag", C.c_double),
+                ("asym_term", C.c_double)]
+
+
+def last_w_info(device=0):
+    """eagle_last_w_info as a dict: which engine formed the W of the last scan on this device, its configuration and error bound."""
+    ctx = context(device)
+    i = _WInfo()
+    _check(ctx, _lib.load().eagle_last_w_info(ctx, C.byref(i)))
+    return {k: getattr(i, k) for k, _ in _WInfo._fields_}
+
+
 def drop_cache(device=0):
     _lib.load().eagle_drop_cache(context(device))
 

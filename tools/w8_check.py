@@ -28,6 +28,7 @@ del MMt, P
 sh.set_operands(S, V, ahat)
 sh._check(lib.eagle_set_scan_budget(sh.ctx, budget))
 sh.mode = 1
+if os.environ.get('TUNE'): lib.eagle_dev_set_tune(sh.ctx, int(os.environ['TUNE']))
 out = {"n": n, "L": L, "budget": budget}
 
 def timed(fn, reps):
