@@ -116,7 +116,7 @@ extern "C" eagle_ctx* eagle_open(int device) {
     // EAGLE_HIP_SCAN_BUDGET=1e-7: the digit budget of the int8 scan for an R session that has no call for it (eagle_set_scan_budget)
     if (const char* bv = getenv("EAGLE_HIP_SCAN_BUDGET")) {
         const double b = atof(bv);
-        if (b >= 1e-12 && b <= 5e-7) ctx->scan_budget = b;
+        if (b >= 1e-12 && b <= 5e-7) ctx->scan_budget = ctx->scan_budget_tight = b;
     }
     // the loader stream outranks the compute stream: its decode / unpack / fill kernels are microseconds of work that must get
     // onto CUs the scan kernel's long-lived workgroups fill completely (2 waves x 256 VGPRs per SIMD), as soon as one retires
@@ -344,10 +344,16 @@ extern "C" int eagle_set_scan_rounding(eagle_ctx* ctx, int stochastic) {
     return EAGLE_OK;
 }
 extern "C" int eagle_set_scan_budget(eagle_ctx* ctx, double relative_budget) {
+    if (ctx && relative_budget == 0.0) {   // the default policy: 1e-7 where the digits that run certify it, else 5e-7
+        ctx->scan_budget = 5e-7; ctx->scan_budget_tight = 1e-7; ctx->spectral_off = false;
+        for (eagle_ctx* p : ctx->peers) { p->scan_budget = 5e-7; p->scan_budget_tight = 1e-7; p->spectral_off = false; }
+        return EAGLE_OK;
+    }
     if (!ctx || !(relative_budget >= 1e-12 && relative_budget <= 5e-7)) return EAGLE_ERR_ARG;   // 1.8 x budget is enforced per marker: never above 0.9e-6
-    ctx->scan_budget = relative_budget;
+    // a budget asked for is THE budget: nothing tighter is tried first (the default context tries 1e-7, then 5e-7; relative_budget = 0 restores that)
+    ctx->scan_budget = ctx->scan_budget_tight = relative_budget;
     ctx->spectral_off = false;
-    for (eagle_ctx* p : ctx->peers) { p->scan_budget = relative_budget; p->spectral_off = false; }
+    for (eagle_ctx* p : ctx->peers) { p->scan_budget = p->scan_budget_tight = relative_budget; p->spectral_off = false; }
     return EAGLE_OK;
 }
 // on = 0: this context stops taking a digit off under the spectral bound (what eagle_calculate_a_and_vara does by itself after a
@@ -1442,7 +1448,7 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
         const double glb = rv ? rv->vmax : lb;
         if (Lr > 0) {
             eagle_cert_info hd;
-            rc = eagle_dev_cert_select_b(ctx, Lr, ctx->d_a, ctx->d_vara, ctx->d_bound, cert, glb, ctx->stream);
+            rc = eagle_dev_cert_select_b(ctx, Lr, ctx->d_a, ctx->d_vara, ctx->d_bound, cert, glb, ws, ctx->stream);
             if (!rc) {
                 e = hipMemcpyAsync(&hd, cert, sizeof hd, hipMemcpyDeviceToHost, ctx->stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1526,12 +1532,14 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
         HIPCHK(ctx, hipMemcpyAsync(vara_out + m0, ctx->d_vara, sizeof(double) * (size_t)Lr, hipMemcpyDeviceToHost, ctx->stream));
     }
     HIPCHK(ctx, hipMemcpyAsync(totals, cert_totals, sizeof totals, hipMemcpyDeviceToHost, ctx->stream));
-    struct { double maxabs_off; int S, pad; double bound, sumdiag, R, specH; int S_sliced, pad2; } vh = {};   // head of the digit workspace (VaraHdr)
+    struct { double maxabs_off; int S, pad; double bound, sumdiag, R, specH; int S_sliced, pad2; double budget; int e, pad3; unsigned long long lo_sumsq;
+             int maxdiag, hi_overflow, spec_try2, level; double wErr; } vh = {};   // head of the digit workspace (VaraHdr)
     if (use_i8 && Lr > 0) HIPCHK(ctx, hipMemcpyAsync(&vh, ws, sizeof vh, hipMemcpyDeviceToHost, ctx->stream));
     ph.mark(ctx->stream, PH_D2H);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cert_reevaluated = totals[0]; ctx->cert_flagged = totals[1]; ctx->cert_fell_back = totals[2] != 0;
     ctx->scan_digits_used = vh.S; ctx->scan_digits_cut = vh.S_sliced; ctx->scan_specH = vh.specH;
+    ctx->scan_budget_used = vh.budget; ctx->scan_bound_level = vh.level; ctx->scan_w_err = vh.wErr;
     // a scan that took a digit off under the spectral bound and then had to redo a block in fp64: markers of this data set sit
     // outside what the bound covers -- this context keeps the worst-case digit count from now on (eagle_set_scan_budget re-arms)
     if (ctx->cert_fell_back && vh.specH > 0.0) ctx->spectral_off = true;
@@ -1668,6 +1676,13 @@ extern "C" int eagle_last_scan_certificate(eagle_ctx* ctx, long* n_reevaluated, 
     return EAGLE_OK;
 }
 
+extern "C" int eagle_last_scan_budget(eagle_ctx* ctx, double* budget_used, int* bound_level, double* w_error_bound) {
+    if (!ctx) return EAGLE_ERR_ARG;
+    if (budget_used) *budget_used = ctx->scan_budget_used;
+    if (bound_level) *bound_level = ctx->scan_bound_level;
+    if (w_error_bound) *w_error_bound = ctx->scan_w_err;
+    return EAGLE_OK;
+}
 extern "C" int eagle_set_w_mode(eagle_ctx* ctx, int mode) {
     if (!ctx || mode < 0 || mode > 2) return EAGLE_ERR_ARG;
     ctx->w_mode = mode;

@@ -55,6 +55,8 @@ struct eagle_ctx {
     int scan_slices = 0; // 0 = chosen per call from the error bound (3..7), 1..8 = fixed
     int scan_stochastic = 0;  // 1 = digits of W rounded at random (unbiased): probabilistic certificate, one digit fewer (opt-in)
     double scan_budget = 5e-7;  // relative digit budget of the int8 scan (eagle_set_scan_budget): half of the path's 1e-6 tolerance
+    double scan_budget_tight = 1e-7;  // tried first (round 4): the budget in force is this one whenever the digits that run certify it too; eagle_set_scan_budget sets both
+    double scan_budget_used = 0.0; int scan_bound_level = 0; double scan_w_err = 0.0;   // of the last digit-slice scan (eagle_last_scan_budget)
     bool spectral_off = false;  // a scan that took a digit off under the spectral bound fell back to fp64: this context stops trying
     std::vector<GenoEntry> cache;
     // results of the last calls, kept in HBM

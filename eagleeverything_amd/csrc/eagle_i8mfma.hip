@@ -194,6 +194,10 @@ struct VaraHdr {        // head of the workspace, written on the device, never r
     // W itself came from int8 digit slices (eagle_w8.hip): || Wu - truth ||_F <= wErr, i.e. |error of marker i| <= wErr sum_j m'_ij^2 on top
     // of the digit terms (0: the fp64 products)
     double wErr;
+    // round 4: the budget is tried TIGHT first (1e-7 unless eagle_set_scan_budget fixed one): `budget` above is the one in force for this
+    // scan -- the tight one if the digits that run certify a marker with q2 = n_pad to it, else the default; specH1 = level 1's bound while
+    // level 2 is being tried
+    double specH1;
 };
 __global__ __launch_bounds__(256) void k_absmax_offdiag(const double* __restrict__ x, long np, unsigned long long* __restrict__ bits) {
     double m = 0.0;
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(256) void k_absmax_offdiag(const double* __restrict
 #define VARA_HOEFFDING_K 8.355  /* sqrt(ln(2 / 1e-30)) */
 // One block: dW[k] = Wu[k][k] (contiguous copy), sumdiag in a fixed order, then the slice count (forced = 1..8: that S).
 __global__ __launch_bounds__(256) void k_vara_prep(const double* __restrict__ Wu, long n_pad, int forced_arg, VaraHdr* __restrict__ hdr,
-                                                   double* __restrict__ dW, double budget, double wErr) {
+                                                   double* __restrict__ dW, double budget, double wErr, double tight) {
     const int forced = forced_arg & 0xff, stochastic = (forced_arg & EAGLE_SLICES_STOCHASTIC) ? 1 : 0;
     double s = 0.0;
     for (long k = threadIdx.x; k < n_pad; k += 256) {
@@ -269,7 +273,11 @@ __global__ __launch_bounds__(256) void k_vara_prep(const double* __restrict__ Wu
         hdr->S = S;
         hdr->S_sliced = S;
         hdr->specH = 0.0;
-        hdr->budget = budget;
+        // in force: the tight budget if the worst-case bound of the digits chosen meets it too (a forced count: the context's budget)
+        hdr->budget = (forced <= 0 && mx > 0.0 && tight < budget &&
+                       (stochastic ? VARA_HOEFFDING_K * (double)n_pad * ldexp(1.0, e + 1 - 8 * S) : ldexp(nn, e + 1 - 8 * S)) + wErr * (double)n_pad <= tight * 0.5 * red[0])
+                          ? tight : budget;
+        hdr->specH1 = 0.0;
         hdr->wErr = wErr;
         hdr->e = e;
         hdr->pad = stochastic;
@@ -458,7 +466,7 @@ __global__ __launch_bounds__(512, 2) void k_gram_hi_i8(const int8_t* __restrict_
 // One block: g = max_j rs[j]; the decision (see above).  rs is exact, the fp64 steps round up.  level 1: rs = row sums of |Ds Ds|;
 // level 2 (spec_try2 left by level 1): rs = row sums of |E_hi E_hi|, with max_j G_jj and ||E_lo||_F^2 in the header.
 __global__ __launch_bounds__(256) void k_spectral_decide(const unsigned long long* __restrict__ rs, long n_pad, VaraHdr* __restrict__ hdr, double budget,
-                                                         int smax, int level, int shift) {
+                                                         double tight, int smax, int level, int shift) {
     if (level == 2 && !hdr->spec_try2) return;
     unsigned long long g = 0;
     for (long k = threadIdx.x; k < n_pad; k += 256) g = rs[k] > g ? rs[k] : g;
@@ -472,22 +480,36 @@ __global__ __launch_bounds__(256) void k_spectral_decide(const unsigned long lon
     if (threadIdx.x == 0) {
         const double mx = hdr->maxabs_off;
         const int S = hdr->S_sliced;
-        if (mx > 0.0 && S >= 2 && S < smax && hdr->S == S && !hdr->pad && !(level == 2 && hdr->hi_overflow)) {
+        if (mx > 0.0 && S >= 2 && S < smax && hdr->S == S && !hdr->pad) {
             const int e = hdr->e;
             const double u = ldexp(1.0, e + 2 - 8 * S);
             const double up = 1.0 + 0x1p-50;
-            double normsq = (double)red[0] * up;       // red[0] < 2^53 for n_pad < 2^19: the conversion is exact or rounds within `up`
-            if (level == 2)   // max_j G_jj + 2^s sqrt(max row sum |E_hi E_hi|) + ||E_lo||_F, every step rounded up
-                normsq = ((double)hdr->maxdiag + ldexp(sqrt(normsq) * up, shift) + sqrt((double)hdr->lo_sumsq * up) * up) * up;
-            const double normDs = sqrt(normsq) * up;
-            const double H = 0.5 * u * (normDs + 0.5 * (double)(n_pad - 1)) * up;
-            if ((H + hdr->wErr) * (double)n_pad <= budget * 0.5 * hdr->sumdiag) {
+            double H = 0.0;   // this level's bound (level 2 with an entry of E_hi outside int8: none)
+            if (!(level == 2 && hdr->hi_overflow)) {
+                double normsq = (double)red[0] * up;       // red[0] < 2^53 for n_pad < 2^19: the conversion is exact or rounds within `up`
+                if (level == 2)   // max_j G_jj + 2^s sqrt(max row sum |E_hi E_hi|) + ||E_lo||_F, every step rounded up
+                    normsq = ((double)hdr->maxdiag + ldexp(sqrt(normsq) * up, shift) + sqrt((double)hdr->lo_sumsq * up) * up) * up;
+                const double normDs = sqrt(normsq) * up;
+                H = 0.5 * u * (normDs + 0.5 * (double)(n_pad - 1)) * up;
+            }
+            // a marker with q2 = n_pad inside budget b of 0.5 sum_k |W_kk|, the error of W itself (wErr) included
+            auto pass = [&](double Hx, double b) { return Hx > 0.0 && (Hx + hdr->wErr) * (double)n_pad <= b * 0.5 * hdr->sumdiag; };
+            auto take = [&](double Hx, int lev, double b) {
                 hdr->S = S - 1;
-                hdr->specH = H;
-                hdr->level = level;
+                hdr->specH = Hx;
+                hdr->level = lev;
+                hdr->budget = b;
                 hdr->bound = ldexp((double)n_pad * (double)n_pad, e + 1 - 8 * (S - 1)) * (1.0 + 0x1p-8);
-            } else if (level == 1) {
-                hdr->spec_try2 = S < smax - 1;   // a spare slot of the slice area for E_hi
+            };
+            // Order: the tight budget first (level 1, then level 2), then the default (level 1's bound, then level 2's).
+            if (level == 1) {
+                if (pass(H, tight)) take(H, 1, tight);
+                else if (S < smax - 1) { hdr->specH1 = H; hdr->spec_try2 = 1; }   // a spare slot of the slice area for E_hi: level 2 decides
+                else if (pass(H, budget)) take(H, 1, budget);
+            } else {
+                if (pass(H, tight)) take(H, 2, tight);
+                else if (pass(hdr->specH1, budget)) take(hdr->specH1, 1, budget);
+                else if (pass(H, budget)) take(H, 2, budget);
             }
         }
         if (level == 2) hdr->spec_try2 = 0;
@@ -1487,7 +1509,9 @@ __global__ __launch_bounds__(256) void k_cert_lb_b(const double* __restrict__ a,
     if ((threadIdx.x & 63) == 0 && best > 0.0 && isfinite(best)) atomicMax(&ch->lb_bits, (unsigned long long)__double_as_longlong(best));
 }
 __global__ __launch_bounds__(256) void k_cert_select_b(const double* __restrict__ a, const double* __restrict__ vara, const double* __restrict__ bound,
-                                                       long L, CertHdr* __restrict__ ch, long* __restrict__ idx, double lb, double flag_rel) {
+                                                       long L, CertHdr* __restrict__ ch, long* __restrict__ idx, double lb, double flag_rel_default,
+                                                       const VaraHdr* __restrict__ hdr) {
+    const double flag_rel = hdr ? VARA_FLAG_FACTOR * hdr->budget : flag_rel_default;   // the budget in force for this scan
     const double thr = lb * (1.0 - 1e-9);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L; i += (long)gridDim.x * 256) {
         const double x = a[i], v = vara[i];
@@ -1537,13 +1561,13 @@ extern "C" int eagle_dev_cert_lb_b(eagle_ctx* ctx, long L, const double* a, cons
 }
 // candidates against `lb` into the index list of cert_ws (count / flagged / overflow in its head, which eagle_dev_cert_lb_b zeroed)
 extern "C" int eagle_dev_cert_select_b(eagle_ctx* ctx, long L, const double* a, const double* vara, const double* bound, void* cert_ws, double lb,
-                                       void* stream) {
+                                       const void* vara_ws, void* stream) {
     if (L < 0 || !cert_ws) return eagle_fail(ctx, EAGLE_ERR_ARG, "cert_select_b: bad arguments");
     if (L == 0) return EAGLE_OK;
     unsigned blocks = (unsigned)((L + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_cert_select_b, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, vara, bound, L, (CertHdr*)cert_ws,
-                       (long*)((char*)cert_ws + cert_idx_off()), lb, VARA_FLAG_FACTOR * ctx->scan_budget);
+                       (long*)((char*)cert_ws + cert_idx_off()), lb, VARA_FLAG_FACTOR * ctx->scan_budget, (const VaraHdr*)vara_ws);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "k_cert_select_b");
     return EAGLE_OK;
@@ -1653,7 +1677,7 @@ extern "C" int eagle_dev_vara_i8_prepare_part(eagle_ctx* ctx, const int8_t* Mt8,
         // W from the int8 engine (eagle_w8.hip, the image it left is the one being prepared): its error bound rides in the header, and
         // the correction vector of the re-centred markers comes from r = S (V (S 1)) instead of the row sums of this image
         const bool w8 = ctx->w8_active && ctx->w8_Wu == Wu;
-        hipLaunchKernelGGL(k_vara_prep, dim3(1), dim3(256), 0, s, Wu, n_pad, nslices, hdr, dW, ctx->scan_budget, w8 ? ctx->w8_eta : 0.0);
+        hipLaunchKernelGGL(k_vara_prep, dim3(1), dim3(256), 0, s, Wu, n_pad, nslices, hdr, dW, ctx->scan_budget, w8 ? ctx->w8_eta : 0.0, ctx->scan_budget_tight);
         // correction terms of the re-centred markers: rho and R from Wu, m^T rho from the genotype pass
         double* colpart = (double*)((char*)ws + ws_cp_off(n_pad, L_pad, smax));
         if (w8) {
@@ -1691,7 +1715,7 @@ extern "C" int eagle_dev_vara_i8_prepare_part(eagle_ctx* ctx, const int8_t* Mt8,
             if (e != hipSuccess) return eagle_fail_hip(ctx, e, "spectral row sums memset");
             hipLaunchKernelGGL(k_gram_rowabs_i8, dim3((unsigned)((npairs + 7) / 8 * 8)), dim3(512), 0, s, Ds, n_pad, pairs, npairs, n_pad / BK8, rsum,
                                (const int*)nullptr);
-            hipLaunchKernelGGL(k_spectral_decide, dim3(1), dim3(256), 0, s, rsum, n_pad, hdr, ctx->scan_budget, smax, 1, 0);
+            hipLaunchKernelGGL(k_spectral_decide, dim3(1), dim3(256), 0, s, rsum, n_pad, hdr, ctx->scan_budget, ctx->scan_budget_tight, smax, 1, 0);
             // second level, dropped on the device unless the first declined: E_hi into the next spare slot, then its Gram row sums
             int8_t* Ehi = Bs + (size_t)(smax - 2) * n_pad * n_pad;
             int shift = 8;   // 127 * 2^shift >= 8 standard deviations sqrt(n) 74^2 of a random Gram entry
@@ -1701,7 +1725,7 @@ extern "C" int eagle_dev_vara_i8_prepare_part(eagle_ctx* ctx, const int8_t* Mt8,
             if (e != hipSuccess) return eagle_fail_hip(ctx, e, "spectral row sums memset");
             hipLaunchKernelGGL(k_gram_rowabs_i8, dim3((unsigned)((npairs + 7) / 8 * 8)), dim3(512), 0, s, Ehi, n_pad, pairs, npairs, n_pad / BK8, rsum,
                                (const int*)&hdr->spec_try2);
-            hipLaunchKernelGGL(k_spectral_decide, dim3(1), dim3(256), 0, s, rsum, n_pad, hdr, ctx->scan_budget, smax, 2, shift);
+            hipLaunchKernelGGL(k_spectral_decide, dim3(1), dim3(256), 0, s, rsum, n_pad, hdr, ctx->scan_budget, ctx->scan_budget_tight, smax, 2, shift);
         }
     }
     e = hipGetLastError();

@@ -7,7 +7,7 @@
 #endif
 
 #define W8_KMAX 6         /* digits cut per operand row (48 bits below the row's scale) */
-#define W8_TARGET 0.02    /* the W error the configurations are chosen for, as a fraction of budget x mean|W_kk| */
+#define W8_TARGET 0.02    /* the W error the configurations are chosen for, as a fraction of (tight) budget x mean|W_kk| */
 #define W8_ACCEPT 0.05    /* ... and what the finished W must meet against its own diagonal, or the call declines */
 
 struct W8Stats {          // per operand, reduced on the device (k_w8_reduce)

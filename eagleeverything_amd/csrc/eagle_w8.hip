@@ -911,7 +911,9 @@ extern "C" int eagle_dev_scan_operands_w8(eagle_ctx* ctx, const double* Sa, cons
     const double up = 1.0 + 1e-9;
     const double normS = (st[0].maxd + sqrt(st[0].fro2 * up)) * up, normV = (st[1].maxd + sqrt(st[1].fro2 * up)) * up;
     const double wd_est = st[1].wdsum / (double)n;               // mean_k |W_kk| ~ mean_k D_k^2 |Dv_k|
-    const double target = W8_TARGET * ctx->scan_budget * wd_est;
+    // chosen for the TIGHT budget the scan tries first (k_spectral_decide): a W error that ate the little room the spectral bound leaves there
+    // would cost the scan its tighter certificate (or a digit); accepted, at the end, against the budget the scan falls back to
+    const double target = W8_TARGET * ctx->scan_budget_tight * wd_est;
     // The images stand in for their transposes (NT products, upper triangle only).  With A = (Sa - Sa^T)/2, B = (Va - Va^T)/2:
     // computed W' = Sa Vs Sa^T + Sa B Sa^T - 2 Sa B D against T' = Sa Va Sa, whose symmetric part is what the scan's quadratic
     // forms see:  || W' - T' ||_F <= 2 ||S|| (||V|| ||A||_F + (||A|| + max|D|) ||B||_F),  and folding the upper triangle of T' instead of

@@ -122,6 +122,14 @@ def set_scan_budget(relative_budget, device=0):
     _check(ctx, _lib.load().eagle_set_scan_budget(ctx, float(relative_budget)))
 
 
+def last_scan_budget(device=0):
+    """(budget in force for the last digit-slice scan, level of the spectral bound that took the digit off, error bound of an int8-made W)."""
+    ctx = context(device)
+    b, lv, we = C.c_double(), C.c_int(), C.c_double()
+    _check(ctx, _lib.load().eagle_last_scan_budget(ctx, C.byref(b), C.byref(lv), C.byref(we)))
+    return b.value, lv.value, we.value
+
+
 def set_w_mode(mode, device=0):
     """Which engine forms W = S (V S) for a digit-slice scan: 1 (default) = int8 digit slices from 4,096 padded individuals up, 0 = always
     the fp64 GEMM, 2 = int8 at any size (eagle_set_w_mode, csrc/eagle_w8.hip)."""

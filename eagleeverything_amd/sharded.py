@@ -400,7 +400,9 @@ class DeviceShard:
 
     def vara_i8_info(self):
         """(slices used, absolute error bound, max |off-diagonal W|) of the last int8-slice vara launch (synchronises)."""
-        h = self.ws[:96].cpu().numpy().tobytes()
+        h = self.ws[:112].cpu().numpy().tobytes()
+        self.last_budget = float(np.frombuffer(h[56:64], dtype=np.float64)[0])   # the budget in force (tight one first: eagle_last_scan_budget)
+        self.last_wErr = float(np.frombuffer(h[96:104], dtype=np.float64)[0])    # || W - S V S ||_F bound of a W from the int8 engine (0: fp64 products)
         self.last_level = int(np.frombuffer(h[92:96], dtype=np.int32)[0])   # which level of the spectral bound took the digit off (0: none)
         self.last_e = int(np.frombuffer(h[64:68], dtype=np.int32)[0])   # scale exponent of the digits: unit of digit s = 2^(e + 2 - 8 (s + 1))
         self.last_sumdiag = float(np.frombuffer(h[24:32], dtype=np.float64)[0])  # sum_k |W_kk|

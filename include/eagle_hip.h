@@ -414,6 +414,12 @@ int eagle_last_scan_certificate(eagle_ctx* ctx, long* n_reevaluated, long* n_fla
 /* Digit slices of the LAST eagle_calculate_a_and_vara call in digit-slice mode: used by the scan, cut from W (the same, or one more
  * when the spectral bound took the last one off), and that bound (|error_i| <= spectral_bound * sum_j m'_ij^2; 0 = not in use). */
 int eagle_last_scan_digits(eagle_ctx* ctx, int* digits_used, int* digits_cut, double* spectral_bound);
+/* Round 4.  The budget IN FORCE for the last digit-slice scan (what its certificate enforced per marker is 1.8 x this), the level of the
+ * spectral bound that took the last digit off (0: none, 1, 2) and the error bound of W itself when the int8 engine formed it (0: fp64
+ * products).  A context whose budget was never set tries 1e-7 first and falls back to 5e-7: the tight budget is in force whenever
+ * the digits that run anyway certify a marker with q2 = n_pad to it (worst-case bound, or the spectral bound at level 1 / 2);
+ * eagle_set_scan_budget(b) makes b the only budget, eagle_set_scan_budget(0) restores the default policy. */
+int eagle_last_scan_budget(eagle_ctx* ctx, double* budget_used, int* bound_level, double* w_error_bound);
 /* Out-of-core bookkeeping of the LAST call of this ctx that streamed its file through HBM in marker chunks (a file larger than
  * free HBM or than EAGLE_HIP_MAX_RESIDENT_GB; the lead device's share in a multi-device context): what SURVEY 8(d) asks to be
  * reported for the streamed configurations.  The loader of chunk k+1 (pread -> pinned -> H2D -> decode / 2-bit unpack) runs

@@ -17,7 +17,9 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-RTOL_DIGITS = 9e-7  # what the digit-slice certificate enforces per marker (1.8 x the default budget 5e-7; north_star: 1e-6)
+RTOL_DIGITS = 1e-7  # vara from the digit-slice kernels against the oracle: the level actually MEASURED on these cases (1e-8 and below), so that
+# an order of magnitude of drift shows; what the certificate ENFORCES per marker is RTOL_ENFORCED = 1.8 x the budget in force (9e-7 at most; north_star: 1e-6)
+RTOL_ENFORCED = 9e-7
 
 
 @pytest.fixture(scope="module")

@@ -14,9 +14,9 @@ from eagleeverything_amd import synth
 pytestmark = pytest.mark.gpu
 NA = np.nan
 RTOL = 1e-9        # a, and vara from the fp64 MFMA kernel (mode 0)
-RTOL_DIGITS = 9e-7  # vara from the digit-slice kernels: what the certificate ENFORCES per marker (1.8 x the default budget of 5e-7; a
-                    # marker whose bound is larger is re-evaluated in fp64), inside the 1e-6 relative tolerance BASELINE.json's
-                    # north_star states for the score statistics.  Measured errors on unstructured operands are orders smaller.
+RTOL_DIGITS = 1e-7  # vara from the digit-slice kernels against the oracle: the level actually MEASURED on these cases (1e-8 and below), so that
+# an order of magnitude of drift shows; what the certificate ENFORCES per marker is RTOL_ENFORCED = 1.8 x the budget in force (9e-7 at most; north_star: 1e-6)
+RTOL_ENFORCED = 9e-7
 
 
 @pytest.fixture(scope="module")

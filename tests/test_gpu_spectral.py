@@ -98,22 +98,26 @@ def test_one_digit_fewer_under_a_rigorous_spectral_bound():
     assert H_host <= sh.last_specH <= H_host * (1 + 1e-12)
 
 
-def _host_decision(Wu, n_pad, budget=5e-7):
-    """The library's digit rule restated on the host: (worst-case digit count, level of the spectral bound that takes one off or 0, H)."""
+def _host_decision(Wu, n_pad, budget=5e-7, tight=1e-7, w_err=0.0):
+    """The library's digit rule restated on the host (round 4: the tight budget is tried first, at both levels, then the default):
+    (worst-case digit count, level of the spectral bound that takes one off or 0, H, budget in force)."""
     off = np.triu(Wu, 1)
     mx = np.abs(off).max()
     f, e = np.frexp(mx)
     e = int(e) - (1 if f <= 0.98 else 0)
-    target = budget * 0.5 * np.abs(np.diag(Wu)).sum()
-    S_wc = next((c for c in range(3, 8) if float(n_pad) ** 2 * 2.0 ** (e + 1 - 8 * c) <= target), 7)
+    half_sumdiag = 0.5 * np.abs(np.diag(Wu)).sum()
+    wc = lambda c: float(n_pad) ** 2 * 2.0 ** (e + 1 - 8 * c) + w_err * n_pad
+    S_wc = next((c for c in range(3, 8) if wc(c) <= budget * half_sumdiag), 7)
+    in_force = tight if wc(S_wc) <= tight * half_sumdiag else budget
     Q = np.rint(np.ldexp(off, 8 * S_wc - (e + 2)))
     d = (np.mod(Q + 128, 256) - 128).astype(np.int64)
     Ds = d + d.T
     G = Ds @ Ds
     u = 2.0 ** (e + 2 - 8 * S_wc)
     H1 = 0.5 * u * (np.sqrt(float(np.abs(G).sum(axis=1).max())) + 0.5 * (n_pad - 1))
-    if H1 * n_pad <= target:
-        return S_wc, 1, H1
+    ok = lambda H, b: H > 0.0 and (H + w_err) * n_pad <= b * half_sumdiag
+    if ok(H1, tight):
+        return S_wc, 1, H1, tight
     # level 2: lambda_max(G) <= max G_jj + 2^s ||E_hi||_2 + ||E_lo||_F
     shift = 8
     while shift < 23 and 127.0 * (1 << shift) < 8.0 * 5476.0 * np.sqrt(n_pad):
@@ -121,12 +125,18 @@ def _host_decision(Wu, n_pad, budget=5e-7):
     E = G - np.diag(np.diag(G))
     hi = (E + (1 << (shift - 1))) >> shift
     lo = E - (hi << shift)
-    if np.abs(hi).max() > 127 and hi.min() < -128 or hi.max() > 127:
-        return S_wc, 0, 0.0
-    g2 = np.abs(hi @ hi).sum(axis=1).max()
-    normsq = float(np.diag(G).max()) + 2.0 ** shift * np.sqrt(float(g2)) + np.sqrt(float((lo * lo).sum()))
-    H2 = 0.5 * u * (np.sqrt(normsq) + 0.5 * (n_pad - 1))
-    return S_wc, (2 if H2 * n_pad <= target else 0), H2
+    H2 = 0.0
+    if not (hi.min() < -128 or hi.max() > 127):
+        g2 = np.abs(hi @ hi).sum(axis=1).max()
+        normsq = float(np.diag(G).max()) + 2.0 ** shift * np.sqrt(float(g2)) + np.sqrt(float((lo * lo).sum()))
+        H2 = 0.5 * u * (np.sqrt(normsq) + 0.5 * (n_pad - 1))
+    if ok(H2, tight):
+        return S_wc, 2, H2, tight
+    if ok(H1, budget):
+        return S_wc, 1, H1, budget
+    if ok(H2, budget):
+        return S_wc, 2, H2, budget
+    return S_wc, 0, 0.0, in_force
 
 
 def test_saving_is_not_taken_when_it_does_not_pay_or_is_not_allowed():
@@ -144,8 +154,9 @@ def test_saving_is_not_taken_when_it_does_not_pay_or_is_not_allowed():
         sh.scan()
         torch.cuda.synchronize()
         S_used = sh.vara_i8_info()[0]
-        S_wc, level, H = _host_decision(sh.Wu.cpu().numpy(), sh.np_)
+        S_wc, level, H, in_force = _host_decision(sh.Wu.cpu().numpy(), sh.np_)
         assert sh.last_sliced == S_wc and S_used == S_wc - (1 if level else 0) and sh.last_level == level, (diag, S_used, S_wc, level, sh.last_level)
+        assert sh.last_budget == in_force, (diag, sh.last_budget, in_force)
         if level:
             assert H <= sh.last_specH <= H * (1 + 1e-12)
         else:
