@@ -902,6 +902,36 @@ static int upload_square(eagle_ctx* ctx, const double* host, long n, long np, do
                                  hipMemcpyHostToDevice, ctx->stream));
     return EAGLE_OK;
 }
+// The same upload through the context's two pinned staging buffers: host threads copy piece k + 1 of the caller's pageable matrix into
+// one while the DMA of piece k runs out of the other (the runtime's own pageable path stages single-threaded: 25-27 GB/s on the GPU
+// boxes against 50+ this way).  Synchronous for the caller's memory: nothing of `host` is in flight when it returns.
+static int upload_square_staged(eagle_ctx* ctx, const double* host, long n, long np, double* dev, hipStream_t st) {
+    const size_t piece = (size_t)64 << 20, rowb = sizeof(double) * (size_t)n;
+    if (rowb * (size_t)n < 4 * piece || rowb > piece) return upload_square_on(ctx, host, n, np, dev, st);
+    int rc = eagle_stage_ensure(ctx, piece);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemsetAsync(dev, 0, sizeof(double) * np * np, st));
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    for (int b = 0; b < 2; b++) HIPCHK(ctx, hipEventCreateWithFlags(&ev[b], hipEventDisableTiming));
+    const long rows_per = (long)(piece / rowb);
+    const int threads = std::max(1, std::min(host_threads(), 16));
+    hipError_t e = hipSuccess;
+    long k = 0;
+    for (long r0 = 0; r0 < n && e == hipSuccess; r0 += rows_per, k++) {
+        const long nr = std::min(rows_per, n - r0);
+        if (k >= 2) e = hipEventSynchronize(ev[k & 1]);   // the DMA that last read this buffer
+        if (e != hipSuccess) break;
+        char* dst = (char*)ctx->stage_pin[k & 1];
+        const char* src = (const char*)(host + r0 * n);
+        parallel_for((long)(rowb * (size_t)nr), threads, [&](long a, long b, int) { memcpy(dst + a, src + a, (size_t)(b - a)); });
+        e = hipMemcpy2DAsync(dev + r0 * np, sizeof(double) * np, dst, rowb, rowb, (size_t)nr, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipEventRecord(ev[k & 1], st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);   // (the staging buffers serve other loaders after this call)
+    for (int b = 0; b < 2; b++) (void)hipEventDestroy(ev[b]);
+    if (e != hipSuccess) { (void)hipStreamSynchronize(st); return eagle_fail_hip(ctx, e, "staged upload"); }
+    return EAGLE_OK;
+}
 static int upload_vec(eagle_ctx* ctx, const double* host, long n, long np, double* dev) {
     HIPCHK(ctx, hipMemsetAsync(dev, 0, sizeof(double) * np, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(dev, host, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
@@ -1165,7 +1195,10 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
     const size_t sq = sizeof(double) * (size_t)np * np;
     const bool use_i8 = ctx->scan_mode == 1 && 64.0 * 512.0 * (double)np < 2147483648.0;
     const int nslices = ctx->scan_slices | (ctx->scan_stochastic ? EAGLE_SLICES_STOCHASTIC : 0);
-    const bool share_w = !w_direct && rccl && (np / 128) % nd == 0;  // the same answer on every device (rccl: several devices, or one forced)
+    // W's rows shared between devices + ONE all-gather: only for the fp64 products.  The int8 digit-slice products (round 4) cost half
+    // as much, are a deterministic function of S and V -- every device forms the bits a single device forms, no exchange, no all-gather
+    // of 8 n^2 bytes, each device's copy of S stays cached and verified -- and so run replicated on every device.
+    const bool share_w = !w_direct && rccl && (np / 128) % nd == 0 && !(use_i8 && eagle_w8_wanted(ctx, np));  // the same answer on every device
     int rc = EAGLE_OK;
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) rc = eagle_fail_hip(ctx, e, "hipSetDevice");
@@ -1238,9 +1271,9 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
             // n^3 products run; a difference starts the products over (below).  V changes with every call; it arrives in row
             // blocks on the loader stream UNDER the first product, which works on the rows that have landed (below) -- unless the
             // rows of W are shared between devices (share_w: the row-block product there needs all of V at once).
-            if (share_w && (r = upload_square(ctx, dim_reduced_vara, n, np, Va))) return r;
+            if (share_w && (r = upload_square_staged(ctx, dim_reduced_vara, n, np, Va, ctx->stream))) return r;
             if ((r = upload_vec(ctx, a, n, np, ah))) return r;
-            const bool cacheable = !share_w && np <= 16384 && !getenv("EAGLE_HIP_NO_SCACHE");
+            const bool cacheable = np <= 16384 && !getenv("EAGLE_HIP_NO_SCACHE");   // (round 4: also when W's rows are shared)
             if (cacheable && ctx->scache_np != np) {
                 if (ctx->d_Scache) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->d_Scache); ctx->d_Scache = nullptr; }
                 if (ctx->d_Sscr) { (void)hipFree(ctx->d_Sscr); ctx->d_Sscr = nullptr; }
@@ -1288,9 +1321,7 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
                 // W on the int8 engine (csrc/eagle_w8.hip): its configuration is chosen from statistics of ALL of V, so V is uploaded
                 // whole (loader stream; S's statistics and slices do not wait for it) and the products follow; a call that declines
                 // runs the fp64 products on the resident operands
-                if ((e = hipMemsetAsync(Va, 0, sq, ctx->load_stream)) != hipSuccess) rc = eagle_fail_hip(ctx, e, "V memset");
-                if (!rc && (e = hipMemcpy2DAsync(Va, sizeof(double) * np, dim_reduced_vara, sizeof(double) * n, sizeof(double) * n, (size_t)n,
-                                                 hipMemcpyHostToDevice, ctx->load_stream)) != hipSuccess) rc = eagle_fail_hip(ctx, e, "upload of V");
+                rc = upload_square_staged(ctx, dim_reduced_vara, n, np, Va, ctx->load_stream);
                 hipEvent_t ev = nullptr;
                 if (!rc && (e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) rc = eagle_fail_hip(ctx, e, "hipEventCreate");
                 if (!rc && ((e = hipEventRecord(ev, ctx->load_stream)) != hipSuccess || (e = hipStreamWaitEvent(ctx->stream, ev, 0)) != hipSuccess))
@@ -1325,38 +1356,40 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
             for (hipEvent_t ev : landed) (void)hipEventDestroy(ev);
             }
         }
-        if (!rc && s_from_cache) {
-            // under the product: the caller's S to the scratch copy (loader stream), compared with the cached one.  One resident block
-            // on one device: nothing below needs the host before the results go back, so the answer is collected only then (S's 800 MB
-            // at n = 10,000 then hide under the whole scan, not under W alone: on a host whose pageable copies run at 25 GB/s the
-            // two uploads of a call took 64 ms against W's 47); otherwise (marker blocks, several devices: the host is in the loop
-            // anyway) right here.
-            int* flag = (int*)((char*)ctx->d_scratch + EAGLE_SCR_SCACHE_FLAG);
-            if (!ctx->h_flag && (e = hipHostMalloc((void**)&ctx->h_flag, 64, hipHostMallocDefault)) != hipSuccess) rc = eagle_fail_hip(ctx, e, "pinned flag");
-            if (!rc) {
-                *ctx->h_flag = 0;
-                e = hipMemsetAsync(flag, 0, sizeof(int), ctx->load_stream);
-                if (e == hipSuccess) rc = upload_square_on(ctx, inv_MMt_sqrt, n, np, ctx->d_Sscr, ctx->load_stream);
-                if (e == hipSuccess && !rc) {
-                    hipLaunchKernelGGL(k_bits_differ, dim3(1024), dim3(256), 0, ctx->load_stream, (const unsigned long long*)ctx->d_Sscr,
-                                       (const unsigned long long*)ctx->d_Scache, np * np, flag);
-                    e = hipMemcpyAsync(ctx->h_flag, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->load_stream);
-                }
-                if (e != hipSuccess && !rc) rc = eagle_fail_hip(ctx, e, "verification of the cached S");
-                s_check_pending = true;
+    }
+    if (!rc && s_from_cache) {
+        // under the product: the caller's S to the scratch copy (loader stream), compared with the cached one.  One resident block
+        // on one device: nothing below needs the host before the results go back, so the answer is collected only then (S's 800 MB
+        // at n = 10,000 then hide under the whole scan, not under W alone: on a host whose pageable copies run at 25 GB/s the
+        // two uploads of a call took 64 ms against W's 47); otherwise (marker blocks, several devices: the host is in the loop
+        // anyway) right here.
+        int* flag = (int*)((char*)ctx->d_scratch + EAGLE_SCR_SCACHE_FLAG);
+        if (!ctx->h_flag && (e = hipHostMalloc((void**)&ctx->h_flag, 64, hipHostMallocDefault)) != hipSuccess) rc = eagle_fail_hip(ctx, e, "pinned flag");
+        if (!rc) {
+            *ctx->h_flag = 0;
+            e = hipMemsetAsync(flag, 0, sizeof(int), ctx->load_stream);
+            if (e == hipSuccess) rc = upload_square_on(ctx, inv_MMt_sqrt, n, np, ctx->d_Sscr, ctx->load_stream);
+            if (e == hipSuccess && !rc) {
+                hipLaunchKernelGGL(k_bits_differ, dim3(1024), dim3(256), 0, ctx->load_stream, (const unsigned long long*)ctx->d_Sscr,
+                                   (const unsigned long long*)ctx->d_Scache, np * np, flag);
+                e = hipMemcpyAsync(ctx->h_flag, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->load_stream);
             }
-            if (s_check_pending && (streamed || bounds_flow || rc)) {
-                s_check_pending = false;
-                e = hipStreamSynchronize(ctx->load_stream);
-                if (e != hipSuccess && !rc) rc = eagle_fail_hip(ctx, e, "verification of the cached S");
-                if (!rc && *ctx->h_flag) {  // another S: it is already on the device -- start the product over with it
-                    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) rc = eagle_fail_hip(ctx, e, "scan operands");
-                    std::swap(ctx->d_Scache, ctx->d_Sscr);
-                    Sa = ctx->d_Scache;
-                    if (!rc) rc = eagle_dev_scan_operands(ctx, Sa, Va, ah, n, np, v, Wu, tmp, ctx->stream);
-                    ctx->scache_misses++;
-                } else if (!rc) ctx->scache_hits++;
-            }
+            if (e != hipSuccess && !rc) rc = eagle_fail_hip(ctx, e, "verification of the cached S");
+            s_check_pending = true;
+        }
+        // (rv: a device of a multi-device call must not defer -- a peer that streams or holds no cached S settles a changed S inline,
+        // and a deferred restart of this one would pass every rendezvous of the call a second time)
+        if (s_check_pending && (streamed || bounds_flow || rv || rc)) {
+            s_check_pending = false;
+            e = hipStreamSynchronize(ctx->load_stream);
+            if (e != hipSuccess && !rc) rc = eagle_fail_hip(ctx, e, "verification of the cached S");
+            if (!rc && *ctx->h_flag) {  // another S: it is already on the device -- start the product over with it
+                if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) rc = eagle_fail_hip(ctx, e, "scan operands");
+                std::swap(ctx->d_Scache, ctx->d_Sscr);
+                Sa = ctx->d_Scache;
+                if (!rc) rc = eagle_dev_scan_operands(ctx, Sa, Va, ah, n, np, v, Wu, tmp, ctx->stream);
+                ctx->scache_misses++;
+            } else if (!rc) ctx->scache_hits++;
         }
     }
     if (!rc) ph.mark(ctx->stream, PH_W);

@@ -226,3 +226,60 @@ def test_a_collective_that_cannot_be_enqueued_aborts_the_communicators_instead_o
     np.testing.assert_array_equal(mmt, G.T @ G)
     assert raised
     api.drop_cache(device=dev)
+
+
+def test_int8_w_is_replicated_bit_for_bit_and_every_device_keeps_its_copy_of_S(api, oracle, tmp_path, monkeypatch):
+    """Round 4: with W on the int8 engine every device of a multi-device context forms the WHOLE W from exact
+    digit slices -- a deterministic function of S and V, so no rows are shared, no all-gather runs, and the arrays are bit for bit the
+    single-device ones with RCCL in the context as well as without; each device's copy of S is cached and verified (hits on every
+    sub-context), and a changed S is picked up by all of them (the restart of a device never passes a rendezvous twice)."""
+    n, L = 700, 3000
+    rng = np.random.default_rng(6)
+    Mt8 = synth.genotypes_marker_major(n, L, seed=31)
+    A = rng.standard_normal((n, 40)) / 6.0
+    S = np.eye(n) + A @ A.T
+    V = 0.7 * np.eye(n) - 0.03 * (A[:, :3] @ A[:, :3].T)
+    ahat = rng.standard_normal(n)
+    geno = synth.write_geno_pair(str(tmp_path), Mt8)
+    ref = oracle.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat)
+    monkeypatch.setenv("EAGLE_HIP_W_MODE", "2")          # contexts opened from here on form W on the int8 engine at any size
+    api.close_all()
+    try:
+        one = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat, device=0)
+        assert api.last_w_info(device=0)["int8"] == 1
+        best_one = api.last_scan_argmax(device=0)
+        np.testing.assert_allclose(one["vara"], ref["vara"], rtol=1e-7)
+        for devs in ((0, 0), (0, 0, 0)):
+            h0, m0 = api.scan_operand_cache_stats(device=devs)
+            for call in range(3):
+                r = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat, device=devs)
+                np.testing.assert_array_equal(r["a"], one["a"])
+                np.testing.assert_array_equal(r["vara"], one["vara"])
+                assert api.last_scan_argmax(device=devs)[:2] == best_one[:2]
+            h1, m1 = api.scan_operand_cache_stats(device=devs)
+            assert (h1 - h0, m1 - m0) == (2 * len(devs), 0)            # calls 2 and 3: every sub-context verified its cached copy
+            S2 = S + 1e-3 * np.eye(n)                                   # another S: every device starts over with it, once
+            r2 = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S2, V, 8.0, (L, n), ahat, device=devs)
+            ref2 = oracle.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S2, V, 8.0, (L, n), ahat)
+            np.testing.assert_allclose(r2["vara"], ref2["vara"], rtol=1e-7)
+            h2, m2 = api.scan_operand_cache_stats(device=devs)
+            assert (h2 - h1, m2 - m1) == (0, len(devs))
+            api.set_scan_mode(0, device=devs)                           # fp64 scan, changed S again, no RCCL: ADVICE r3 (a deferred restart hung)
+            r3 = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat, device=devs)
+            api.set_scan_mode(1, device=devs)
+            np.testing.assert_allclose(r3["vara"], ref["vara"], rtol=1e-9)
+            api.drop_cache(device=devs)
+        # with RCCL in the context (a communicator of one rank is what this box has): still replicated, still the same bits
+        monkeypatch.setenv("EAGLE_HIP_COLLECTIVES", "rccl")
+        api.close_all()
+        forced = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat, device=(0,))
+        assert api.last_w_info(device=(0,))["int8"] == 1
+        np.testing.assert_array_equal(forced["vara"], one["vara"])
+        np.testing.assert_array_equal(forced["a"], one["a"])
+        forced2 = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, S, V, 8.0, (L, n), ahat, device=(0,))
+        np.testing.assert_array_equal(forced2["vara"], one["vara"])
+        assert api.scan_operand_cache_stats(device=(0,))[0] >= 1
+    finally:
+        monkeypatch.delenv("EAGLE_HIP_COLLECTIVES", raising=False)
+        monkeypatch.delenv("EAGLE_HIP_W_MODE", raising=False)
+        api.close_all()
