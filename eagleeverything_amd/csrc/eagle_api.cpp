@@ -45,11 +45,59 @@ extern "C" int eagle_fail_hip(eagle_ctx* ctx, hipError_t e, const char* where) {
 
 // Grow-only device arena: the n x n operand images and kernel workspaces of a call are carved from one allocation that
 // survives between calls (a find_qtl iteration would otherwise pay ~10 hipMalloc/hipFree pairs of 100s of MB each).
+// The first allocation of a large arena is the slowest thing a first find_qtl call does (3-6 s for 100 GB at 50,000 individuals:
+// the driver maps the pages).  Whoever knows the problem size earlier -- eagle_calculateMMt (AM() calls it once, then spends seconds in
+// the host's eigen-decomposition), eagle_prepare_scan, EAGLE_HIP_ARENA_GB at eagle_open -- starts it on a background thread;
+// arena_reserve collects it.
+struct ArenaPrefetch { std::thread th; void* p = nullptr; size_t bytes = 0; hipError_t e = hipSuccess; };
+static void arena_collect(eagle_ctx* ctx) {
+    ArenaPrefetch* pf = (ArenaPrefetch*)ctx->arena_prefetch;
+    if (!pf) return;
+    ctx->arena_prefetch = nullptr;
+    if (pf->th.joinable()) pf->th.join();
+    if (pf->e == hipSuccess && pf->p) {
+        if (pf->bytes > ctx->arena_cap) {
+            if (ctx->arena) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->arena); }
+            ctx->arena = pf->p;
+            ctx->arena_cap = pf->bytes;
+        } else (void)hipFree(pf->p);
+    } else (void)hipGetLastError();
+    delete pf;
+}
+static void arena_prefetch(eagle_ctx* ctx, size_t total) {
+    if (ctx->arena_prefetch || total <= ctx->arena_cap || total < ((size_t)4 << 30)) return;
+    ArenaPrefetch* pf = new ArenaPrefetch;
+    pf->bytes = total;
+    const int device = ctx->device;
+    pf->th = std::thread([pf, device] {
+        pf->e = hipSetDevice(device);
+        if (pf->e == hipSuccess) pf->e = hipMalloc(&pf->p, pf->bytes);
+    });
+    ctx->arena_prefetch = pf;
+}
+// Frees the fp4 operand images of MM^T kept with the resident files (GenoEntry.dev_f4: n L / 2 bytes each, 5 GB at 10,000 x 1,000,000;
+// the next calculateMMt on the file re-makes its image in 3 ms).  Returns the bytes given back.
+size_t eagle_drop_f4_images(eagle_ctx* ctx) {
+    size_t freed = 0;
+    for (GenoEntry& g : ctx->cache)
+        if (g.dev_f4) {
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipFree(g.dev_f4);
+            g.dev_f4 = nullptr;
+            freed += (size_t)g.rows_pad * (size_t)g.ld / 2;
+        }
+    return freed;
+}
 static int arena_reserve(eagle_ctx* ctx, size_t total) {
     ctx->arena_off = 0;
+    arena_collect(ctx);
     if (total <= ctx->arena_cap) return EAGLE_OK;
     if (ctx->arena) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->arena); ctx->arena = nullptr; ctx->arena_cap = 0; }
     hipError_t e = hipMalloc(&ctx->arena, total);
+    if (e != hipSuccess && eagle_drop_f4_images(ctx) > 0) {   // the fp4 MM^T operand images kept with resident files are not in any budget
+        (void)hipGetLastError();
+        e = hipMalloc(&ctx->arena, total);
+    }
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "arena hipMalloc");
     ctx->arena_cap = total;
     return EAGLE_OK;
@@ -109,6 +157,10 @@ extern "C" eagle_ctx* eagle_open(int device) {
     // EAGLE_HIP_TUNE=9: the compiler-scheduled forms of the two hand-scheduled kernels (k_vara_i8w, k_syrk_f4) for a whole session:
     // same results bit for bit, 3-8 % slower; a switch for ruling the inline-asm kernels out when chasing a problem
     if (const char* tv = getenv("EAGLE_HIP_TUNE")) ctx->tune = atoi(tv);
+    if (const char* ag = getenv("EAGLE_HIP_ARENA_GB")) {   // reserve the scan arena at open (background thread), e.g. 100 for 50,000 individuals
+        const double gb = atof(ag);
+        if (gb > 0.0 && gb < 4096.0) arena_prefetch(ctx, (size_t)(gb * 1e9));
+    }
     if (const char* wm = getenv("EAGLE_HIP_W_MODE")) {   // 0 / 1 / 2: eagle_set_w_mode for an R session that has no call for it
         const int m = atoi(wm);
         if (m >= 0 && m <= 2) ctx->w_mode = m;
@@ -165,11 +217,22 @@ static void rccl_abort_all(RcclState* r) {
     for (ncclComm_t& c : r->comms)
         if (c) { if (r->CommAbort) (void)r->CommAbort(c); c = nullptr; }
 }
-// EAGLE_HIP_FAULT=reduce | allgather: the named collective of the next call reports a failure instead of running (tests of the
-// abort path on a one-GPU box; never set in production)
-static bool rccl_fault(const char* which) {
-    const char* f = getenv("EAGLE_HIP_FAULT");
-    return f && strcmp(f, which) == 0;
+// The communicator of device k for the collective a worker is about to enqueue, or NULL when the leg was aborted meanwhile (ADVICE r3:
+// a peer used to read comms[k] unlocked while rccl_abort_all was writing it).  A handle taken here can still be aborted before the
+// enqueue -- RCCL then returns an error from the call, which is the outcome the abort exists for.
+static ncclComm_t rccl_comm(RcclState* r, int k) {
+    std::lock_guard<std::mutex> lock(r->abort_mutex);
+    return r->dead.load() ? nullptr : r->comms[(size_t)k];
+}
+// EAGLE_HIP_FAULT=reduce | allgather [:<device index>]: the named collective reports a failure instead of running -- on every device,
+// or on the one named, while its peers go on into theirs (tests of the abort path; never set in production).
+static bool rccl_fault(const char* which, int k) {
+    const char* e = getenv("EAGLE_HIP_FAULT");   // (tests set and unset it between calls of one process: a cached copy would go stale)
+    if (!e) return false;
+    const size_t n = strlen(which);
+    if (strncmp(e, which, n) != 0) return false;
+    if (e[n] == '\0') return true;
+    return e[n] == ':' && atoi(e + n + 1) == k;
 }
 static RcclState* rccl_open(const int* devices, int ndev, char* err, size_t errlen) {
     RcclState* r = new RcclState();
@@ -294,6 +357,7 @@ extern "C" void eagle_close(eagle_ctx* ctx) {
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_Scache) (void)hipFree(ctx->d_Scache);
     if (ctx->d_Sscr) (void)hipFree(ctx->d_Sscr);
+    arena_collect(ctx);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->gemv_ws) (void)hipFree(ctx->gemv_ws);
     if (ctx->f4_buf) (void)hipFree(ctx->f4_buf);
@@ -1085,8 +1149,9 @@ extern "C" int eagle_calculateMMt(eagle_ctx* ctx, const char* f_name_ascii, doub
         if (!r && (e = hipStreamSynchronize(c->stream)) != hipSuccess) r = eagle_fail_hip(c, e, "MM^T partial");
         if (!rv.arrive(r == 0)) return r ? r : eagle_fail(c, EAGLE_ERR_HIP, "another device failed before the MM^T sum");
         if (rccl) {
-            ncclResult_t nr = rccl_fault("reduce") ? ncclSystemError
-                                                   : rccl->Reduce(c->d_pack, c->d_pack, (size_t)packed, ncclInt32, ncclSum, 0, rccl->comms[k], c->stream);
+            const ncclComm_t comm = rccl_comm(rccl, k);
+            ncclResult_t nr = (rccl_fault("reduce", k) || !comm) ? ncclSystemError
+                                                   : rccl->Reduce(c->d_pack, c->d_pack, (size_t)packed, ncclInt32, ncclSum, 0, comm, c->stream);
             if (nr != ncclSuccess) { r = failf(c, EAGLE_ERR_HIP, "ncclReduce: %s", rccl->GetErrorString(nr)); rccl_abort_all(rccl); }
             else if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) r = eagle_fail_hip(c, e, "ncclReduce sync");
         } else if (k == 0) {  // host-staged stand-in: the peers' packed tiles are copied to the lead and added, one by one
@@ -1114,6 +1179,9 @@ extern "C" int eagle_calculateMMt(eagle_ctx* ctx, const char* f_name_ascii, doub
     if (!ctx->d_mmt_max) HIPCHK(ctx, hipMalloc((void**)&ctx->d_mmt_max, sizeof(double)));
     rc = eagle_dev_mmt_finish(ctx, ctx->d_c32, n, np, ctx->d_mmt, n, ctx->d_mmt_max, ctx->stream);
     if (rc) return rc;
+    // AM() calls this once, then works on the host for seconds (eigen, REML) before its first find_qtl: the arena of that scan is
+    // reserved meanwhile, on a background thread (a no-op below 4 GB)
+    (void)eagle_prepare_scan(ctx, n, L);
     return download_big(ctx, MMt_out, ctx->d_mmt, sizeof(double) * (size_t)n * n);
 }
 
@@ -1166,6 +1234,26 @@ extern "C" int eagle_last_mmt_normalised(eagle_ctx* ctx, double* MMt_norm_out, d
     if (rc) return rc;
     if (max_out) HIPCHK(ctx, hipMemcpyAsync(max_out, ctx->d_mmt_max, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     return download_big(ctx, MMt_norm_out, tmp.p, sizeof(double) * (size_t)n * n);
+}
+
+// what scan_range's setup reserves for a resident scan of Lr markers on n individuals (the same terms)
+static size_t scan_arena_bytes(eagle_ctx* ctx, long n, long Lr) {
+    const long np = eagle_pad(n), Lp = eagle_pad(Lr > 0 ? Lr : 1);
+    const size_t sq = sizeof(double) * (size_t)np * np;
+    const bool use_i8 = ctx->scan_mode == 1 && 64.0 * 512.0 * (double)np < 2147483648.0;
+    const int nslices = ctx->scan_slices | (ctx->scan_stochastic ? EAGLE_SLICES_STOCHASTIC : 0);
+    const size_t wsb = use_i8 ? (size_t)eagle_vara_i8_workspace_bytes(np, Lp, nslices) : 0;
+    const size_t certb = use_i8 ? (size_t)eagle_scan_certify_workspace_bytes(np) : 0;
+    return 4 * arena_round(sq) + 2 * arena_round(sizeof(double) * np) + arena_round(wsb) + arena_round(certb);
+}
+extern "C" int eagle_prepare_scan(eagle_ctx* ctx, long n, long L) {
+    if (!ctx || n <= 0 || L <= 0) return EAGLE_ERR_ARG;
+    const int nd = ndev_of(ctx);
+    std::vector<long> edge;
+    split_markers(L, nd, edge);
+    arena_prefetch(ctx, scan_arena_bytes(ctx, n, edge[1] - edge[0]));
+    for (size_t k = 0; k < ctx->peers.size(); k++) arena_prefetch(ctx->peers[k], scan_arena_bytes(ctx->peers[k], n, edge[k + 2] - edge[k + 1]));
+    return EAGLE_OK;
 }
 
 static int ensure_scan_out(eagle_ctx* ctx, long L_pad) {
@@ -1307,8 +1395,9 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
         if (!rc) rc = eagle_dev_scan_operands_rows(ctx, Sa, Va, ah, n, np, r0, r0 + rows, v, Wu, tmp, ctx->stream);
         if (!rc && (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) rc = eagle_fail_hip(ctx, e, "rows of W");
         EAGLE_ARRIVE(0.0);
-        ncclResult_t nr = rccl_fault("allgather") ? ncclSystemError
-                                                  : rccl->AllGather(Wu + r0 * np, Wu, (size_t)(rows * np), ncclDouble, rccl->comms[k], ctx->stream);
+        const ncclComm_t comm = rccl_comm(rccl, k);
+        ncclResult_t nr = (rccl_fault("allgather", k) || !comm) ? ncclSystemError
+                                                  : rccl->AllGather(Wu + r0 * np, Wu, (size_t)(rows * np), ncclDouble, comm, ctx->stream);
         if (nr != ncclSuccess) { rc = failf(ctx, EAGLE_ERR_HIP, "ncclAllGather: %s", rccl->GetErrorString(nr)); rccl_abort_all(rccl); }
         if (!rc) rc = eagle_dev_fold_upper(ctx, Wu, np, ctx->stream);
     } else if (!rc) {
@@ -1419,6 +1508,7 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
             } else {
                 if (!g->dev_s) {
                     e = hipMalloc((void**)&g->dev_s, (size_t)g->rows_pad * g->ld);
+                    if (e != hipSuccess && eagle_drop_f4_images(ctx) > 0) { (void)hipGetLastError(); e = hipMalloc((void**)&g->dev_s, (size_t)g->rows_pad * g->ld); }
                     if (e == hipSuccess) e = hipMalloc((void**)&g->cshift, (size_t)g->rows_pad);
                     if (e == hipSuccess) e = hipMalloc((void**)&g->l1, 2 * sizeof(int32_t) * (size_t)g->rows_pad);
                     rc = e == hipSuccess ? eagle_dev_marker_shift(ctx, g->dev, g->rows_pad, n, np, g->ld, g->dev_s, g->cshift, g->l1, ctx->stream)

@@ -76,6 +76,7 @@ struct eagle_ctx {
     void* d_scratch = nullptr;
     void* argmax_ws = nullptr;   // block partials + result of eagle_last_scan_argmax (ctx-owned: no allocation per call)
     void* arena = nullptr; size_t arena_cap = 0, arena_off = 0;  // grow-only device workspace reused across calls
+    void* arena_prefetch = nullptr;   // ArenaPrefetch* (eagle_api.cpp): a background hipMalloc of the arena in flight
     void* f4_buf = nullptr; size_t f4_cap = 0;  // fp4 image of the tile eagle_dev_mmt_accumulate is working on
     void* gemm_scratch = nullptr; size_t gemm_scratch_cap = 0;  // split-K partial tiles of the fp64 GEMM's last wave
     void* gemv_ws = nullptr;  // 16 digit-slice rows of the GEMV vectors + their exponents (k_gemv_mfma)
@@ -168,4 +169,5 @@ int eagle_get_resident(eagle_ctx* ctx, const char* path, long rows, long cols, d
 int eagle_get_resident_window(eagle_ctx* ctx, const char* path, long row0, long rows, long col0, long cols, double max_mem_gb, int threads,
                               const GenoEntry** out);
 size_t eagle_resident_budget();
+size_t eagle_drop_f4_images(eagle_ctx* ctx);   // frees the fp4 MM^T operand images kept with resident files; bytes given back
 #endif

@@ -1620,7 +1620,15 @@ static size_t ws_bs_off(long n_pad, long L_pad, int smax) {
 //   [ ExtHdr 256 B | idx: cap int32 | flag: L_pad bytes | qc: cap int64 | Xc: cap x n_pad int8 ],  cap = min(65,536, L_pad) rounded to 768
 #define EXT_CAP_MAX 65536
 struct ExtHdr { VaraHdr h2; int count; int overflow; };   // h2: a header for the vara kernels, which read only its S (1: run, 0: every worker leaves)
-static long ext_cap(long L_pad) { const long c = L_pad < EXT_CAP_MAX ? L_pad : EXT_CAP_MAX; return (c + 767) / 768 * 768; }
+static long ext_cap(long L_pad) {
+    long mx = EXT_CAP_MAX;
+    if (const char* e = getenv("EAGLE_HIP_EXT_CAP")) {   // tests: a small compact image forces the extension through several passes
+        const long v = atol(e);
+        if (v >= 768 && v < EXT_CAP_MAX) mx = v;
+    }
+    const long c = L_pad < mx ? L_pad : mx;
+    return (c + 767) / 768 * 768;
+}
 static size_t r256(size_t x) { return (x + 255) / 256 * 256; }
 static size_t ws_ext_off(long n_pad, long L_pad, int smax) { return r256(ws_bs_off(n_pad, L_pad, smax) + (size_t)smax * n_pad * n_pad); }
 static size_t ws_xidx_off(long n_pad, long L_pad, int smax) { return ws_ext_off(n_pad, L_pad, smax) + 256; }
@@ -1830,7 +1838,7 @@ __global__ __launch_bounds__(256) void k_ext_select(const double* __restrict__ v
     const double delta = ldexp(1.0, hdr->e + 1 - 8 * hdr->S) * (1.0 + 0x1p-8), thr = VARA_FLAG_FACTOR * hdr->budget;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L; i += (long)gridDim.x * 256) {
         const double v = vara[i];
-        if (!isfinite(v)) continue;
+        if (!isfinite(v) || flag[i]) continue;   // (flag: extended by an earlier pass of this block)
         const double l = (double)l1q2[2 * i];
         const double b = fmin(H * (double)l1q2[2 * i + 1], 0.5 * l * l * delta) + hdr->wErr * (double)l1q2[2 * i + 1];
         if (b > thr * fabs(v)) {
@@ -1843,13 +1851,17 @@ __global__ __launch_bounds__(256) void k_ext_select(const double* __restrict__ v
 // kernels take their slice base from the host, which does not know S_sliced); no spare slot: nobody is extended.
 __global__ void k_ext_head(const VaraHdr* __restrict__ hdr, ExtHdr* __restrict__ xh, unsigned char* __restrict__ flag, const int* __restrict__ idx, int cap,
                            int spare) {
-    const bool on = xh->count > 0 && !xh->overflow && hdr->S_sliced - 1 < spare;
+    // more than `cap` qualified: the first cap are extended in this pass, the rest by the next one (eagle_dev_vara_i8_extend)
+    const bool on = xh->count > 0 && hdr->S_sliced - 1 < spare;
     if (!on && threadIdx.x == 0 && xh->count > 0) {   // take the flags back: these markers keep the spectral bound (and will be re-evaluated)
         const int c = xh->count < cap ? xh->count : cap;
         for (int k = 0; k < c; k++) flag[idx[k]] = 0;
         xh->count = 0;
     }
-    if (threadIdx.x == 0) xh->h2.S = on ? 1 : 0;
+    if (threadIdx.x == 0) {
+        if (xh->count > cap) xh->count = cap;
+        xh->h2.S = on ? 1 : 0;
+    }
 }
 __global__ __launch_bounds__(256) void k_ext_copy_slice(const ExtHdr* __restrict__ xh, const VaraHdr* __restrict__ hdr, int8_t* __restrict__ Bs, long nn, int spare) {
     if (!xh->h2.S) return;
@@ -1904,13 +1916,23 @@ extern "C" int eagle_dev_vara_i8_extend(eagle_ctx* ctx, const int8_t* Mt8s, cons
     const int spare = smax - 3;   // slot 4 of 7: slots 5 and 6 hold E_hi and Ds of the spectral bound
     unsigned blocks = (unsigned)((L + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_ext_select, dim3(blocks), dim3(256), 0, s, vara, L, l1norm, hdr, xh, idx, flag, (int)cap);
-    hipLaunchKernelGGL(k_ext_head, dim3(1), dim3(64), 0, s, hdr, xh, flag, idx, (int)cap, spare);
-    hipLaunchKernelGGL(k_ext_copy_slice, dim3(1024), dim3(256), 0, s, xh, hdr, Bs, n_pad * n_pad, spare);
-    hipLaunchKernelGGL(k_ext_gather, dim3((unsigned)cap), dim3(256), 0, s, Mt8s, ld, n_pad, xh, idx, Xc, qc);
-    rc = vara_i8_launch(ctx, Xc, cap, n_pad, n_pad, 1, &xh->h2, Bs + (size_t)spare * n_pad * n_pad, qc, s, true);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_ext_apply, dim3(64), dim3(256), 0, s, xh, idx, qc, q, L_pad, hdr, vdiag, cshift, mrho, vara);
+    // A block with more qualifying markers than the compact image holds (cap = min(65,536, L_pad)) is worked in up to four passes of
+    // cap markers (a per-block overflow rule made the returned bits depend on the blocking); a pass with nobody left drops
+    // its kernels on the device.  More than 4 cap in ONE block: the rest keep the spectral bound and go to the certificate.
+    const int passes = cap < L_pad ? 4 : 1;
+    for (int pass = 0; pass < passes; pass++) {
+        if (pass) {
+            hipError_t em = hipMemsetAsync(&xh->count, 0, 2 * sizeof(int), s);   // count, overflow (the flags stay)
+            if (em != hipSuccess) return eagle_fail_hip(ctx, em, "vara_i8_extend memset");
+        }
+        hipLaunchKernelGGL(k_ext_select, dim3(blocks), dim3(256), 0, s, vara, L, l1norm, hdr, xh, idx, flag, (int)cap);
+        hipLaunchKernelGGL(k_ext_head, dim3(1), dim3(64), 0, s, hdr, xh, flag, idx, (int)cap, spare);
+        if (pass == 0) hipLaunchKernelGGL(k_ext_copy_slice, dim3(1024), dim3(256), 0, s, xh, hdr, Bs, n_pad * n_pad, spare);
+        hipLaunchKernelGGL(k_ext_gather, dim3((unsigned)cap), dim3(256), 0, s, Mt8s, ld, n_pad, xh, idx, Xc, qc);
+        rc = vara_i8_launch(ctx, Xc, cap, n_pad, n_pad, 1, &xh->h2, Bs + (size_t)spare * n_pad * n_pad, qc, s, true);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_ext_apply, dim3(64), dim3(256), 0, s, xh, idx, qc, q, L_pad, hdr, vdiag, cshift, mrho, vara);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "vara_i8_extend");
     return EAGLE_OK;

@@ -781,7 +781,7 @@ static size_t r256(size_t x) { return (x + 255) / 256 * 256; }
 static int w8_workspace(eagle_ctx* ctx, long np, W8Ws* w) {
     const size_t nn = (size_t)np * np;
     const size_t full_levels = 12 * nn * sizeof(int32_t);   // the largest configuration: 11 levels (+ splits at very large n)
-    size_t cap = W8_LEVEL_CAP;
+    size_t cap = np >= 32768 ? 4 * W8_LEVEL_CAP : W8_LEVEL_CAP;   // (14 GB at 50,000 individuals: panels of 24 row tiles instead of 4)
     if (const char* e = getenv("EAGLE_HIP_W8_LEVEL_MB")) {   // tests: small level images force the products through several row panels
         const long mb = atol(e);
         if (mb >= 1) cap = (size_t)mb << 20;
@@ -792,7 +792,11 @@ static int w8_workspace(eagle_ctx* ctx, long np, W8Ws* w) {
     const size_t need = 2 * r256(W8_KMAX * nn) + r256(level_bytes) + 13 * vec + 8 * vec + 4 * vec + 3 * dss + asymb + 4096;
     if (need > ctx->w8_ws_cap || (getenv("EAGLE_HIP_W8_LEVEL_MB") && need != ctx->w8_ws_cap)) {
         if (ctx->w8_ws) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->w8_ws); ctx->w8_ws = nullptr; ctx->w8_ws_cap = 0; }
-        if (hipMalloc(&ctx->w8_ws, need) != hipSuccess) { (void)hipGetLastError(); ctx->w8_ws = nullptr; return 1; }   // no room: decline
+        if (hipMalloc(&ctx->w8_ws, need) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->w8_ws = nullptr;
+            if (!(eagle_drop_f4_images(ctx) > 0 && hipMalloc(&ctx->w8_ws, need) == hipSuccess)) { (void)hipGetLastError(); ctx->w8_ws = nullptr; return 1; }   // no room: decline
+        }
         ctx->w8_ws_cap = need;
     }
     char* p = (char*)ctx->w8_ws;
@@ -839,7 +843,8 @@ static int w8_product(eagle_ctx* ctx, int cfg, bool upper, long np, const int8_t
     long rt_per_panel = (long)(w.level_bytes / ((size_t)ngroups * T8 * np * sizeof(int32_t)));
     if (rt_per_panel < 1) return 1;
     if (rt_per_panel >= nt) rt_per_panel = nt;
-    else if (rt_per_panel > 4) rt_per_panel = rt_per_panel / 4 * 4;   // whole super-tile rows
+    else if (rt_per_panel > 8) rt_per_panel = rt_per_panel / 8 * 8;   // whole super-tile rows (8 row tiles in the 384 x 256 tiling, 4 in the other)
+    else if (rt_per_panel > 4) rt_per_panel = 4;
     for (int rt0 = 0; rt0 < nt; rt0 += (int)rt_per_panel) {
         const int rt1 = (int)std::min<long>(nt, rt0 + rt_per_panel);
         W8List l;

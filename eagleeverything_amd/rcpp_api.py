@@ -130,6 +130,12 @@ def last_scan_budget(device=0):
     return b.value, lv.value, we.value
 
 
+def prepare_scan(n, L, device=0):
+    """Start the allocation of the scan's device arena on a background thread (eagle_prepare_scan; calculateMMt_rcpp does it by itself)."""
+    ctx = context(device)
+    _check(ctx, _lib.load().eagle_prepare_scan(ctx, int(n), int(L)))
+
+
 def set_w_mode(mode, device=0):
     """Which engine forms W = S (V S) for a digit-slice scan: 1 (default) = int8 digit slices from 4,096 padded individuals up, 0 = always
     the fp64 GEMM, 2 = int8 at any size (eagle_set_w_mode, csrc/eagle_w8.hip)."""

@@ -420,6 +420,11 @@ int eagle_last_scan_digits(eagle_ctx* ctx, int* digits_used, int* digits_cut, do
  * the digits that run anyway certify a marker with q2 = n_pad to it (worst-case bound, or the spectral bound at level 1 / 2);
  * eagle_set_scan_budget(b) makes b the only budget, eagle_set_scan_budget(0) restores the default policy. */
 int eagle_last_scan_budget(eagle_ctx* ctx, double* budget_used, int* bound_level, double* w_error_bound);
+/* Round 4.  The first eagle_calculate_a_and_vara of a context allocates its device arena (four n x n fp64 images + the digit-slice and
+ * certification workspaces: 100 GB at 50,000 individuals, 3-6 s of hipMalloc).  This call starts that allocation on a background
+ * thread and returns at once; the scan collects it.  eagle_calculateMMt calls it by itself (AM() calls calcMMt once and then works
+ * on the host for seconds); EAGLE_HIP_ARENA_GB=<GB> does the same at eagle_open.  dims as R has them: n individuals, L markers. */
+int eagle_prepare_scan(eagle_ctx* ctx, long n, long L);
 /* Out-of-core bookkeeping of the LAST call of this ctx that streamed its file through HBM in marker chunks (a file larger than
  * free HBM or than EAGLE_HIP_MAX_RESIDENT_GB; the lead device's share in a multi-device context): what SURVEY 8(d) asks to be
  * reported for the streamed configurations.  The loader of chunk k+1 (pread -> pinned -> H2D -> decode / 2-bit unpack) runs

@@ -314,6 +314,20 @@ def test_markers_outside_the_spectral_bound_get_the_dropped_digit_back():
     sh.scan()
     sh.best()
     assert sh.vara_i8_info()[0] == S_wc - 1 and sh.last_specH > 0.0                          # no fallback: the saving stays
+    # a block with more qualifying markers than the compact image holds is worked in several passes, not given up --
+    # with room for 768 of the 3,072 per pass the extended values are the very same bits
+    import os
+    os.environ["EAGLE_HIP_EXT_CAP"] = "768"
+    try:
+        sh.ws = None                                    # the workspace layout follows the cap
+        sh.certified = False
+        sh.scan()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(sh.vara[:L].cpu().numpy(), v_ext)
+    finally:
+        os.environ.pop("EAGLE_HIP_EXT_CAP")
+        sh.ws = None
+        sh.certified = True
 
 
 def test_extension_is_a_per_marker_decision_resident_and_streamed(tmp_path, monkeypatch):

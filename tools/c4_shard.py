@@ -135,6 +135,7 @@ def main():
     del S, V
     torch.cuda.empty_cache()
     sh.mode = 1
+    sh.w_mode = int(os.environ.get("W_MODE", 1))
 
     # ---- phase A2: the resident scan ------------------------------------------------------------------------------------
     names = ("W = S V S", "prepare", "vara kernel", "certify")
@@ -157,7 +158,8 @@ def main():
     ops = sum(2.0 * Lp * 256 * min((ct + 1) * 256, np_) for ct in range(nct8)) * S_used
     res = {"phases_s": r, "markers_per_s": L / r["step_s"], "slices": S_used,
            "vara_kernel_frac_of_int8_peak": ops / r["vara kernel"] / 1e12 / I8_PEAK,
-           "W_frac_of_fp64_peak": 3.0 * np_ ** 3 / r["W = S V S"] / 1e12 / F64_PEAK, "certificate": sh.certificate()}
+           "W_frac_of_fp64_peak": 3.0 * np_ ** 3 / r["W = S V S"] / 1e12 / F64_PEAK, "certificate": sh.certificate(),
+           "W_engine": sh.w_info(), "budget_in_force": sh.last_budget, "spectral_level": sh.last_level}
     a_res, v_res = sh.a[:L].cpu().numpy(), sh.vara[:L].cpu().numpy()
     rows = np.r_[0:64, L // 2:L // 2 + 64, L - 64:L]
     M = sh.Mt8[torch.as_tensor(rows, device=sh.dev)][:, :n].cpu().numpy().astype(np.float64)
