@@ -47,7 +47,7 @@ HBM_PEAK_GBS = 8000.0
 def kernel_sha16():
     """Hash of the kernel sources: a committed PMC figure is only attached to a line made by the same kernels."""
     h = hashlib.sha256()
-    for f in ("eagle_i8mfma.hip", "eagle_kernels.hip"):
+    for f in ("eagle_t8.h", "eagle_i8mfma.hip", "eagle_kernels.hip", "eagle_w8.hip"):
         h.update(open(os.path.join(ROOT, "eagleeverything_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

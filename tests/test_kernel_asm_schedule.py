@@ -10,7 +10,8 @@ import re
 
 from conftest import ROOT
 
-SRC = open(os.path.join(ROOT, "eagleeverything_amd", "csrc", "eagle_i8mfma.hip")).read()
+# (round 4: the 384 x 256 engine's macros moved to csrc/eagle_t8.h, shared with the int8 W products of eagle_w8.hip)
+SRC = open(os.path.join(ROOT, "eagleeverything_amd", "csrc", "eagle_t8.h")).read() + open(os.path.join(ROOT, "eagleeverything_amd", "csrc", "eagle_i8mfma.hip")).read()
 
 
 def macro_body(name):

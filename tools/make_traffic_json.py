@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/<prof dir>/summary.txt (tools/profile_gpu.sh + summarise_prof.py) -> profiles/r03_traffic.json: per-launch HBM-side
+"""profiles/<prof dir>/summary.txt (tools/profile_gpu.sh + summarise_prof.py) -> profiles/r04_traffic.json: per-launch HBM-side
 bytes, L2 hit rate and MFMA-busy fraction of the dominant kernels, tagged with the hash of the kernel sources they were
 measured on (bench.py attaches roofline.traffic only while that hash and the configuration still match).
 Usage: tools/make_traffic_json.py profiles/<dir> n markers slices"""
@@ -74,7 +74,12 @@ npad = (n + 255) // 256 * 256
 lpad = (markers + 255) // 256 * 256
 out = {"kernel_sha16": kernel_sha16(),
        "k_vara_i8": entry("k_vara_i8p", float(lpad) * npad + slices * npad * npad / 2.0),
-       "k_gemv_mfma": entry("k_gemv_mfma", float(lpad) * npad),
+       # per launch shape: <true,true> = the genotype pass of the digit-slice scan (a, the diagonal term and m^T rho in one read)
+       "k_gemv_mfma": entry("k_gemv_mfma<true,true>", float(lpad) * npad),
+       "k_gemv_mfma<false,false>": entry("k_gemv_mfma<false,false>", float(lpad) * npad),
+       # the int8 digit-slice products of W = S V S: per launch the digit panels of both operands (pairs x 2 x 256-row panels, shared) -- algorithmic = the slices read once
+       "k_w8_gemm_p": entry("k_w8_gemm_p", 2.0 * 6 * npad * npad),
+       "k_w8_combine1": entry("k_w8_combine1", (16.0 + 8.0 + 4.0 * 5) * npad * npad),
        "k_syrk_f4": entry("k_syrk_f4w", float(lpad) * npad / 2.0),
        "k_gemm_f64_dma": entry("k_gemm_f64_dma", 3.0 * 8 * npad * npad),
        "k_transpose_pack_fp4": entry("k_transpose_pack_fp4", 1.5 * float(lpad) * npad),
@@ -82,5 +87,5 @@ out = {"kernel_sha16": kernel_sha16(),
        "k_gram_rowabs_i8": entry("k_gram_rowabs_i8", float(npad) * npad),
        "k_spectral_scan": entry("k_spectral_scan", 8.0 * float(lpad) * npad, True),
        "k_zbuild_i8": entry("k_zbuild_i8", float(lpad) * npad + 6.0 * npad * npad + 8.0 * float(lpad) * npad, True)}
-json.dump(out, open(os.path.join(ROOT, "profiles", "r03_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", "r04_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -15,7 +15,7 @@ OPS=/tmp/eagle_bench_operands.pt
 # scan, Z builds), so that k_vara_f64, k_spectral_scan and k_zbuild_i8 appear in the summary
 if [ -n "$SECONDARY" ]; then NOSEC="--no-e2e"; else NOSEC="--no-secondary"; fi
 ARGS="$ROOT/bench.py --cpu-sample 0 $NOSEC --steps 3 --warmup 1 --load-operands $OPS $@"
-KF="--kernel-include-regex k_vara_i8|k_vara_f64|k_syrk_f4|k_gemm_f64|k_gemv|k_mmt_finish|k_slice_w|k_pack_fp4|k_transpose_pack_fp4|k_cert|k_spectral|k_zbuild|k_gram_rowabs|k_gram_hi|k_last_digit"
+KF="--kernel-include-regex k_vara_i8|k_vara_f64|k_syrk_f4|k_gemm_f64|k_gemv|k_mmt_finish|k_slice_w|k_pack_fp4|k_transpose_pack_fp4|k_cert|k_spectral|k_zbuild|k_gram_rowabs|k_gram_hi|k_last_digit|k_w8_"
 echo "== stats pass";
 # the stats pass profiles the bench command itself (model-algebra operands; the CPU sample and the secondary entries are skipped)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $ROOT/bench.py --cpu-sample 0 $NOSEC --save-operands $OPS "$@" > $OUT/stats.log 2>&1 || { tail -5 $OUT/stats.log; exit 1; }
