@@ -362,6 +362,7 @@ extern "C" void eagle_close(eagle_ctx* ctx) {
     if (ctx->gemv_ws) (void)hipFree(ctx->gemv_ws);
     if (ctx->f4_buf) (void)hipFree(ctx->f4_buf);
     if (ctx->gemm_scratch) (void)hipFree(ctx->gemm_scratch);
+    eagle_w8_release(ctx);
     if (ctx->w8_ws) (void)hipFree(ctx->w8_ws);
     if (ctx->w8_true_ws) (void)hipFree(ctx->w8_true_ws);
     if (ctx->w8_host) (void)hipHostFree(ctx->w8_host);
@@ -969,9 +970,13 @@ static int upload_square(eagle_ctx* ctx, const double* host, long n, long np, do
 // The same upload through the context's two pinned staging buffers: host threads copy piece k + 1 of the caller's pageable matrix into
 // one while the DMA of piece k runs out of the other (the runtime's own pageable path stages single-threaded: 25-27 GB/s on the GPU
 // boxes against 50+ this way).  Synchronous for the caller's memory: nothing of `host` is in flight when it returns.
-static int upload_square_staged(eagle_ctx* ctx, const double* host, long n, long np, double* dev, hipStream_t st) {
+// block_rows / on_block: after every block of `block_rows` rows of the image (the last one runs to n_pad: padding rows are zero) an event is
+// recorded on `st` and on_block(r0, r1, event) is called -- the caller makes its compute stream wait for the event and works on the rows.
+static int upload_square_staged(eagle_ctx* ctx, const double* host, long n, long np, double* dev, hipStream_t st, long block_rows = 0,
+                                const std::function<int(long, long, hipEvent_t)>& on_block = nullptr) {
     const size_t piece = (size_t)64 << 20, rowb = sizeof(double) * (size_t)n;
-    if (rowb * (size_t)n < 4 * piece || rowb > piece) return upload_square_on(ctx, host, n, np, dev, st);
+    if (!on_block && (rowb * (size_t)n < 4 * piece || rowb > piece)) return upload_square_on(ctx, host, n, np, dev, st);
+    if (rowb > piece) return eagle_fail(ctx, EAGLE_ERR_ARG, "staged upload: a row does not fit a staging buffer");
     int rc = eagle_stage_ensure(ctx, piece);
     if (rc) return rc;
     HIPCHK(ctx, hipMemsetAsync(dev, 0, sizeof(double) * np * np, st));
@@ -980,9 +985,12 @@ static int upload_square_staged(eagle_ctx* ctx, const double* host, long n, long
     const long rows_per = (long)(piece / rowb);
     const int threads = std::max(1, std::min(host_threads(), 16));
     hipError_t e = hipSuccess;
-    long k = 0;
-    for (long r0 = 0; r0 < n && e == hipSuccess; r0 += rows_per, k++) {
-        const long nr = std::min(rows_per, n - r0);
+    std::vector<hipEvent_t> block_events;
+    int rcb = EAGLE_OK;
+    long k = 0, block0 = 0;
+    for (long r0 = 0; r0 < n && e == hipSuccess && !rcb; k++) {
+        long nr = std::min(rows_per, n - r0);
+        if (on_block && block_rows > 0) nr = std::min(nr, block0 + block_rows - r0);   // pieces end at block boundaries
         if (k >= 2) e = hipEventSynchronize(ev[k & 1]);   // the DMA that last read this buffer
         if (e != hipSuccess) break;
         char* dst = (char*)ctx->stage_pin[k & 1];
@@ -990,9 +998,22 @@ static int upload_square_staged(eagle_ctx* ctx, const double* host, long n, long
         parallel_for((long)(rowb * (size_t)nr), threads, [&](long a, long b, int) { memcpy(dst + a, src + a, (size_t)(b - a)); });
         e = hipMemcpy2DAsync(dev + r0 * np, sizeof(double) * np, dst, rowb, rowb, (size_t)nr, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipEventRecord(ev[k & 1], st);
+        r0 += nr;
+        if (on_block && e == hipSuccess && (r0 == block0 + block_rows || r0 == n)) {
+            // the block [block0, r0) is on its way; the last one takes the zero padding rows n .. n_pad along (block_rows is a multiple
+            // of 256, so a block that ends exactly at n leaves no padding rows behind)
+            const long end = (r0 == n) ? np : r0;
+            hipEvent_t be = nullptr;
+            e = hipEventCreateWithFlags(&be, hipEventDisableTiming);
+            if (e == hipSuccess) { block_events.push_back(be); e = hipEventRecord(be, st); }
+            if (e == hipSuccess) rcb = on_block(block0, end, be);
+            block0 = end;
+        }
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);   // (the staging buffers serve other loaders after this call)
     for (int b = 0; b < 2; b++) (void)hipEventDestroy(ev[b]);
+    for (hipEvent_t be : block_events) (void)hipEventDestroy(be);
+    if (rcb) { (void)hipStreamSynchronize(st); return rcb; }
     if (e != hipSuccess) { (void)hipStreamSynchronize(st); return eagle_fail_hip(ctx, e, "staged upload"); }
     return EAGLE_OK;
 }
@@ -1410,14 +1431,38 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
                 // W on the int8 engine (csrc/eagle_w8.hip): its configuration is chosen from statistics of ALL of V, so V is uploaded
                 // whole (loader stream; S's statistics and slices do not wait for it) and the products follow; a call that declines
                 // runs the fp64 products on the resident operands
-                rc = upload_square_staged(ctx, dim_reduced_vara, n, np, Va, ctx->load_stream);
-                hipEvent_t ev = nullptr;
-                if (!rc && (e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) rc = eagle_fail_hip(ctx, e, "hipEventCreate");
-                if (!rc && ((e = hipEventRecord(ev, ctx->load_stream)) != hipSuccess || (e = hipStreamWaitEvent(ctx->stream, ev, 0)) != hipSuccess))
-                    rc = eagle_fail_hip(ctx, e, "V upload event");
-                if (!rc) rc = eagle_dev_scan_operands(ctx, Sa, Va, ah, n, np, v, Wu, tmp, ctx->stream);
+                // Since the first version of round 4 the upload is pipelined when this context has a configuration to guess (its last
+                // call's): V goes up in blocks of 1,536 rows through the pinned staging buffers (16 host threads), and each block's
+                // statistics, digit slices and columns of the first product run on the compute stream as soon as its rows have landed;
+                // the finish step keeps that product only if the rule, on the statistics of ALL of V, chooses the guessed configuration.
+                int r8 = eagle_w8_begin(ctx, Sa, Va, ah, n, np, v, Wu, tmp, 1, ctx->stream);
+                if (r8 < 0) rc = r8;
+                if (!rc) {
+                    const long vb = eagle_w8_vrows_block();
+                    rc = upload_square_staged(ctx, dim_reduced_vara, n, np, Va, ctx->load_stream, vb, [&](long r0, long r1, hipEvent_t landed) -> int {
+                        if (r8) return EAGLE_OK;   // declined at the start (no workspace): only the upload
+                        hipError_t ew = hipStreamWaitEvent(ctx->stream, landed, 0);
+                        if (ew != hipSuccess) return eagle_fail_hip(ctx, ew, "row block event");
+                        const int rv8 = eagle_w8_vrows(ctx, r0, r1, ctx->stream);
+                        if (rv8 < 0) return rv8;
+                        if (rv8) r8 = 1;
+                        return EAGLE_OK;
+                    });
+                }
+                if (!rc && !r8) {
+                    r8 = eagle_w8_finish(ctx, ctx->stream);
+                    if (r8 < 0) rc = r8;
+                }
+                if (!rc && r8 == 1) {   // declined: the fp64 products on the operands that are resident now (v is made already)
+                    hipEvent_t ev = nullptr;
+                    if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) rc = eagle_fail_hip(ctx, e, "hipEventCreate");
+                    if (!rc && ((e = hipEventRecord(ev, ctx->load_stream)) != hipSuccess || (e = hipStreamWaitEvent(ctx->stream, ev, 0)) != hipSuccess))
+                        rc = eagle_fail_hip(ctx, e, "V upload event");
+                    ctx->w8_active = false;
+                    if (!rc) rc = eagle_dev_scan_operands_w_f64(ctx, Sa, Va, np, Wu, tmp, ctx->stream);
+                    if (ev) (void)hipEventDestroy(ev);
+                }
                 if (rc) (void)hipStreamSynchronize(ctx->load_stream);
-                if (ev) (void)hipEventDestroy(ev);
             } else {
             ctx->w8_active = false;
             ctx->w8_info = W8Info();
@@ -1820,6 +1865,7 @@ extern "C" int eagle_last_w_info(eagle_ctx* ctx, eagle_w_info* out) {
     out->k1 = i.k1; out->T1 = i.T1; out->pairs1 = i.pairs1;
     out->k2 = i.k2; out->T2 = i.T2; out->pairs2 = i.pairs2;
     out->eta = i.eta; out->eta_x = i.eta_x; out->target = i.target; out->mean_diag = i.mean_diag; out->asym_term = i.asym_term;
+    out->pipelined = i.pipelined ? 1 : 0; out->pad = 0;
     return EAGLE_OK;
 }
 extern "C" int eagle_last_scan_digits(eagle_ctx* ctx, int* digits_used, int* digits_cut, double* spectral_bound) {

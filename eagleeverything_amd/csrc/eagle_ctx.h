@@ -95,6 +95,8 @@ struct eagle_ctx {
     const double* w8_Wu = nullptr; const double* w8_Sa = nullptr; const double* w8_Va = nullptr; long w8_n = 0;   //   the image it describes, and the operands
     double* w8_tmp = nullptr; void* w8_true_ws = nullptr; size_t w8_true_cap = 0;
     W8Info w8_info;
+    void* w8_pipe = nullptr;            // W8Pipe* (eagle_w8.hip): the state between eagle_w8_begin / _vrows / _finish
+    int w8_guess_c1 = -1; long w8_guess_np = 0;   // the first product's configuration of the last call: what a pipelined call starts on
     char arch[64] = {0};
     int cu_count = 0;
     int64_t hbm_bytes = 0;

@@ -23,6 +23,12 @@ int eagle_dev_scan_operands_w_f64(eagle_ctx* ctx, const double* Sa, const double
 int eagle_dev_scan_operands_w8(eagle_ctx* ctx, const double* Sa, const double* Va, const double* ahat, long n, long n_pad, double* v_out, double* Wu_out,
                                double* tmp, void* stream);
 int eagle_dev_colgemv_parts(eagle_ctx* ctx, const double* At, long n, long n_pad, const double* x, double* out, double* part, void* stream);
+// the same in three steps (eagle_w8.hip): V may arrive in row blocks of eagle_w8_vrows_block() rows under the first product
+int eagle_w8_begin(eagle_ctx* ctx, const double* Sa, const double* Va, const double* ahat, long n, long n_pad, double* v_out, double* Wu_out, double* tmp,
+                   int allow_guess, void* stream);
+int eagle_w8_vrows(eagle_ctx* ctx, long r0, long r1, void* stream);
+int eagle_w8_finish(eagle_ctx* ctx, void* stream);
+int eagle_w8_vrows_block(void);
 int eagle_w8_rho(eagle_ctx* ctx, const double* Wu, long n_pad, double* rho, void* stream);
 int eagle_w8_true_vara(eagle_ctx* ctx, const int8_t* rows8, long count, long n_pad, long ld, const long* dst_dev, double* out, void* stream);
 int eagle_w8_redo_f64(eagle_ctx* ctx, long n_pad, void* stream);
@@ -74,5 +80,6 @@ int eagle_dev_extract_col(eagle_ctx* ctx, const int8_t* M8, long n, long ld, lon
 }
 struct eagle_ctx;
 bool eagle_w8_wanted(const eagle_ctx* ctx, long n_pad);
+void eagle_w8_release(eagle_ctx* ctx);
 #endif
 #endif

@@ -26,12 +26,13 @@ struct W8Info {           // what the last eagle_dev_scan_operands_w8 did (eagle
                           // 5 no workspace, 6 finished W failed the check against its own diagonal, 7 switched off / too small
     int config1 = -1, config2 = -1, k1 = 0, T1 = 0, k2 = 0, T2 = 0, pairs1 = 0, pairs2 = 0;
     double eta = 0, eta_x = 0, bound1 = 0, bound2 = 0, norm_s = 0, target = 0, mean_diag = 0, asym_term = 0;
+    bool pipelined = false;   // the first product ran column block by column block under V's upload, on a guessed configuration the rule confirmed
 };
 #ifdef __cplusplus
 int w8_config_pairs(const W8Config& c);
 std::vector<W8Group> w8_groups(const W8Config& c, int maxp);
 void w8_work_list(int rt0, int rt1, int ntj, int ti_rows, int tj_rows, int ui, int uj, bool upper, const std::vector<W8Group>& gs,
-                  std::vector<unsigned>& out, int* maxlen_out);
+                  std::vector<unsigned>& out, int* maxlen_out, int tj0 = 0);
 double w8_product_bound(const W8Stats& A, const W8Stats& B, const W8Config& c, long np);
 #endif
 #endif

@@ -50,8 +50,8 @@
 // Row statistics of an n_pad x n_pad fp64 image: diagonal, largest off-diagonal magnitude, off-diagonal sum of squares.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_w8_rowstats(const double* __restrict__ M, long np, double* __restrict__ d, double* __restrict__ mx,
-                                                     double* __restrict__ ssq, int* __restrict__ bad) {
-    const long i = blockIdx.x;
+                                                     double* __restrict__ ssq, int* __restrict__ bad, long row0) {
+    const long i = row0 + blockIdx.x;
     const double* row = M + i * np;
     double m = 0.0, s = 0.0;
     int nf = 0;
@@ -113,8 +113,8 @@ __global__ __launch_bounds__(256) void k_w8_asymsq(const double* __restrict__ M,
 // Digit slices of the off-diagonal part of one row: D[p][i][l] = digit p (0 = most significant) of round(M[i][l] 2^(8*6 - e_i - 2)),
 // balanced, peeled least significant first with a carry (as k_slice_w); dssq[p][i] = sum_l D[p][i][l]^2 (exact).
 __global__ __launch_bounds__(256) void k_w8_slice(const double* __restrict__ M, long np, const double* __restrict__ mx, int8_t* __restrict__ D,
-                                                  long sstride, unsigned long long* __restrict__ dssq, int* __restrict__ eout) {
-    const long i = blockIdx.x;
+                                                  long sstride, unsigned long long* __restrict__ dssq, int* __restrict__ eout, long row0) {
+    const long i = row0 + blockIdx.x;
     const double* row = M + i * np;
     const double mxi = mx[i];
     const int e = w_scale_exp(mxi);
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(1024) void k_w8_reduce(long np, const double* __res
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512, 2) void k_w8_gemm(const int8_t* __restrict__ As, const int8_t* __restrict__ Bs, long sstride, long ld,
                                                     const unsigned* __restrict__ work, int maxlen, const W8Group* __restrict__ groups,
-                                                    int32_t* __restrict__ L, long img_elems, long ldc, int row_tile0, int nstages) {
+                                                    int32_t* __restrict__ L, long img_elems, long ldc, int row_tile0, int nstages, long col0) {
     __shared__ __attribute__((aligned(1024))) int8_t lds[2][2][TILE_BYTES];
     const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
     if (pos >= maxlen) return;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(512, 2) void k_w8_gemm(const int8_t* __restrict__ A
         s = s1; pr = pr1;
     }
     // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    int32_t* Lg = L + (long)g * img_elems + ((long)(ti - row_tile0) * T8 + wr * 128 + 4 * (lane >> 5)) * ldc + (long)tj * T8 + wc * 64 + (lane & 31);
+    int32_t* Lg = L + (long)g * img_elems + ((long)(ti - row_tile0) * T8 + wr * 128 + 4 * (lane >> 5)) * ldc + ((long)tj * T8 - col0) + wc * 64 + (lane & 31);
 #pragma unroll
     for (int m = 0; m < 4; m++)
 #pragma unroll
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void k_w8_gemm(const int8_t* __restrict__ A
 // tj = 384-row tile of the column operand (the last one may be short: rows beyond n_pad read as zero and are not stored).
 __global__ __launch_bounds__(512, 2) void k_w8_gemm_p(const int8_t* __restrict__ Ss, const int8_t* __restrict__ Cs, long sstride, long ld,
                                                       const unsigned* __restrict__ work, int maxlen, const W8Group* __restrict__ groups,
-                                                      int32_t* __restrict__ L, long img_elems, long ldc, int row_tile0, int nstages, long np) {
+                                                      int32_t* __restrict__ L, long img_elems, long ldc, int row_tile0, int nstages, long np, long col0) {
     extern __shared__ __attribute__((aligned(1024))) int8_t ldsv[];  // [2][A 48 KiB | B 32 KiB]
     const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
     if (pos >= maxlen) return;
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void k_w8_gemm_p(const int8_t* __restrict__
 #pragma unroll
             for (int n = 0; n < 4; n++)
 #pragma unroll
-                for (int x = 0; x < 16; x++) Lg[(long)(n * 32 + (x & 3) + 8 * (x >> 2)) * ldc + j] = c[m][n][x];
+                for (int x = 0; x < 16; x++) Lg[(long)(n * 32 + (x & 3) + 8 * (x >> 2)) * ldc + (j - col0)] = c[m][n][x];
         }
     }
 }
@@ -391,9 +391,11 @@ __device__ __forceinline__ double w8_levels(const int32_t* __restrict__ L, long 
 __global__ __launch_bounds__(256) void k_w8_combine1(const double* __restrict__ Sa, const double* Va, long np, const double* __restrict__ dS,
                                                      const double* __restrict__ dV, const int* __restrict__ eS, const int* __restrict__ eV,
                                                      const int32_t* __restrict__ L, long img_elems, const W8Group* __restrict__ groups, int ngroups,
-                                                     long row0, double* X) {
-    const long k = (long)blockIdx.x * 256 + threadIdx.x, j = row0 + blockIdx.y;
-    const double g = ldexp(w8_levels(L, img_elems, (long)blockIdx.y * np + k, groups, ngroups), eS[j] + eV[k] + 4);
+                                                     long row0, double* X, long col0, long ncols) {
+    const long kk = (long)blockIdx.x * 256 + threadIdx.x, j = row0 + blockIdx.y;
+    if (kk >= ncols) return;
+    const long k = col0 + kk;
+    const double g = ldexp(w8_levels(L, img_elems, (long)blockIdx.y * ncols + kk, groups, ngroups), eS[j] + eV[k] + 4);
     double x;
     if (j == k) x = dS[j] * dV[j] + g;
     else x = (dS[j] * Va[j * np + k] + Sa[j * np + k] * dV[k]) + g;
@@ -654,11 +656,11 @@ std::vector<W8Group> w8_groups(const W8Config& c, int maxp) {
 // Units = (ui x uj super-tile, group) -- what an XCD's 32 workgroups run at a time -- dealt longest first to the XCD with the least
 // work so far.
 void w8_work_list(int rt0, int rt1, int ntj, int ti_rows, int tj_rows, int ui, int uj, bool upper, const std::vector<W8Group>& gs,
-                  std::vector<unsigned>& out, int* maxlen_out) {
+                  std::vector<unsigned>& out, int* maxlen_out, int tj0) {
     struct Unit { int cost; std::vector<unsigned> items; };
     std::vector<Unit> units;
     for (int si = rt0; si < rt1; si += ui)
-        for (int sj = 0; sj < ntj; sj += uj)
+        for (int sj = tj0; sj < ntj; sj += uj)
             for (size_t g = 0; g < gs.size(); g++) {
                 Unit u;
                 for (int i = si; i < si + ui && i < rt1; i++)
@@ -706,8 +708,8 @@ extern "C" int eagle_w8_host_work_list(int nt, int rt0, int rt1, int upper, int 
     const std::vector<W8Group> gs = w8_groups(c, maxp);
     std::vector<unsigned> wl;
     int ml = 0;
-    if (piped) w8_work_list(rt0, rt1, (int)(((long)nt * T8 + TW_M - 1) / TW_M), T8, TW_M, 8, 4, upper != 0, gs, wl, &ml);
-    else w8_work_list(rt0, rt1, nt, T8, T8, 4, 8, upper != 0, gs, wl, &ml);
+    if (piped) w8_work_list(rt0, rt1, (int)(((long)nt * T8 + TW_M - 1) / TW_M), T8, TW_M, 8, 4, upper != 0, gs, wl, &ml, 0);
+    else w8_work_list(rt0, rt1, nt, T8, T8, 4, 8, upper != 0, gs, wl, &ml, 0);
     if ((long)wl.size() > cap || gs.size() > 64) return -1;
     std::copy(wl.begin(), wl.end(), out);
     std::copy(gs.begin(), gs.end(), groups_out);
@@ -737,20 +739,24 @@ static int w8_choose(const W8Stats& A, const W8Stats& B, long np, double limit, 
 }
 
 struct W8List { unsigned* work = nullptr; W8Group* groups = nullptr; int maxlen = 0, ngroups = 0; };
-static std::map<std::tuple<int, int, int, int, int, int, int>, W8List> g_w8_lists;   // (device, nt, rt0, rt1, upper | engine, config, maxp)
+static std::map<std::tuple<int, int, int, int, int, int, int, int, int>, W8List> g_w8_lists;   // (device, nt, rt0, rt1, upper | engine, config, maxp, column window)
 static std::mutex g_w8_mutex;
-static int w8_get_list(eagle_ctx* ctx, int nt, int rt0, int rt1, bool upper, bool piped, int cfg, int maxp, W8List* out) {
+// c0, c1: the column window [c0, c1) of the product (multiples of 1536 = 4 x 384 = 6 x 256, or c1 = n_pad); -1: all columns
+static int w8_get_list(eagle_ctx* ctx, int nt, int rt0, int rt1, bool upper, bool piped, int cfg, int maxp, W8List* out, long c0 = -1, long c1 = -1) {
     std::lock_guard<std::mutex> lock(g_w8_mutex);
     int dev = 0;
     (void)hipGetDevice(&dev);
-    auto key = std::make_tuple(dev, nt, rt0, rt1, (upper ? 1 : 0) | (piped ? 2 : 0), cfg, maxp);
+    const long np = (long)nt * T8;
+    const int tjr = piped ? TW_M : T8;
+    const int tj0 = c0 < 0 ? 0 : (int)(c0 / tjr), tj1 = c0 < 0 ? (int)((np + tjr - 1) / tjr) : (int)((c1 + tjr - 1) / tjr);
+    auto key = std::make_tuple(dev, nt, rt0, rt1, (upper ? 1 : 0) | (piped ? 2 : 0), cfg, maxp, tj0, tj1);
     auto it = g_w8_lists.find(key);
     if (it != g_w8_lists.end()) { *out = it->second; return EAGLE_OK; }
     const std::vector<W8Group> gs = w8_groups(W8_CONFIGS[cfg], maxp);
     std::vector<unsigned> wl;
     W8List l;
-    if (piped) w8_work_list(rt0, rt1, (int)(((long)nt * T8 + TW_M - 1) / TW_M), T8, TW_M, 8, 4, upper, gs, wl, &l.maxlen);
-    else w8_work_list(rt0, rt1, nt, T8, T8, 4, 8, upper, gs, wl, &l.maxlen);
+    if (piped) w8_work_list(rt0, rt1, tj1, T8, TW_M, 8, 4, upper, gs, wl, &l.maxlen, tj0);
+    else w8_work_list(rt0, rt1, tj1, T8, T8, 4, 8, upper, gs, wl, &l.maxlen, tj0);
     l.ngroups = (int)gs.size();
     hipError_t e = hipMalloc((void**)&l.work, wl.size() * sizeof(unsigned) + 16);
     if (e == hipSuccess) e = hipMalloc((void**)&l.groups, gs.size() * sizeof(W8Group));
@@ -817,30 +823,47 @@ static int w8_workspace(eagle_ctx* ctx, long np, W8Ws* w) {
     return 0;
 }
 
-// statistics + digit slices of one operand; asym: also || M - M^T ||_F
+// row statistics + digit slices of the rows [r0, r1) of one operand
+static int w8_rows_of(eagle_ctx* ctx, const double* M, long np, long r0, long r1, double* d, double* mx, double* ssq, int* e, unsigned long long* dssq,
+                      int8_t* slices, W8Ws& w, hipStream_t s) {
+    hipLaunchKernelGGL(k_w8_rowstats, dim3((unsigned)(r1 - r0)), dim3(256), 0, s, M, np, d, mx, ssq, w.bad, r0);
+    hipLaunchKernelGGL(k_w8_slice, dim3((unsigned)(r1 - r0)), dim3(256), 0, s, M, np, (const double*)mx, slices, np * np, dssq, e, r0);
+    hipError_t er = hipGetLastError();
+    if (er != hipSuccess) return eagle_fail_hip(ctx, er, "w8 row statistics");
+    return EAGLE_OK;
+}
+// the numbers the configuration choice needs, of an operand whose rows have all been through w8_rows_of; asym: also || M - M^T ||_F
+static int w8_reduce_of(eagle_ctx* ctx, const double* M, long np, double* d, double* mx, double* ssq, int* e, unsigned long long* dssq, const double* d2,
+                        bool asym, W8Ws& w, W8Stats* out_dev, hipStream_t s) {
+    const long nb = np / 32;
+    if (asym) hipLaunchKernelGGL(k_w8_asymsq, dim3((unsigned)nb, (unsigned)nb), dim3(256), 0, s, M, np, w.asympart);
+    hipLaunchKernelGGL(k_w8_reduce, dim3(1), dim3(1024), 0, s, np, (const double*)d, (const double*)mx, (const double*)ssq, (const int*)e,
+                       (const unsigned long long*)dssq, d2, (const int*)w.bad, asym ? (const double*)w.asympart : nullptr, nb * nb, out_dev);
+    hipError_t er = hipGetLastError();
+    if (er != hipSuccess) return eagle_fail_hip(ctx, er, "w8 statistics");
+    return EAGLE_OK;
+}
+// statistics + digit slices of one operand
 static int w8_stats_of(eagle_ctx* ctx, const double* M, long np, double* d, double* mx, double* ssq, int* e, unsigned long long* dssq, int8_t* slices,
                        const double* d2, bool asym, W8Ws& w, W8Stats* out_dev, hipStream_t s) {
     hipError_t er = hipMemsetAsync(w.bad, 0, sizeof(int), s);
     if (er != hipSuccess) return eagle_fail_hip(ctx, er, "w8 memset");
-    const long nb = np / 32;
-    if (asym) hipLaunchKernelGGL(k_w8_asymsq, dim3((unsigned)nb, (unsigned)nb), dim3(256), 0, s, M, np, w.asympart);
-    hipLaunchKernelGGL(k_w8_rowstats, dim3((unsigned)np), dim3(256), 0, s, M, np, d, mx, ssq, w.bad);
-    hipLaunchKernelGGL(k_w8_slice, dim3((unsigned)np), dim3(256), 0, s, M, np, mx, slices, np * np, dssq, e);
-    hipLaunchKernelGGL(k_w8_reduce, dim3(1), dim3(1024), 0, s, np, d, mx, ssq, e, dssq, d2, w.bad, asym ? (const double*)w.asympart : nullptr, nb * nb, out_dev);
-    er = hipGetLastError();
-    if (er != hipSuccess) return eagle_fail_hip(ctx, er, "w8 statistics");
-    return EAGLE_OK;
+    int rc = w8_rows_of(ctx, M, np, 0, np, d, mx, ssq, e, dssq, slices, w, s);
+    if (rc) return rc;
+    return w8_reduce_of(ctx, M, np, d, mx, ssq, e, dssq, d2, asym, w, out_dev, s);
 }
 
+// c0, c1: the column window of the product (-1: all columns); the level images then hold that window only (row pitch c1 - c0)
 static int w8_product(eagle_ctx* ctx, int cfg, bool upper, long np, const int8_t* sA, const int8_t* sB, W8Ws& w, hipStream_t s,
-                      const std::function<void(const W8List&, long, long, long)>& combine) {
+                      const std::function<void(const W8List&, long, long, long)>& combine, long c0 = -1, long c1 = -1) {
+    const long col0 = c0 < 0 ? 0 : c0, ncols = c0 < 0 ? np : c1 - c0;
     const int nt = (int)(np / T8);
     int maxp = (int)(131071 / np);
     if (maxp < 1) return 1;
     if (maxp > 8) maxp = 8;
     const int ngroups = (int)w8_groups(W8_CONFIGS[cfg], maxp).size();
     // rows per panel so that the level images of all groups fit
-    long rt_per_panel = (long)(w.level_bytes / ((size_t)ngroups * T8 * np * sizeof(int32_t)));
+    long rt_per_panel = (long)(w.level_bytes / ((size_t)ngroups * T8 * ncols * sizeof(int32_t)));
     if (rt_per_panel < 1) return 1;
     if (rt_per_panel >= nt) rt_per_panel = nt;
     else if (rt_per_panel > 8) rt_per_panel = rt_per_panel / 8 * 8;   // whole super-tile rows (8 row tiles in the 384 x 256 tiling, 4 in the other)
@@ -849,9 +872,9 @@ static int w8_product(eagle_ctx* ctx, int cfg, bool upper, long np, const int8_t
         const int rt1 = (int)std::min<long>(nt, rt0 + rt_per_panel);
         W8List l;
         const bool piped = ctx->tune != 31 && (double)np * TW_M < 2147483648.0;   // tune 31: the compiler-scheduled 256 x 256 form (A/B runs)
-        int rc = w8_get_list(ctx, nt, rt0, rt1, upper, piped, cfg, maxp, &l);
+        int rc = w8_get_list(ctx, nt, rt0, rt1, upper, piped, cfg, maxp, &l, c0, c1);
         if (rc) return rc;
-        const long img_elems = (long)(rt1 - rt0) * T8 * np;
+        const long img_elems = (long)(rt1 - rt0) * T8 * ncols;
         if (piped) {
             if (!ctx->attr_w8_gemm) {
                 hipError_t ea = hipFuncSetAttribute((const void*)k_w8_gemm_p, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (TW_ABYTES + TILE_BYTES));
@@ -859,10 +882,10 @@ static int w8_product(eagle_ctx* ctx, int cfg, bool upper, long np, const int8_t
                 ctx->attr_w8_gemm = true;
             }
             hipLaunchKernelGGL(k_w8_gemm_p, dim3((unsigned)(8 * l.maxlen)), dim3(512), 2 * (TW_ABYTES + TILE_BYTES), s, sA, sB, np * np, np, (const unsigned*)l.work,
-                               l.maxlen, (const W8Group*)l.groups, w.levels, img_elems, np, rt0, (int)(np / BK8), np);
+                               l.maxlen, (const W8Group*)l.groups, w.levels, img_elems, ncols, rt0, (int)(np / BK8), np, col0);
         } else
         hipLaunchKernelGGL(k_w8_gemm, dim3((unsigned)(8 * l.maxlen)), dim3(512), 0, s, sA, sB, np * np, np, (const unsigned*)l.work, l.maxlen,
-                           (const W8Group*)l.groups, w.levels, img_elems, np, rt0, (int)(np / BK8));
+                           (const W8Group*)l.groups, w.levels, img_elems, ncols, rt0, (int)(np / BK8), col0);
         combine(l, img_elems, (long)rt0 * T8, (long)(rt1 - rt0) * T8);
     }
     hipError_t e = hipGetLastError();
@@ -882,22 +905,110 @@ static int w8_fetch(eagle_ctx* ctx, void* dst, const void* src, size_t bytes, hi
     return EAGLE_OK;
 }
 
-// Returns EAGLE_OK (Wu_out, v_out written; ctx->w8_* describe the result), 1 = declined (nothing of value written: run the fp64
-// products), or an error.
-extern "C" int eagle_dev_scan_operands_w8(eagle_ctx* ctx, const double* Sa, const double* Va, const double* ahat, long n, long np, double* v_out,
-                                          double* Wu_out, double* tmp, void* stream) {
+// ------------------------------------------------------------------------------------------------
+// The pipeline in three steps, so that the reference-shaped call can work on V while it arrives over PCIe:
+//   eagle_w8_begin   workspace, v = S a_hat, statistics + digit slices of S;
+//   eagle_w8_vrows   the rows [r0, r1) of V's image have landed: their statistics and digit slices -- and, when the caller allows a
+//                    GUESS of the first product's configuration (the one the last call of this context chose: V changes little
+//                    between the find_qtl calls of an AM() run), the columns [r0, r1) of X = S V^T at once (exact integer level sums:
+//                    the same bits whatever the column blocking);
+//   eagle_w8_finish  statistics of all of V, the configuration the RULE chooses; the first product is kept only if the guess WAS that
+//                    configuration (else it is formed anew: the result never depends on the guess), then S X^T, the bound, r.
+// eagle_dev_scan_operands_w8 = the three steps on resident operands, no guess.
+// All three return EAGLE_OK, 1 = declined (run the fp64 products), or an error.
+// ------------------------------------------------------------------------------------------------
+#define W8_VBLOCK 1536   /* rows of V per pipelined step: 4 column tiles of 384 = 6 of 256 */
+struct W8Pipe {
+    bool open = false, guessing = false, product1_done = false;
+    int guess = -1;
+    long n = 0, np = 0, rows_done = 0;
+    const double *Sa = nullptr, *Va = nullptr;
+    double *v = nullptr, *Wu = nullptr, *tmp = nullptr;
+    W8Ws w;
+};
+static W8Pipe* w8_pipe(eagle_ctx* ctx) {
+    if (!ctx->w8_pipe) ctx->w8_pipe = new W8Pipe;
+    return (W8Pipe*)ctx->w8_pipe;
+}
+void eagle_w8_release(eagle_ctx* ctx) {
+    delete (W8Pipe*)ctx->w8_pipe;
+    ctx->w8_pipe = nullptr;
+}
+static int w8_decline(eagle_ctx* ctx, W8Info& info, int why) {
+    info.declined = why;
+    ctx->w8_info = info;
+    w8_pipe(ctx)->open = false;
+    return 1;
+}
+extern "C" int eagle_w8_vrows_block(void) { return W8_VBLOCK; }
+
+extern "C" int eagle_w8_begin(eagle_ctx* ctx, const double* Sa, const double* Va, const double* ahat, long n, long np, double* v_out, double* Wu_out,
+                              double* tmp, int allow_guess, void* stream) {
     ctx->w8_active = false;
     ctx->w8_eta = 0.0;
     ctx->w8_info = W8Info();
+    W8Pipe* P = w8_pipe(ctx);
+    P->open = false;
     if (np % T8 || n > np || n <= 0 || (double)np * T8 >= 2147483648.0 || np / T8 > 4095) return 1;
     hipStream_t s = (hipStream_t)stream;
-    W8Ws w;
-    if (w8_workspace(ctx, np, &w)) { ctx->w8_info.declined = 5; return 1; }
+    if (w8_workspace(ctx, np, &P->w)) { ctx->w8_info.declined = 5; return 1; }
+    W8Ws& w = P->w;
     int rc = eagle_dev_scan_operands_begin(ctx, Sa, ahat, n, np, v_out, tmp, stream);
     if (rc) return rc;
-    // statistics + digit slices of the off-diagonal parts F (of S) and Fv (of V)
+    // statistics + digit slices of the off-diagonal part F of S (V's follow row block by row block: eagle_w8_vrows)
     rc = w8_stats_of(ctx, Sa, np, w.dS, w.mxS, w.ssqS, w.eS, w.dssqS, w.sA, nullptr, true, w, w.stats + 0, s);
-    if (!rc) rc = w8_stats_of(ctx, Va, np, w.dV, w.mxV, w.ssqV, w.eV, w.dssqV, w.sB, w.dS, true, w, w.stats + 1, s);
+    if (rc) return rc;
+    hipError_t er = hipMemsetAsync(w.bad, 0, sizeof(int), s);   // (S's flag is in its statistics already; V's rows raise it again)
+    if (er != hipSuccess) return eagle_fail_hip(ctx, er, "w8 memset");
+    P->open = true;
+    P->n = n; P->np = np; P->Sa = Sa; P->Va = Va; P->v = v_out; P->Wu = Wu_out; P->tmp = tmp;
+    P->rows_done = 0;
+    P->product1_done = false;
+    // a guess is only worth having when the level images of one column block fit the workspace in one row panel
+    const int maxp = (int)std::min<long>(8, 131071 / np);
+    P->guessing = allow_guess && ctx->w8_guess_np == np && ctx->w8_guess_c1 >= 0 && maxp >= 1 &&
+                  w8_groups(W8_CONFIGS[ctx->w8_guess_c1], maxp).size() * (size_t)np * (size_t)std::min<long>(np, W8_VBLOCK + 255) * sizeof(int32_t) <= w.level_bytes;
+    P->guess = P->guessing ? ctx->w8_guess_c1 : -1;
+    return EAGLE_OK;
+}
+
+static void w8_launch_combine1(W8Pipe* P, const W8List& l, long img, long row0, long rows, long c0, long ncols, hipStream_t s) {
+    W8Ws& w = P->w;
+    hipLaunchKernelGGL(k_w8_combine1, dim3((unsigned)((ncols + 255) / 256), (unsigned)rows), dim3(256), 0, s, P->Sa, P->Va, P->np, (const double*)w.dS,
+                       (const double*)w.dV, (const int*)w.eS, (const int*)w.eV, (const int32_t*)w.levels, img, (const W8Group*)l.groups, l.ngroups, row0, P->tmp,
+                       c0, ncols);
+}
+
+extern "C" int eagle_w8_vrows(eagle_ctx* ctx, long r0, long r1, void* stream) {
+    W8Pipe* P = w8_pipe(ctx);
+    if (!P->open) return 1;
+    if (r0 != P->rows_done || r1 <= r0 || r1 > P->np) return eagle_fail(ctx, EAGLE_ERR_ARG, "w8_vrows: row blocks must arrive in order");
+    hipStream_t s = (hipStream_t)stream;
+    W8Ws& w = P->w;
+    int rc = w8_rows_of(ctx, P->Va, P->np, r0, r1, w.dV, w.mxV, w.ssqV, w.eV, w.dssqV, w.sB, w, s);
+    if (rc) return rc;
+    P->rows_done = r1;
+    if (P->guessing && r0 % W8_VBLOCK == 0 && (r1 % W8_VBLOCK == 0 || r1 == P->np)) {
+        // the columns [r0, r1) of X on the guessed configuration (kept by eagle_w8_finish only if the rule chooses the same one)
+        rc = w8_product(ctx, P->guess, false, P->np, w.sA, w.sB, w, s,
+                        [&](const W8List& l, long img, long row0, long rows) { w8_launch_combine1(P, l, img, row0, rows, r0, r1 - r0, s); }, r0, r1);
+        if (rc < 0) return rc;
+        if (rc) P->guessing = false;
+    } else P->guessing = false;
+    return EAGLE_OK;
+}
+
+extern "C" int eagle_w8_finish(eagle_ctx* ctx, void* stream) {
+    W8Pipe* P = w8_pipe(ctx);
+    if (!P->open) return 1;
+    if (P->rows_done != P->np) return eagle_fail(ctx, EAGLE_ERR_ARG, "w8_finish: rows of V missing");
+    P->open = false;
+    hipStream_t s = (hipStream_t)stream;
+    W8Ws& w = P->w;
+    const double *Sa = P->Sa, *Va = P->Va;
+    double *tmp = P->tmp, *Wu_out = P->Wu;
+    const long n = P->n, np = P->np;
+    int rc = w8_reduce_of(ctx, Va, np, w.dV, w.mxV, w.ssqV, w.eV, w.dssqV, w.dS, true, w, w.stats + 1, s);
     if (rc) return rc;
     // r = the row sums of sym(S V S) in fp64: the mean of (Sa Va Sa) 1 (row-type products) and (Sa Va Sa)^T 1 (column-type)
     hipLaunchKernelGGL(k_w8_fill_ones, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, w.r2, n, np);
@@ -912,7 +1023,7 @@ extern "C" int eagle_dev_scan_operands_w8(eagle_ctx* ctx, const double* Sa, cons
     W8Stats st[3];
     if ((rc = w8_fetch(ctx, st, w.stats, 2 * sizeof(W8Stats), s))) return rc;
     W8Info info;
-    if (st[0].bad || st[1].bad) { info.declined = 1; ctx->w8_info = info; return 1; }
+    if (st[0].bad || st[1].bad) return w8_decline(ctx, info, 1);
     const double up = 1.0 + 1e-9;
     const double normS = (st[0].maxd + sqrt(st[0].fro2 * up)) * up, normV = (st[1].maxd + sqrt(st[1].fro2 * up)) * up;
     const double wd_est = st[1].wdsum / (double)n;               // mean_k |W_kk| ~ mean_k D_k^2 |Dv_k|
@@ -928,23 +1039,24 @@ extern "C" int eagle_dev_scan_operands_w8(eagle_ctx* ctx, const double* Sa, cons
     const double asym = (M_SQRT2 * 2.0 * normS * (normV * nA + (nA + st[0].maxd) * nB) + 2.0 * nA * normV * normS + normS * normS * nB +
                          2.0 * (nA * nA * normV + 2.0 * nA * nB * normS)) * up;
     info.asym_term = asym;
-    if (!(target > 0.0) || !(asym <= 0.25 * target)) { info.declined = 2; ctx->w8_info = info; return 1; }
+    if (!(target > 0.0) || !(asym <= 0.25 * target)) return w8_decline(ctx, info, 2);
     double b1 = 0.0;
     // (the bounds fall ~13x per configuration step: the second product is left with at least 30 % of the target, rarely one step's worth)
     const int c1 = w8_choose(st[0], st[1], np, 0.7 * (target - asym) / (normS * M_SQRT2), &b1);
-    if (c1 < 0) { info.declined = 3; ctx->w8_info = info; return 1; }
-    const W8Group* groups_dev = nullptr;
-    rc = w8_product(ctx, c1, false, np, w.sA, w.sB, w, s, [&](const W8List& l, long img, long row0, long rows) {
-        hipLaunchKernelGGL(k_w8_combine1, dim3((unsigned)(np / 256), (unsigned)rows), dim3(256), 0, s, Sa, Va, np, (const double*)w.dS, (const double*)w.dV,
-                           (const int*)w.eS, (const int*)w.eV, (const int32_t*)w.levels, img, (const W8Group*)l.groups, l.ngroups, row0, tmp);
-    });
-    (void)groups_dev;
-    if (rc) { if (rc == 1) { info.declined = 5; ctx->w8_info = info; } return rc; }
+    if (c1 < 0) return w8_decline(ctx, info, 3);
+    ctx->w8_guess_c1 = c1;
+    ctx->w8_guess_np = np;
+    info.pipelined = P->guessing && P->guess == c1;
+    if (!info.pipelined) {   // no guess, or not the configuration the rule chooses: X = S V^T now, all of it
+        rc = w8_product(ctx, c1, false, np, w.sA, w.sB, w, s,
+                        [&](const W8List& l, long img, long row0, long rows) { w8_launch_combine1(P, l, img, row0, rows, 0, np, s); });
+        if (rc) { if (rc == 1) return w8_decline(ctx, info, 5); return rc; }
+    }
     // X = tmp: statistics + slices (over Fv's)
     rc = w8_stats_of(ctx, tmp, np, w.dX, w.mxX, w.ssqX, w.eX, w.dssqX, w.sB, nullptr, false, w, w.stats + 2, s);
     if (rc) return rc;
     if ((rc = w8_fetch(ctx, st + 2, w.stats + 2, sizeof(W8Stats), s))) return rc;
-    if (st[2].bad) { info.declined = 1; ctx->w8_info = info; return 1; }
+    if (st[2].bad) return w8_decline(ctx, info, 1);
     // rounding of the element-wise terms and the level sums of X: a handful of roundings on terms of these sizes
     const double fS = sqrt(st[0].fro2 * up) * up, fV = sqrt(st[1].fro2 * up) * up, fX = sqrt(st[2].fro2 * up) * up;
     const double round1 = ldexp(st[0].maxd * fV + fS * st[1].maxd + fS * fV + st[0].maxd * st[1].maxd * sqrt((double)np), -49);
@@ -952,13 +1064,13 @@ extern "C" int eagle_dev_scan_operands_w8(eagle_ctx* ctx, const double* Sa, cons
     const double used = (normS * etaX * M_SQRT2 + asym) * up;
     double b2 = 0.0;
     const int c2 = w8_choose(st[0], st[2], np, (target - used) / M_SQRT2 * 0.98, &b2);
-    if (c2 < 0) { info.declined = 4; ctx->w8_info = info; return 1; }
+    if (c2 < 0) return w8_decline(ctx, info, 4);
     rc = w8_product(ctx, c2, true, np, w.sA, w.sB, w, s, [&](const W8List& l, long img, long row0, long rows) {
         hipLaunchKernelGGL(k_w8_combine2, dim3((unsigned)(np / 32), (unsigned)(rows / 32)), dim3(256), 0, s, Sa, (const double*)tmp, np, (const double*)w.dS,
                            (const double*)w.dX, (const int*)w.eS, (const int*)w.eX, (const int32_t*)w.levels, img, (const W8Group*)l.groups, l.ngroups, row0,
                            Wu_out);
     });
-    if (rc) { if (rc == 1) { info.declined = 5; ctx->w8_info = info; } return rc; }
+    if (rc) { if (rc == 1) return w8_decline(ctx, info, 5); return rc; }
     const double round2 = ldexp(st[0].maxd * fX + fS * st[2].maxd + fS * fX + st[0].maxd * st[2].maxd * sqrt((double)np), -49);
     const double eta = ((normS * etaX + b2 + round2) * M_SQRT2 + asym) * up;
     // the a-posteriori check against the diagonal of the W just made
@@ -970,7 +1082,7 @@ extern "C" int eagle_dev_scan_operands_w8(eagle_ctx* ctx, const double* Sa, cons
     info.pairs1 = w8_config_pairs(W8_CONFIGS[c1]); info.pairs2 = w8_config_pairs(W8_CONFIGS[c2]);
     info.eta = eta; info.eta_x = etaX; info.bound1 = b1; info.bound2 = b2; info.norm_s = normS; info.target = target;
     info.mean_diag = sumdiag / (double)n;
-    if (!(eta <= W8_ACCEPT * ctx->scan_budget * info.mean_diag)) { info.declined = 6; ctx->w8_info = info; return 1; }
+    if (!(eta <= W8_ACCEPT * ctx->scan_budget * info.mean_diag)) return w8_decline(ctx, info, 6);
     ctx->w8_info = info;
     ctx->w8_active = true;
     ctx->w8_eta = eta;
@@ -981,4 +1093,12 @@ extern "C" int eagle_dev_scan_operands_w8(eagle_ctx* ctx, const double* Sa, cons
     ctx->w8_n = n;
     ctx->w8_tmp = tmp;
     return EAGLE_OK;
+}
+
+extern "C" int eagle_dev_scan_operands_w8(eagle_ctx* ctx, const double* Sa, const double* Va, const double* ahat, long n, long np, double* v_out,
+                                          double* Wu_out, double* tmp, void* stream) {
+    int rc = eagle_w8_begin(ctx, Sa, Va, ahat, n, np, v_out, Wu_out, tmp, 0, stream);
+    if (!rc) rc = eagle_w8_vrows(ctx, 0, np, stream);
+    if (!rc) rc = eagle_w8_finish(ctx, stream);
+    return rc;
 }

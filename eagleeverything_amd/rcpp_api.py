@@ -146,7 +146,7 @@ def set_w_mode(mode, device=0):
 class _WInfo(C.Structure):
     _fields_ = [("int8", C.c_int), ("declined", C.c_int), ("k1", C.c_int), ("T1", C.c_int), ("pairs1", C.c_int), ("k2", C.c_int), ("T2", C.c_int),
                 ("pairs2", C.c_int), ("eta", C.c_double), ("eta_x", C.c_double), ("target", C.c_double), ("mean_diag", C.c_double),
-                ("asym_term", C.c_double)]
+                ("asym_term", C.c_double), ("pipelined", C.c_int), ("pad", C.c_int)]
 
 
 def last_w_info(device=0):

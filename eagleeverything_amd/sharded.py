@@ -310,7 +310,7 @@ class DeviceShard:
         class Info(C.Structure):
             _fields_ = [("int8", C.c_int), ("declined", C.c_int), ("k1", C.c_int), ("T1", C.c_int), ("pairs1", C.c_int), ("k2", C.c_int),
                         ("T2", C.c_int), ("pairs2", C.c_int), ("eta", C.c_double), ("eta_x", C.c_double), ("target", C.c_double),
-                        ("mean_diag", C.c_double), ("asym_term", C.c_double)]
+                        ("mean_diag", C.c_double), ("asym_term", C.c_double), ("pipelined", C.c_int), ("pad", C.c_int)]
         i = Info()
         self._check(self.L.eagle_last_w_info(self.ctx, C.byref(i)))
         return {k: getattr(i, k) for k, _ in Info._fields_}

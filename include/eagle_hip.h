@@ -120,7 +120,10 @@ typedef struct eagle_w_info {
     double eta_x;        /* || X computed - V S ||_F bound */
     double target;       /* what the configurations were chosen for (0.02 x budget x estimate of mean |W_kk|) */
     double mean_diag;    /* mean |W_kk| of the W delivered */
-    double asym_term;    /* share of eta that pays for max |S - S^T|, max |V - V^T| */
+    double asym_term;    /* share of eta that pays for || S - S^T ||_F, || V - V^T ||_F (measured) */
+    int pipelined;       /* 1: eagle_calculate_a_and_vara formed V S column block by column block while V was still arriving over PCIe (on the
+                            configuration of the context's last call, which the rule then confirmed: the bits are the same either way) */
+    int pad;
 } eagle_w_info;
 int eagle_last_w_info(eagle_ctx* ctx, eagle_w_info* out);
 

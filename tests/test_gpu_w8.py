@@ -265,6 +265,21 @@ def test_reference_shaped_call_on_the_int8_w(tmp_path):
         np.testing.assert_allclose(r["a"], ref["a"], rtol=1e-9, atol=1e-12 * np.abs(ref["a"]).max())
         np.testing.assert_allclose(r["vara"], ref["vara"], rtol=1e-7)
         assert api.last_scan_argmax()[0] == oracle_c.tsq_argmax(ref["a"], ref["vara"])[1]
+        # the second call of a context forms V S block by block while V arrives (on the first call's configuration): the same bits
+        rp = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], np.nan, S, V, 8.0, (L, n), ahat)
+        assert api.last_w_info()["pipelined"] == 1 and info["pipelined"] == 0
+        assert np.array_equal(rp["vara"], r["vara"]) and np.array_equal(rp["a"], r["a"])
+        # ... and a V that calls for another configuration is not served by the guess: a stronger off-diagonal part, new statistics
+        V2 = V + 0.05 * (B + B.T)
+        rq = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], np.nan, S, V2, 8.0, (L, n), ahat)
+        iq = api.last_w_info()
+        refq = oracle_c.calculate_a_and_vara_rcpp(geno["asciifileMt"], np.nan, S, V2, 8.0, (L, n), ahat)
+        np.testing.assert_allclose(rq["vara"], refq["vara"], rtol=1e-7)
+        api.set_w_mode(0)
+        r0q = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], np.nan, S, V2, 8.0, (L, n), ahat)
+        api.set_w_mode(2)
+        np.testing.assert_allclose(rq["vara"], r0q["vara"], rtol=1e-7)
+        assert iq["int8"] == 1
         os.environ["EAGLE_HIP_MAX_RESIDENT_GB"] = "0.0012"              # marker blocks of 768: the file is streamed
         api.drop_cache()
         r2 = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], np.nan, S, V, 8.0, (L, n), ahat)
