@@ -477,11 +477,11 @@ def main_abi(args):
         Lp0 = (ph["markers"] + 255) // 256 * 256
         roof = None
         if args.mode == "i8" and ph["vara_ms"] > 0:
-            # the digit count is chosen inside the library from the error bound (4 at this shape); the line states the assumption
-            S_used = args.slices or 4
+            # the digit count is chosen inside the library from the error bound: eagle_last_scan_digits says what the last scan ran on
+            S_used = rcpp_api.last_scan_digits(device=device)[0] or args.slices or 3
             ops = sum(2.0 * Lp0 * 256 * min((ct + 1) * 256, np_) for ct in range(np_ // 256)) * S_used
             roof = {"bound": "mfma", "kernel": "k_vara_i8p on the lead device's shard (%d markers), HIP events inside the library "
-                                               "(eagle_last_scan_timing.vara_ms), %d digit slices assumed" % (ph["markers"], S_used),
+                                               "(eagle_last_scan_timing.vara_ms), %d digit slices (eagle_last_scan_digits)" % (ph["markers"], S_used),
                     "achieved": ops / (ph["vara_ms"] / 1e3) / 1e12, "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s",
                     "frac": ops / (ph["vara_ms"] / 1e3) / 1e12 / I8_MFMA_PEAK_TOPS, "kernel_ms": ph["vara_ms"], "traffic": None}
         distinct = len(set(devs)) == len(devs)
@@ -757,7 +757,7 @@ def main():
         rel_all = ((vara_step - v64_all).abs() / v64_all.abs())[okm]
         all_marker_parity = {"markers": int(okm.sum()), "vara_max_rel_digit_scan_vs_fp64_scan": float(rel_all.max()),
                              "vara_p999_rel": float(torch.quantile(rel_all[:: max(1, rel_all.numel() // 1000000)], 0.999)),
-                             "a_bitwise_equal": bool(torch.equal(a_step, sh.a[:sh.Lloc])),
+                             "a_max_rel": float((a_step - sh.a[:sh.Lloc]).abs().max() / sh.a[:sh.Lloc].abs().max()),
                              "note": "every marker of the timed digit-slice step against the fp64-MFMA scan of the same operands (eagle_set_scan_mode(0)), on the device"}
         secondary["scan_fp64_mode"] = {"value": Ltot / el64, "unit": "markers/s", "ms_per_step": el64 * 1e3,
                                        "selected_marker_equal_to_digit_mode": bool(s64[0] == sel_i8[0]),

@@ -64,8 +64,12 @@ static void arena_collect(eagle_ctx* ctx) {
     } else (void)hipGetLastError();
     delete pf;
 }
-static void arena_prefetch(eagle_ctx* ctx, size_t total) {
+static void arena_prefetch(eagle_ctx* ctx, size_t total, bool only_if_roomy = false) {
     if (ctx->arena_prefetch || total <= ctx->arena_cap || total < ((size_t)4 << 30)) return;
+    if (only_if_roomy) {   // a guess about what the caller does next must not crowd the card: at most half of what is free now
+        size_t freeb = 0, totalb = 0;
+        if (hipMemGetInfo(&freeb, &totalb) != hipSuccess || total > freeb / 2) { (void)hipGetLastError(); return; }
+    }
     ArenaPrefetch* pf = new ArenaPrefetch;
     pf->bytes = total;
     const int device = ctx->device;
@@ -88,6 +92,7 @@ size_t eagle_drop_f4_images(eagle_ctx* ctx) {
         }
     return freed;
 }
+static int prepare_scan(eagle_ctx* ctx, long n, long L, bool only_if_roomy);
 static int arena_reserve(eagle_ctx* ctx, size_t total) {
     ctx->arena_off = 0;
     arena_collect(ctx);
@@ -327,10 +332,23 @@ static void drop_cache_local(eagle_ctx* ctx) {
     ctx->cache.clear();
     if (ctx->f4_buf) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->f4_buf); ctx->f4_buf = nullptr; ctx->f4_cap = 0; }
 }
+// The resident genotype files AND the grow-only workspaces this context holds between calls (the scan arena -- a background reservation
+// in flight included --, the workspace of the int8 W products): everything a caller can get back without closing the context.
+static void drop_workspaces(eagle_ctx* c) {
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    arena_collect(c);
+    if (c->arena) { (void)hipFree(c->arena); c->arena = nullptr; c->arena_cap = 0; c->arena_off = 0; }
+    if (c->w8_ws) { (void)hipFree(c->w8_ws); c->w8_ws = nullptr; c->w8_ws_cap = 0; }
+    if (c->w8_true_ws) { (void)hipFree(c->w8_true_ws); c->w8_true_ws = nullptr; c->w8_true_cap = 0; }
+    c->w8_active = false;
+}
 extern "C" void eagle_drop_cache(eagle_ctx* ctx) {
     if (!ctx) return;
-    for (eagle_ctx* p : ctx->peers) drop_cache_local(p);
+    for (eagle_ctx* p : ctx->peers) { drop_cache_local(p); drop_workspaces(p); }
     drop_cache_local(ctx);
+    drop_workspaces(ctx);
+    (void)hipSetDevice(ctx->device);
 }
 
 extern "C" void eagle_close(eagle_ctx* ctx) {
@@ -1202,7 +1220,7 @@ extern "C" int eagle_calculateMMt(eagle_ctx* ctx, const char* f_name_ascii, doub
     if (rc) return rc;
     // AM() calls this once, then works on the host for seconds (eigen, REML) before its first find_qtl: the arena of that scan is
     // reserved meanwhile, on a background thread (a no-op below 4 GB)
-    (void)eagle_prepare_scan(ctx, n, L);
+    (void)prepare_scan(ctx, n, L, true);
     return download_big(ctx, MMt_out, ctx->d_mmt, sizeof(double) * (size_t)n * n);
 }
 
@@ -1267,15 +1285,21 @@ static size_t scan_arena_bytes(eagle_ctx* ctx, long n, long Lr) {
     const size_t certb = use_i8 ? (size_t)eagle_scan_certify_workspace_bytes(np) : 0;
     return 4 * arena_round(sq) + 2 * arena_round(sizeof(double) * np) + arena_round(wsb) + arena_round(certb);
 }
-extern "C" int eagle_prepare_scan(eagle_ctx* ctx, long n, long L) {
+static int prepare_scan(eagle_ctx* ctx, long n, long L, bool only_if_roomy) {
     if (!ctx || n <= 0 || L <= 0) return EAGLE_ERR_ARG;
     const int nd = ndev_of(ctx);
     std::vector<long> edge;
     split_markers(L, nd, edge);
-    arena_prefetch(ctx, scan_arena_bytes(ctx, n, edge[1] - edge[0]));
-    for (size_t k = 0; k < ctx->peers.size(); k++) arena_prefetch(ctx->peers[k], scan_arena_bytes(ctx->peers[k], n, edge[k + 2] - edge[k + 1]));
+    (void)hipSetDevice(ctx->device);
+    arena_prefetch(ctx, scan_arena_bytes(ctx, n, edge[1] - edge[0]), only_if_roomy);
+    for (size_t k = 0; k < ctx->peers.size(); k++) {
+        (void)hipSetDevice(ctx->peers[k]->device);
+        arena_prefetch(ctx->peers[k], scan_arena_bytes(ctx->peers[k], n, edge[k + 2] - edge[k + 1]), only_if_roomy);
+    }
+    (void)hipSetDevice(ctx->device);
     return EAGLE_OK;
 }
+extern "C" int eagle_prepare_scan(eagle_ctx* ctx, long n, long L) { return prepare_scan(ctx, n, L, false); }
 
 static int ensure_scan_out(eagle_ctx* ctx, long L_pad) {
     if (ctx->scan_cap >= L_pad) return EAGLE_OK;
@@ -1319,10 +1343,14 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
     GenoEntry* g = nullptr;
     bool streamed = false;
     if (!rc && Lr > 0) {
+        // operands, digit + certification workspaces (the arena: what this context already holds of it -- from an earlier call or from
+        // the background reservation -- is not free memory any more and must not be counted against the file a second time), the
+        // re-centred image of the shard
+        arena_collect(ctx);
+        const size_t arena_need = 4 * sq + (use_i8 ? (size_t)eagle_vara_i8_workspace_bytes(np, Lp, nslices) + (size_t)eagle_scan_certify_workspace_bytes(np) : 0);
         int r = get_resident(ctx, f_name_ascii, m0, Lr, 0, n, max_memory_in_Gbytes, host_threads(), &g,
-                             4 * sq + (use_i8 ? (size_t)eagle_vara_i8_workspace_bytes(np, Lp, nslices) + (size_t)Lp * np + 9 * (size_t)Lp +
-                                                    (size_t)eagle_scan_certify_workspace_bytes(np) : 0) +
-                                 ((size_t)1 << 30));  // operands, digit + certification workspaces, the re-centred image of the shard
+                             (arena_need > ctx->arena_cap ? arena_need - ctx->arena_cap : 0) + (use_i8 ? (size_t)Lp * np + 9 * (size_t)Lp : 0) +
+                                 ((size_t)1 << 30));
         if (r < 0) rc = r;
         streamed = (r == EAGLE_STREAM);
     }

@@ -1766,7 +1766,10 @@ static int vara_i8_launch(eagle_ctx* ctx, const int8_t* Mt8s, long L_pad, long n
     // form (k_vara_i8w), 7 = whole workers in the last round.
     if (vara_piped(ctx, n_pad) || (ctx->tune == 9 && n_pad < 32768)) {
         const bool piped = vara_piped(ctx, n_pad);
-        const bool pace = piped && ctx->tune == 14 && !ext;
+        // paced workers (a soft barrier per column-tile pair, round 3's tune 14): 1 % slower at n_pad = 10,240, where the L2 serves 68-72 % of
+        // the stage fills anyway, 3.3 % FASTER at n_pad = 50,176, where the unpaced workers drift apart over the 5x longer K loops and the hit
+        // rate falls to 53 % (profiles/r04_rocprof_C4, r04_vara_pace_50k.txt): on from 32,768 padded individuals up; same integer sums either way
+        const bool pace = piped && !ext && (ctx->tune == 14 || (ctx->tune == 0 && n_pad >= 32768));
         const bool px = piped && ext;
         const void* kfn = !piped ? (const void*)k_vara_i8w
                                  : (pace ? (const void*)k_vara_i8p<true> : (px ? (const void*)k_vara_i8p<false, true> : (const void*)k_vara_i8p<false>));

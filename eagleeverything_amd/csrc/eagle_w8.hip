@@ -7,7 +7,7 @@
 //
 // Splitting.  S = D + F, V = Dv + Fv (diagonal + off-diagonal part of the row-major images Sa, Va).  MMt^-1/2 and a variance
 // matrix are diagonally dominant: the diagonal parts are handled exactly, element by element, in fp64 --
-//     X[j][k] = (S V)[j][k] = D_j Dv_j [j = k]  +  D_j Fv[j][k]  +  F[j][k] Dv_k  +  G1[j][k],      G1 = F Fv^T   (NT product),
+//     X[j][k] = (S V^T)[j][k] = D_j Dv_j [j = k]  +  D_j Fv[k][j]  +  F[j][k] Dv_k  +  G1[j][k],    G1 = F Fv^T   (NT product of the images),
 //     W[i][j] = (S X^T)[i][j] = D_i Dx_i [i = j]  +  D_i Fx[j][i]  +  F[i][j] Dx_j  +  G2[i][j],    G2 = F Fx^T,  X = Dx + Fx,
 // and only G1, G2 are matrix products.  Their operands are flat (no dominant entry), so a per-ROW power-of-two scale wastes no bits:
 //     F[i][l] = 2^(e_i+2) ( sum_{p=1..6} 256^-p a_p[i][l]  +  r ),   a_p in [-128, 127] balanced digits,  |r| <= 256^-6 / 2,
@@ -386,20 +386,26 @@ __device__ __forceinline__ double w8_levels(const int32_t* __restrict__ L, long 
     return s;
 }
 
-// X[j][k] for the rows [row0, row0 + gridDim.y) of X's image (see the head of the file)
-// (Va and X may be the same buffer: every element is read, then written, by one thread)
-__global__ __launch_bounds__(256) void k_w8_combine1(const double* __restrict__ Sa, const double* Va, long np, const double* __restrict__ dS,
+// X[j][k] = (Sa Va^T)[j][k] for one 32 x 32 tile: rows j of the panel [row0, ...), columns k of the window [col0, col0 + ncols).  The
+// element-wise term D_j Va[k][j] reads V's image TRANSPOSED (through LDS): it is row k of V that the product's digit slices come from,
+// so X is exactly Sa Va^T -- and a column window needs only the rows of V that have landed (eagle_w8_vrows).
+__global__ __launch_bounds__(256) void k_w8_combine1(const double* __restrict__ Sa, const double* __restrict__ Va, long np, const double* __restrict__ dS,
                                                      const double* __restrict__ dV, const int* __restrict__ eS, const int* __restrict__ eV,
                                                      const int32_t* __restrict__ L, long img_elems, const W8Group* __restrict__ groups, int ngroups,
-                                                     long row0, double* X, long col0, long ncols) {
-    const long kk = (long)blockIdx.x * 256 + threadIdx.x, j = row0 + blockIdx.y;
-    if (kk >= ncols) return;
-    const long k = col0 + kk;
-    const double g = ldexp(w8_levels(L, img_elems, (long)blockIdx.y * ncols + kk, groups, ngroups), eS[j] + eV[k] + 4);
-    double x;
-    if (j == k) x = dS[j] * dV[j] + g;
-    else x = (dS[j] * Va[j * np + k] + Sa[j * np + k] * dV[k]) + g;
-    X[j * np + k] = x;
+                                                     long row0, double* __restrict__ X, long col0, long ncols) {
+    const long bj = row0 + (long)blockIdx.y * 32, bk = col0 + (long)blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    __shared__ double vt[32][33];   // vt[a][b] = Va[bk + a][bj + b]
+    for (int r = ty; r < 32; r += 8) vt[r][tx] = Va[(bk + r) * np + bj + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const long j = bj + r, k = bk + tx;
+        const double g = ldexp(w8_levels(L, img_elems, (j - row0) * ncols + (k - col0), groups, ngroups), eS[j] + eV[k] + 4);
+        double x;
+        if (j == k) x = dS[j] * dV[j] + g;
+        else x = (dS[j] * vt[tx][r] + Sa[j * np + k] * dV[k]) + g;
+        X[j * np + k] = x;
+    }
 }
 
 // The folded image of W from its upper triangle: Wu[i][j] = 2 W[i][j] (i < j), W[i][i], 0 below; one block per 32 x 32 tile.
@@ -974,7 +980,7 @@ extern "C" int eagle_w8_begin(eagle_ctx* ctx, const double* Sa, const double* Va
 
 static void w8_launch_combine1(W8Pipe* P, const W8List& l, long img, long row0, long rows, long c0, long ncols, hipStream_t s) {
     W8Ws& w = P->w;
-    hipLaunchKernelGGL(k_w8_combine1, dim3((unsigned)((ncols + 255) / 256), (unsigned)rows), dim3(256), 0, s, P->Sa, P->Va, P->np, (const double*)w.dS,
+    hipLaunchKernelGGL(k_w8_combine1, dim3((unsigned)(ncols / 32), (unsigned)(rows / 32)), dim3(256), 0, s, P->Sa, P->Va, P->np, (const double*)w.dS,
                        (const double*)w.dV, (const int*)w.eS, (const int*)w.eV, (const int32_t*)w.levels, img, (const W8Group*)l.groups, l.ngroups, row0, P->tmp,
                        c0, ncols);
 }
@@ -1031,8 +1037,8 @@ extern "C" int eagle_w8_finish(eagle_ctx* ctx, void* stream) {
     // would cost the scan its tighter certificate (or a digit); accepted, at the end, against the budget the scan falls back to
     const double target = W8_TARGET * ctx->scan_budget_tight * wd_est;
     // The images stand in for their transposes (NT products, upper triangle only).  With A = (Sa - Sa^T)/2, B = (Va - Va^T)/2:
-    // computed W' = Sa Vs Sa^T + Sa B Sa^T - 2 Sa B D against T' = Sa Va Sa, whose symmetric part is what the scan's quadratic
-    // forms see:  || W' - T' ||_F <= 2 ||S|| (||V|| ||A||_F + (||A|| + max|D|) ||B||_F),  and folding the upper triangle of T' instead of
+    // computed W' = Sa Va^T Sa^T = Sa Vs Sa^T - Sa B Sa^T against T' = Sa Va Sa, whose symmetric part is what the scan's quadratic
+    // forms see:  || W' - T' ||_F <= 2 ||S|| (||V|| ||A||_F + (||A|| + max|D|) ||B||_F) (generous),  and folding the upper triangle of T' instead of
     // symmetrising it costs || antisym(T') ||_F <= 2 ||A||_F ||V|| ||S|| + ||S||^2 ||B||_F (+ second order).  Visibly asymmetric
     // operands make this term large and the call declines (the fp64 path then takes its general products).
     const double nA = 0.5 * st[0].asym * up, nB = 0.5 * st[1].asym * up;

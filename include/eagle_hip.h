@@ -66,6 +66,8 @@ void eagle_close(eagle_ctx* ctx);
 const char* eagle_last_error(eagle_ctx* ctx);
 void eagle_set_message_callback(eagle_ctx* ctx, eagle_message_fn fn, void* user);
 /* Drops HBM-resident genotype copies kept between calls. */
+/* (round 4: also the grow-only workspaces held between calls -- the scan arena, a background reservation of it, the workspace of
+ * the int8 W products; the next call allocates them again) */
 void eagle_drop_cache(eagle_ctx* ctx);
 /* "gfx950", CU count, HBM bytes -- for logs and bench JSON. */
 int eagle_device_info(eagle_ctx* ctx, char* arch_out, int arch_len, int* cu_count, int64_t* hbm_bytes);

@@ -239,13 +239,13 @@ def test_structured_population_panel():
     assert sh.best()[1] == best64[1]
 
 
-def test_reference_shaped_call_on_the_int8_w(tmp_path):
+@pytest.mark.parametrize("n,L", [(700, 3000), (3300, 1024)])   # one block of V's rows; three blocks of 1,536 (the pipelined upload)
+def test_reference_shaped_call_on_the_int8_w(tmp_path, n, L):
     """Through the C ABI of the Rcpp surface, resident and streamed in marker blocks: the oracle's marker, vara inside 1e-7 of it, the
-    same bits from both paths."""
+    same bits from both paths -- and from a call that forms V S block by block while V is still arriving."""
     from eagleeverything_amd import rcpp_api as api, synth
     from oracle import oracle_c
     oracle_c.build()
-    n, L = 700, 3000
     Mt8 = synth.genotypes_marker_major(n, L, seed=4)
     rng = np.random.default_rng(2)
     A = rng.standard_normal((n, 30)) / np.sqrt(n)
@@ -280,7 +280,7 @@ def test_reference_shaped_call_on_the_int8_w(tmp_path):
         api.set_w_mode(2)
         np.testing.assert_allclose(rq["vara"], r0q["vara"], rtol=1e-7)
         assert iq["int8"] == 1
-        os.environ["EAGLE_HIP_MAX_RESIDENT_GB"] = "0.0012"              # marker blocks of 768: the file is streamed
+        os.environ["EAGLE_HIP_MAX_RESIDENT_GB"] = "%.6f" % (1.6 * ((n + 255) // 256 * 256) * 768 / 1e9)   # marker blocks of 768: the file is streamed
         api.drop_cache()
         r2 = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], np.nan, S, V, 8.0, (L, n), ahat)
         assert api.last_w_info()["int8"] == 1
