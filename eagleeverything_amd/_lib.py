@@ -35,6 +35,7 @@ SIGNATURES = {
     "eagle_set_scan_rounding": (C.c_int, [C.c_void_p, C.c_int]),
     "eagle_set_scan_budget": (C.c_int, [C.c_void_p, C.c_double]),
     "eagle_last_scan_budget": (C.c_int, [C.c_void_p, c_dp, C.POINTER(C.c_int), c_dp]),
+    "eagle_last_scan_enforced": (C.c_int, [C.c_void_p, c_dp, C.POINTER(C.c_long)]),
     "eagle_prepare_scan": (C.c_int, [C.c_void_p, C.c_long, C.c_long]),
     "eagle_set_w_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "eagle_last_w_info": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -1335,9 +1335,10 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
     int rc = EAGLE_OK;
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) rc = eagle_fail_hip(ctx, e, "hipSetDevice");
-#define EAGLE_ARRIVE(v)                                                                                            \
+#define EAGLE_ARRIVE(v) EAGLE_ARRIVE2(v, 0)
+#define EAGLE_ARRIVE2(v, add)                                                                                      \
     do {                                                                                                           \
-        if (rv && !rv->arrive(rc == EAGLE_OK, (v))) return rc ? rc : eagle_fail(ctx, EAGLE_ERR_HIP, "another device of the scan failed"); \
+        if (rv && !rv->arrive(rc == EAGLE_OK, (v), (add))) return rc ? rc : eagle_fail(ctx, EAGLE_ERR_HIP, "another device of the scan failed"); \
         if (!rv && rc) return rc;                                                                                  \
     } while (0)
     GenoEntry* g = nullptr;
@@ -1359,6 +1360,7 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
     // certified against ONE lower bound of the maximum over every block of every device, so that the candidates, and with them every
     // returned bit, are those of the one-block scan of the whole file (the per-marker bounds of all blocks stay: 8 bytes per marker).
     const bool bounds_flow = use_i8 && (streamed || rv);
+    long over_tight_all = 0;   // markers of the whole scan over the tight threshold (CERT_TIGHT_MAX)
     const long Lc = streamed ? stream_chunk_rows(np, Lp) : Lp;  // marker rows per pass
     DevBuf dsel;
     const size_t wsb = use_i8 ? (size_t)eagle_vara_i8_workspace_bytes(np, Lc, nslices) : 0;
@@ -1368,7 +1370,7 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
     bool s_from_cache = false;  // the product runs on the device copy of the last call's S; the caller's S is verified under it
     bool s_check_pending = false;  // ... and the outcome of that verification has not been collected yet
     void *ws = nullptr, *cert = nullptr;
-    long* cert_totals = (long*)((char*)ctx->d_scratch + EAGLE_SCR_CERT_TOTALS);  // {re-evaluated, flagged, fell back}, summed over marker blocks
+    long* cert_totals = (long*)((char*)ctx->d_scratch + EAGLE_SCR_CERT_TOTALS);  // {re-evaluated, flagged, fell back, over the tight threshold}, summed over marker blocks
     ChunkRing ring;
     int8_t* shifted[2] = {nullptr, nullptr};
     int8_t* cs[2] = {nullptr, nullptr};
@@ -1428,7 +1430,7 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
         // streamed: every block is worked as a full chunk of Lc rows (one workspace layout for all of them; the rows beyond a short
         // last block are zero and land in the slack behind the shard's results)
         if ((r = ensure_scan_out(ctx, streamed ? (Lr + Lc - 1) / Lc * Lc : Lp))) return r;
-        HIPCHK(ctx, hipMemsetAsync(cert_totals, 0, 3 * sizeof(long), ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(cert_totals, 0, 4 * sizeof(long), ctx->stream));
         ph.mark(ctx->stream, PH_UPLOAD);
         return EAGLE_OK;
     };
@@ -1631,20 +1633,24 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
     }
     if (streamed && !rc) ring.finish(ctx);
     if (bounds_flow) {
-        double lb = 0.0;  // this shard's lower bound of the maximum tsq (0 for an empty shard)
+        // this shard's lower bound of the maximum tsq (0 for an empty shard) and its markers over the tight threshold: the maximum / the
+        // sum over the devices decide for all of them
+        eagle_cert_info mine = {};
         if (!rc && Lr > 0) {
-            rc = eagle_dev_cert_lb_b(ctx, Lr, ctx->d_a, ctx->d_vara, ctx->d_bound, cert, ctx->stream);
+            rc = eagle_dev_cert_lb_b(ctx, Lr, ctx->d_a, ctx->d_vara, ctx->d_bound, cert, ws, ctx->stream);
             if (!rc) {
-                e = hipMemcpyAsync(&lb, cert, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+                e = hipMemcpyAsync(&mine, cert, sizeof mine, hipMemcpyDeviceToHost, ctx->stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
                 if (e != hipSuccess) rc = eagle_fail_hip(ctx, e, "lower bound of the shard's maximum");
             }
         }
-        EAGLE_ARRIVE(lb);
+        const double lb = mine.lower_bound;
+        EAGLE_ARRIVE2(lb, (long)mine.over_tight);
         const double glb = rv ? rv->vmax : lb;
+        over_tight_all = rv ? rv->vsum : (long)mine.over_tight;
         if (Lr > 0) {
             eagle_cert_info hd;
-            rc = eagle_dev_cert_select_b(ctx, Lr, ctx->d_a, ctx->d_vara, ctx->d_bound, cert, glb, ws, ctx->stream);
+            rc = eagle_dev_cert_select_b(ctx, Lr, ctx->d_a, ctx->d_vara, ctx->d_bound, cert, glb, over_tight_all, ws, ctx->stream);
             if (!rc) {
                 e = hipMemcpyAsync(&hd, cert, sizeof hd, hipMemcpyDeviceToHost, ctx->stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1693,6 +1699,7 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
         }
     }
 #undef EAGLE_ARRIVE
+#undef EAGLE_ARRIVE2
     if (s_check_pending) {   // the deferred outcome of the verification of the cached S (nothing of the caller's S may be in flight past here)
         e = hipStreamSynchronize(ctx->load_stream);
         if (e != hipSuccess && !rc) rc = eagle_fail_hip(ctx, e, "verification of the cached S");
@@ -1722,20 +1729,23 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
     }
     ctx->scan_L = Lr;
     ctx->scan_first = m0;
-    long totals[3] = {0, 0, 0};
+    long totals[4] = {0, 0, 0, 0};
     if (Lr > 0) {
         HIPCHK(ctx, hipMemcpyAsync(a_out + m0, ctx->d_a, sizeof(double) * (size_t)Lr, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(vara_out + m0, ctx->d_vara, sizeof(double) * (size_t)Lr, hipMemcpyDeviceToHost, ctx->stream));
     }
     HIPCHK(ctx, hipMemcpyAsync(totals, cert_totals, sizeof totals, hipMemcpyDeviceToHost, ctx->stream));
     struct { double maxabs_off; int S, pad; double bound, sumdiag, R, specH; int S_sliced, pad2; double budget; int e, pad3; unsigned long long lo_sumsq;
-             int maxdiag, hi_overflow, spec_try2, level; double wErr; } vh = {};   // head of the digit workspace (VaraHdr)
+             int maxdiag, hi_overflow, spec_try2, level; double wErr, specH1, budget_loose; } vh = {};   // head of the digit workspace (VaraHdr)
     if (use_i8 && Lr > 0) HIPCHK(ctx, hipMemcpyAsync(&vh, ws, sizeof vh, hipMemcpyDeviceToHost, ctx->stream));
     ph.mark(ctx->stream, PH_D2H);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->cert_reevaluated = totals[0]; ctx->cert_flagged = totals[1]; ctx->cert_fell_back = totals[2] != 0;
     ctx->scan_digits_used = vh.S; ctx->scan_digits_cut = vh.S_sliced; ctx->scan_specH = vh.specH;
     ctx->scan_budget_used = vh.budget; ctx->scan_bound_level = vh.level; ctx->scan_w_err = vh.wErr;
+    // (one resident block counted on the device; blocks / shards: the sum the devices exchanged)
+    ctx->cert_over_tight = bounds_flow ? over_tight_all : totals[3];
+    ctx->scan_budget_enforced = ctx->cert_over_tight > eagle_cert_tight_max() ? vh.budget_loose : vh.budget;
     // a scan that took a digit off under the spectral bound and then had to redo a block in fp64: markers of this data set sit
     // outside what the bound covers -- this context keeps the worst-case digit count from now on (eagle_set_scan_budget re-arms)
     if (ctx->cert_fell_back && vh.specH > 0.0) ctx->spectral_off = true;
@@ -1877,6 +1887,12 @@ extern "C" int eagle_last_scan_budget(eagle_ctx* ctx, double* budget_used, int* 
     if (budget_used) *budget_used = ctx->scan_budget_used;
     if (bound_level) *bound_level = ctx->scan_bound_level;
     if (w_error_bound) *w_error_bound = ctx->scan_w_err;
+    return EAGLE_OK;
+}
+extern "C" int eagle_last_scan_enforced(eagle_ctx* ctx, double* budget_enforced, long* n_over_tight) {
+    if (!ctx) return EAGLE_ERR_ARG;
+    if (budget_enforced) *budget_enforced = ctx->scan_budget_enforced;
+    if (n_over_tight) *n_over_tight = ctx->cert_over_tight;
     return EAGLE_OK;
 }
 extern "C" int eagle_set_w_mode(eagle_ctx* ctx, int mode) {

@@ -56,6 +56,7 @@ struct eagle_ctx {
     int scan_stochastic = 0;  // 1 = digits of W rounded at random (unbiased): probabilistic certificate, one digit fewer (opt-in)
     double scan_budget = 5e-7;  // relative digit budget of the int8 scan (eagle_set_scan_budget): half of the path's 1e-6 tolerance
     double scan_budget_tight = 1e-7;  // tried first (round 4): the budget in force is this one whenever the digits that run certify it too; eagle_set_scan_budget sets both
+    double scan_budget_enforced = 0.0; long cert_over_tight = 0;   // (eagle_last_scan_enforced)
     double scan_budget_used = 0.0; int scan_bound_level = 0; double scan_w_err = 0.0;   // of the last digit-slice scan (eagle_last_scan_budget)
     bool spectral_off = false;  // a scan that took a digit off under the spectral bound fell back to fp64: this context stops trying
     std::vector<GenoEntry> cache;

@@ -26,7 +26,7 @@
 // ------------------------------------------------------------------------------------------------
 enum : size_t {
     EAGLE_SCR_SYM = 0,             // int[2]: k_sym_check's verdict on S and V                      (eagle_kernels.hip)
-    EAGLE_SCR_CERT_TOTALS = 256,   // long[3]: certification counters summed over marker blocks      (eagle_api.cpp scan_range)
+    EAGLE_SCR_CERT_TOTALS = 256,   // long[4]: certification counters summed over marker blocks      (eagle_api.cpp scan_range)
     EAGLE_SCR_INGEST = 512,        // u64[2]: first third-allele / first missing position; double: trace  (eagle_ingest.cpp, eagle_linalg.cpp)
     EAGLE_SCR_LOADER_BAD = 1024,   // int: invalid characters / codes seen by the tile loaders       (eagle_api.cpp, any stream)
     EAGLE_SCR_SCACHE_FLAG = 2048,  // int: cached S differs from the caller's                        (eagle_api.cpp, load stream)
@@ -34,7 +34,7 @@ enum : size_t {
     EAGLE_SCR_BYTES = 8192
 };
 static_assert(EAGLE_SCR_SYM + 2 * sizeof(int) <= EAGLE_SCR_CERT_TOTALS, "scratch overlap");
-static_assert(EAGLE_SCR_CERT_TOTALS + 3 * sizeof(long) <= EAGLE_SCR_INGEST, "scratch overlap");
+static_assert(EAGLE_SCR_CERT_TOTALS + 4 * sizeof(long) <= EAGLE_SCR_INGEST, "scratch overlap");
 static_assert(EAGLE_SCR_INGEST + 2 * sizeof(unsigned long long) <= EAGLE_SCR_LOADER_BAD, "scratch overlap");
 static_assert(EAGLE_SCR_LOADER_BAD + sizeof(int) <= EAGLE_SCR_SCACHE_FLAG, "scratch overlap");
 static_assert(EAGLE_SCR_SCACHE_FLAG + sizeof(int) <= EAGLE_SCR_DOT_PARTIALS, "scratch overlap");
@@ -43,7 +43,7 @@ static_assert(EAGLE_SCR_DOT_PARTIALS + 256 * sizeof(double) <= EAGLE_SCR_BYTES, 
 // ------------------------------------------------------------------------------------------------
 // Meeting point of the per-device worker threads of one multi-device call.  arrive(ok, v) blocks until every device has
 // arrived and returns the outcome OF THAT ROUND: false if any device had reported a failure by the time the round completed
-// (then nobody enters the collective that follows); the largest v of the round is left in `vmax`.  Every worker calls it the
+// (then nobody enters the collective that follows); the largest v of the round is left in `vmax`, the sum of the `add`s in `vsum`.  Every worker calls it the
 // same number of times, failed or not.  The outcome is latched per round by the last arriver: a device that leaves round k
 // and fails before a slower peer has woken up from round k can only influence round k + 1 -- the peer still sees round k's
 // verdict, makes its own round k + 1 arrival, and both leave round k + 1 with `false` (a sticky flag read after the wake-up
@@ -57,13 +57,15 @@ struct Rendezvous {
     long gen = 0;
     bool failed = false, round_failed = false;
     double acc = -HUGE_VAL, vmax = -HUGE_VAL;
-    bool arrive(bool ok, double v = -HUGE_VAL) {
+    long sacc = 0, vsum = 0;
+    bool arrive(bool ok, double v = -HUGE_VAL, long add = 0) {
         std::unique_lock<std::mutex> lk(mu);
         if (!ok) failed = true;
         if (v == v && v > acc) acc = v;
+        sacc += add;
         const long g = gen;
         if (++waiting == n) {
-            waiting = 0; vmax = acc; acc = -HUGE_VAL; round_failed = failed; gen++;
+            waiting = 0; vmax = acc; acc = -HUGE_VAL; vsum = sacc; sacc = 0; round_failed = failed; gen++;
             cv.notify_all();
         } else {
             cv.wait(lk, [&] { return gen != g; });

@@ -198,6 +198,9 @@ struct VaraHdr {        // head of the workspace, written on the device, never r
     // scan -- the tight one if the digits that run certify a marker with q2 = n_pad to it, else the default; specH1 = level 1's bound while
     // level 2 is being tried
     double specH1;
+    // the default budget behind a tight one in force (= budget otherwise): what the certificate ENFORCES per marker falls back to it when
+    // more than CERT_TIGHT_MAX markers of the scan miss the tight threshold (see k_cert_select)
+    double budget_loose;
 };
 __global__ __launch_bounds__(256) void k_absmax_offdiag(const double* __restrict__ x, long np, unsigned long long* __restrict__ bits) {
     double m = 0.0;
@@ -278,6 +281,7 @@ __global__ __launch_bounds__(256) void k_vara_prep(const double* __restrict__ Wu
                        (stochastic ? VARA_HOEFFDING_K * (double)n_pad * ldexp(1.0, e + 1 - 8 * S) : ldexp(nn, e + 1 - 8 * S)) + wErr * (double)n_pad <= tight * 0.5 * red[0])
                           ? tight : budget;
         hdr->specH1 = 0.0;
+        hdr->budget_loose = budget;
         hdr->wErr = wErr;
         hdr->e = e;
         hdr->pad = stochastic;
@@ -1293,9 +1297,16 @@ __global__ __launch_bounds__(256) void k_vara_i8_finish(const long long* __restr
 // fp64 kernel (device-side gate, no host round trip).
 // ------------------------------------------------------------------------------------------------
 #define CERT_CAP 2048
-struct CertHdr { unsigned long long lb_bits; int count; int overflow; int flagged; int pad; };  // = eagle_cert_info of the public header
+// Round 4, two-tier enforcement.  With the tight budget in force (1e-7) the per-marker threshold is 1.8e-7 |vara_i|.  Operands of a
+// structured population leave thousands of markers whose quadratic form cancels against its diagonal term between the two thresholds:
+// re-evaluating them all would overflow CERT_CAP and throw the whole scan back to fp64 for nothing (they are inside the path's tolerance
+// under the default budget).  So the markers over the TIGHT threshold are counted over the whole scan first (every block, every device:
+// the decision does not depend on how the markers were cut up); more than CERT_TIGHT_MAX of them and the certificate enforces the
+// default budget (1.8 x 5e-7 = 0.9 of the tolerance, round 3's rule), else the tight one.  eagle_cert_info.over_tight reports the count.
+#define CERT_TIGHT_MAX 512
+struct CertHdr { unsigned long long lb_bits; int count; int overflow; int flagged; int tight; };  // = eagle_cert_info of the public header
 
-struct CertCtx { double delta, absR, sumdiag, specH, flag_rel, wErr; int stochastic; };
+struct CertCtx { double delta, absR, sumdiag, specH, flag_rel, flag_loose, wErr; int stochastic; };
 __device__ __forceinline__ CertCtx cert_ctx(const VaraHdr* hdr) {
     CertCtx c;
     const double mx = hdr->maxabs_off;
@@ -1306,6 +1317,7 @@ __device__ __forceinline__ CertCtx cert_ctx(const VaraHdr* hdr) {
     if (c.specH > 0.0) c.delta *= 1.0 + 0x1p-8;   // the leading S digits of an (S+1)-digit rounding: |R_jk| <= (128 + 1/2) u
     c.absR = fabs(hdr->R);
     c.flag_rel = VARA_FLAG_FACTOR * hdr->budget;
+    c.flag_loose = VARA_FLAG_FACTOR * hdr->budget_loose;
     c.sumdiag = hdr->sumdiag;
     c.stochastic = hdr->pad;
     return c;
@@ -1332,17 +1344,21 @@ __global__ __launch_bounds__(256) void k_cert_lb(const double* __restrict__ a, c
                                                  const VaraHdr* __restrict__ hdr, CertHdr* __restrict__ ch, const unsigned char* __restrict__ xflag) {
     const CertCtx cc = cert_ctx(hdr);
     double best = 0.0;
+    int nt = 0;   // markers over the tight threshold (CERT_TIGHT_MAX)
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L; i += (long)gridDim.x * 256) {
         const double x = a[i], v = vara[i];
         if (!(isfinite(x) && isfinite(v))) continue;
-        const double up = v + cert_bound(cc, l1, i, cshift[i], vdiag[i], mrho[i], v, xflag ? xflag[i] : 0);
+        const double b = cert_bound(cc, l1, i, cshift[i], vdiag[i], mrho[i], v, xflag ? xflag[i] : 0);
+        nt += b > cc.flag_rel * fabs(v);
+        const double up = v + b;
         if (!(up > 0.0)) continue;
         const double lb = (x * x) / up;
         best = lb > best ? lb : best;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_down(best, o); best = y > best ? y : best; }
+    for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_down(best, o); best = y > best ? y : best; nt += __shfl_down(nt, o); }
     if ((threadIdx.x & 63) == 0 && best > 0.0 && isfinite(best)) atomicMax(&ch->lb_bits, (unsigned long long)__double_as_longlong(best));
+    if ((threadIdx.x & 63) == 0 && nt) atomicAdd(&ch->tight, nt);
 }
 __global__ __launch_bounds__(256) void k_cert_select(const double* __restrict__ a, const double* __restrict__ vara, long L,
                                                      const int32_t* __restrict__ l1, const int8_t* __restrict__ cshift,
@@ -1354,11 +1370,12 @@ __global__ __launch_bounds__(256) void k_cert_select(const double* __restrict__ 
     // so that every device selects exactly the candidates a single-device scan of the whole file selects
     const double lb = lb_override == lb_override ? lb_override : __longlong_as_double((long long)ch->lb_bits);
     const double thr = lb * (1.0 - 1e-9);
+    const double flag_rel = ch->tight > CERT_TIGHT_MAX ? cc.flag_loose : cc.flag_rel;   // (k_cert_lb counted; nobody writes it here)
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L; i += (long)gridDim.x * 256) {
         const double x = a[i], v = vara[i];
         if (!(isfinite(x) && isfinite(v))) continue;  // NaN / Inf operands: the fp64 kernel gives the same
         const double b = cert_bound(cc, l1, i, cshift[i], vdiag[i], mrho[i], v, xflag ? xflag[i] : 0);
-        const bool flagged = b > cc.flag_rel * fabs(v);
+        const bool flagged = b > flag_rel * fabs(v);
         const double den = v - b;
         const bool cand = !(den > 0.0) || (x * x) / den >= thr;
         if (flagged) atomicAdd(&ch->flagged, 1);
@@ -1383,11 +1400,12 @@ __global__ __launch_bounds__(256) void k_cert_gather(const int8_t* __restrict__ 
     }
 }
 
-// totals[0..2] += {re-evaluated rows, flagged rows, overflow} of one certification (streamed files certify per marker block)
+// totals[0..3] += {re-evaluated rows, flagged rows, overflow, rows over the tight threshold} of one certification
 __global__ void k_cert_accumulate(const CertHdr* __restrict__ ch, long* __restrict__ totals) {
     totals[0] += ch->count < CERT_CAP ? ch->count : CERT_CAP;
     totals[1] += ch->flagged;
     totals[2] += ch->overflow;
+    totals[3] += ch->tight;
 }
 extern "C" int eagle_dev_cert_accumulate(eagle_ctx* ctx, const void* cert_ws, long* totals_dev, void* stream) {
     hipLaunchKernelGGL(k_cert_accumulate, dim3(1), dim3(1), 0, (hipStream_t)stream, (const CertHdr*)cert_ws, totals_dev);
@@ -1452,7 +1470,7 @@ extern "C" int eagle_dev_scan_certify_apply(eagle_ctx* ctx, const int8_t* Mt8, l
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "scan_certify");
     if (ctx->w8_active && ctx->w8_Wu == Wu) {
-        // W from the int8 engine carries its own error: the candidates are re-evaluated against the TRUE W, (S m)^T V (S m) in fp64
+        // W from the int8 engine carries its own error: the candidates are re-evaluated against the TRUE W, m^T (S (V (S m))) in fp64
         // (the host reads the count: one small round trip); an overflowing certificate first replaces W by the fp64 products
         CertHdr h;
         e = hipMemcpyAsync(&h, ch, sizeof h, hipMemcpyDeviceToHost, s);
@@ -1498,24 +1516,29 @@ __global__ __launch_bounds__(256) void k_cert_bounds(const double* __restrict__ 
         bound[i] = cert_bound(cc, l1, i, cshift[i], vdiag[i], mrho[i], vara[i], xflag ? xflag[i] : 0);
 }
 __global__ __launch_bounds__(256) void k_cert_lb_b(const double* __restrict__ a, const double* __restrict__ vara, const double* __restrict__ bound,
-                                                   long L, CertHdr* __restrict__ ch) {
+                                                   long L, CertHdr* __restrict__ ch, const VaraHdr* __restrict__ hdr) {
     double best = 0.0;
+    const double flag_tight = VARA_FLAG_FACTOR * hdr->budget;
+    int nt = 0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L; i += (long)gridDim.x * 256) {
         const double x = a[i], v = vara[i];
         if (!(isfinite(x) && isfinite(v))) continue;
+        nt += bound[i] > flag_tight * fabs(v);
         const double up = v + bound[i];
         if (!(up > 0.0)) continue;
         const double lb = (x * x) / up;
         best = lb > best ? lb : best;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_down(best, o); best = y > best ? y : best; }
+    for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_down(best, o); best = y > best ? y : best; nt += __shfl_down(nt, o); }
     if ((threadIdx.x & 63) == 0 && best > 0.0 && isfinite(best)) atomicMax(&ch->lb_bits, (unsigned long long)__double_as_longlong(best));
+    if ((threadIdx.x & 63) == 0 && nt) atomicAdd(&ch->tight, nt);
 }
 __global__ __launch_bounds__(256) void k_cert_select_b(const double* __restrict__ a, const double* __restrict__ vara, const double* __restrict__ bound,
-                                                       long L, CertHdr* __restrict__ ch, long* __restrict__ idx, double lb, double flag_rel_default,
+                                                       long L, CertHdr* __restrict__ ch, long* __restrict__ idx, double lb, int loose,
                                                        const VaraHdr* __restrict__ hdr) {
-    const double flag_rel = hdr ? VARA_FLAG_FACTOR * hdr->budget : flag_rel_default;   // the budget in force for this scan
+    // the budget in force for this scan, or the default behind it (`loose`: more than CERT_TIGHT_MAX markers of the WHOLE scan over the tight one)
+    const double flag_rel = VARA_FLAG_FACTOR * (loose ? hdr->budget_loose : hdr->budget);
     const double thr = lb * (1.0 - 1e-9);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L; i += (long)gridDim.x * 256) {
         const double x = a[i], v = vara[i];
@@ -1550,28 +1573,31 @@ extern "C" int eagle_dev_cert_bounds(eagle_ctx* ctx, long L, long L_pad, long n_
     return EAGLE_OK;
 }
 // head of cert_ws zeroed, then eagle_cert_info.lower_bound = max_i a_i^2 / (vara_i + bound_i) over the L markers (0: none positive)
-extern "C" int eagle_dev_cert_lb_b(eagle_ctx* ctx, long L, const double* a, const double* vara, const double* bound, void* cert_ws, void* stream) {
-    if (L < 0 || !cert_ws) return eagle_fail(ctx, EAGLE_ERR_ARG, "cert_lb_b: bad arguments");
+extern "C" int eagle_dev_cert_lb_b(eagle_ctx* ctx, long L, const double* a, const double* vara, const double* bound, void* cert_ws,
+                                   const void* vara_ws, void* stream) {
+    if (L < 0 || !cert_ws || !vara_ws) return eagle_fail(ctx, EAGLE_ERR_ARG, "cert_lb_b: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(cert_ws, 0, 256, s);
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "cert_lb_b memset");
     if (L == 0) return EAGLE_OK;
     unsigned blocks = (unsigned)((L + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_cert_lb_b, dim3(blocks), dim3(256), 0, s, a, vara, bound, L, (CertHdr*)cert_ws);
+    hipLaunchKernelGGL(k_cert_lb_b, dim3(blocks), dim3(256), 0, s, a, vara, bound, L, (CertHdr*)cert_ws, (const VaraHdr*)vara_ws);
     e = hipGetLastError();
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "k_cert_lb_b");
     return EAGLE_OK;
 }
-// candidates against `lb` into the index list of cert_ws (count / flagged / overflow in its head, which eagle_dev_cert_lb_b zeroed)
+// candidates against `lb` into the index list of cert_ws (count / flagged / overflow in its head, which eagle_dev_cert_lb_b zeroed);
+// over_tight: markers of the whole scan over the tight threshold (the sum of eagle_cert_info.over_tight over blocks and devices)
+extern "C" int eagle_cert_tight_max(void) { return CERT_TIGHT_MAX; }
 extern "C" int eagle_dev_cert_select_b(eagle_ctx* ctx, long L, const double* a, const double* vara, const double* bound, void* cert_ws, double lb,
-                                       const void* vara_ws, void* stream) {
-    if (L < 0 || !cert_ws) return eagle_fail(ctx, EAGLE_ERR_ARG, "cert_select_b: bad arguments");
+                                       long over_tight, const void* vara_ws, void* stream) {
+    if (L < 0 || !cert_ws || !vara_ws) return eagle_fail(ctx, EAGLE_ERR_ARG, "cert_select_b: bad arguments");
     if (L == 0) return EAGLE_OK;
     unsigned blocks = (unsigned)((L + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_cert_select_b, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, vara, bound, L, (CertHdr*)cert_ws,
-                       (long*)((char*)cert_ws + cert_idx_off()), lb, VARA_FLAG_FACTOR * ctx->scan_budget, (const VaraHdr*)vara_ws);
+                       (long*)((char*)cert_ws + cert_idx_off()), lb, over_tight > CERT_TIGHT_MAX ? 1 : 0, (const VaraHdr*)vara_ws);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return eagle_fail_hip(ctx, e, "k_cert_select_b");
     return EAGLE_OK;

@@ -57,9 +57,11 @@ int eagle_dev_cert_accumulate(eagle_ctx* ctx, const void* cert_ws, long* totals_
 // certification of a scan cut into marker blocks / device shards against ONE lower bound (eagle_i8mfma.hip, "The same certification ...")
 int eagle_dev_cert_bounds(eagle_ctx* ctx, long L, long L_pad, long n_pad, const int8_t* cshift, const int32_t* l1norm, int nslices,
                           const void* vara_ws, const double* vara, double* bound, void* stream);
-int eagle_dev_cert_lb_b(eagle_ctx* ctx, long L, const double* a, const double* vara, const double* bound, void* cert_ws, void* stream);
+int eagle_dev_cert_lb_b(eagle_ctx* ctx, long L, const double* a, const double* vara, const double* bound, void* cert_ws, const void* vara_ws,
+                        void* stream);
+int eagle_cert_tight_max(void);
 int eagle_dev_cert_select_b(eagle_ctx* ctx, long L, const double* a, const double* vara, const double* bound, void* cert_ws, double lb,
-                            const void* vara_ws, void* stream);
+                            long over_tight, const void* vara_ws, void* stream);
 int8_t* eagle_cert_rows(void* cert_ws);
 long* eagle_cert_indices(void* cert_ws);
 int eagle_dev_cert_reevaluate(eagle_ctx* ctx, const int8_t* Mt8, long ld, long n_pad, const double* Wu, double* vara, void* cert_ws, void* stream);

@@ -27,7 +27,7 @@
 // configurations does (wild scaling, cancelling V, non-finite or visibly asymmetric operands) the call DECLINES and the caller runs the
 // fp64 GEMM as before.  Terms that must not carry eta_W at all are taken from elsewhere: the correction vector of the re-centred
 // markers from r = S (V (S 1)) (three fp64 matrix-vector products), and the markers the certificate re-evaluates from
-// (S m)^T V (S m) in fp64 (k_w8_mgemv below) -- so the selected marker is still decided on fp64 values.
+// m^T (S (V (S m))) in fp64 (k_w8_mgemv below) -- so the selected marker is still decided on fp64 values.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -482,45 +482,75 @@ extern "C" int eagle_w8_rho(eagle_ctx* ctx, const double* Wu, long n_pad, double
 }
 
 // ------------------------------------------------------------------------------------------------
-// Re-evaluation of single markers against the TRUE W: vara = (S m)^T V (S m) in fp64, 16 markers per pass over a matrix.
-//   out[c][i] = sum_j At[j][i] x[c][j]  (At = row-major image of A^T: out_c = A x_c).  Every (c, i) is summed in a fixed order
-//   (wave w takes j = w, w+4, ..., then the four partial sums in order), whatever else is in the batch.
+// Re-evaluation of single markers against the TRUE W: vara = m^T (S (V (S m))) in fp64, 16 or 64 markers per pass over a matrix.
+//   out[c][i] = sum_j At[j][i] x[c][j]  (At = row-major image of A^T: out_c = A x_c) on the fp64 MFMA (v_mfma_f64_16x16x4_f64: 16 markers
+//   x 16 columns x 4 j per instruction).  Every (c, i) is summed in a fixed order whatever else is in the batch and whichever row of a
+//   tile the marker sits in: the j range is cut into W8_JS parts, inside a part wave w takes the groups of four j number w, w + 4, ...
+//   in ascending order, then (w0 + w1) + (w2 + w3), then the parts in order (k_w8_mgemv_sum).  A structured panel sends hundreds of
+//   markers here (tests/test_gpu_structure.py): 64 of them share one read of the matrix; a headline scan sends one or two.
 // ------------------------------------------------------------------------------------------------
-#define W8_MG 8
+#define W8_MG 16    // markers per pass, a handful of candidates (one MFMA row tile)
+#define W8_MGL 64   // ... many candidates (four row tiles)
 #define W8_JS 16
 #define W8_TRUE_CHUNK 256
-// part[js][c][i] = sum over the js-th sixteenth of j of At[j][i] x[c][j]
+typedef double w8_f64x4 __attribute__((ext_vector_type(4)));
+// part[js][c][i] for the 64 columns i of blockIdx.z, the MT * 16 markers of blockIdx.x, the js-th part of j (blockIdx.y)
+template <int MT>
 __global__ __launch_bounds__(256) void k_w8_mgemv_part(const double* __restrict__ At, long n, long np, const double* __restrict__ X, double* __restrict__ part,
                                                        int capr) {
-    const int c0 = blockIdx.z * W8_MG, js = blockIdx.y;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const long i = (long)blockIdx.x * 64 + lane;
+    const int c0 = blockIdx.x * (MT * 16), js = blockIdx.y;
+    const long i0 = (long)blockIdx.z * 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i16 = lane & 15, g = lane >> 4;
+    const long n4 = (n + 3) / 4 * 4;   // (rows n .. np of the images and columns n .. np of x are zero)
     const long per = ((n + W8_JS - 1) / W8_JS + 3) / 4 * 4;
-    const long ja = (long)js * per, jb = ja + per < n ? ja + per : n;
-    __shared__ double xs[W8_MG][256];
-    __shared__ double red[4][W8_MG][64];
-    double acc[W8_MG];
+    const long ja = (long)js * per, jb = ja + per < n4 ? ja + per : n4;
+    w8_f64x4 acc[MT][4];
 #pragma unroll
-    for (int c = 0; c < W8_MG; c++) acc[c] = 0.0;
-    for (long j0 = ja; j0 < jb; j0 += 256) {
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[m][q] = (w8_f64x4){0.0, 0.0, 0.0, 0.0};
+    // operand maps of the instruction: A lane (i16, g) = x[marker i16][j + g], B lane (i16, g) = At[j + g][column i16]
+    const double* xa = X + (long)(c0 + i16) * np + g;
+    const double* bt = At + (long)g * np + i0 + i16;
+    // (the operands of the next group are in flight while this one multiplies)
+    double a[MT], b[4];
+    long j = ja + 4 * w;
+    if (j < jb) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) b[q] = bt[j * np + 16 * q];
+#pragma unroll
+        for (int m = 0; m < MT; m++) a[m] = xa[(long)m * 16 * np + j];
+    }
+    for (; j < jb; j += 16) {
+        double an[MT], bn[4];
+        const long jn = j + 16 < jb ? j + 16 : j;   // (the last group loads itself again: no branch around the loads)
+#pragma unroll
+        for (int q = 0; q < 4; q++) bn[q] = bt[jn * np + 16 * q];
+#pragma unroll
+        for (int m = 0; m < MT; m++) an[m] = xa[(long)m * 16 * np + jn];
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc[m][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[q], acc[m][q], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) b[q] = bn[q];
+#pragma unroll
+        for (int m = 0; m < MT; m++) a[m] = an[m];
+    }
+    // the four waves' tiles, one row tile at a time: C/D map row = g + 4 r, column = i16
+    __shared__ double sm[4][4][256];   // [wave][column tile][lane * 4 + r]: 32 KiB
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < W8_MG; c++) xs[c][threadIdx.x] = j0 + threadIdx.x < jb ? X[(long)(c0 + c) * np + j0 + threadIdx.x] : 0.0;
+        for (int q = 0; q < 4; q++) *(w8_f64x4*)&sm[w][q][lane * 4] = acc[m][q];
         __syncthreads();
-        const long jend = jb - j0 < 256 ? jb - j0 : 256;
-        for (long jj = w; jj < jend; jj += 4) {
-            const double a = At[(j0 + jj) * np + i];
-#pragma unroll
-            for (int c = 0; c < W8_MG; c++) acc[c] += a * xs[c][jj];
+        for (int e = threadIdx.x; e < 1024; e += 256) {   // e = row * 64 + column of the 16 x 64 block
+            const int row = e >> 6, col = e & 63, q = col >> 4;
+            const int k = (((row & 3) << 4) | (col & 15)) * 4 + (row >> 2);   // lane (g = row % 4, i16 = col % 16), register row / 4
+            part[((long)js * capr + c0 + m * 16 + row) * np + i0 + col] = (sm[0][q][k] + sm[1][q][k]) + (sm[2][q][k] + sm[3][q][k]);
         }
     }
-#pragma unroll
-    for (int c = 0; c < W8_MG; c++) red[w][c][lane] = acc[c];
-    __syncthreads();
-    if (w == 0)
-#pragma unroll
-        for (int c = 0; c < W8_MG; c++)
-            part[((long)js * capr + c0 + c) * np + i] = (red[0][c][lane] + red[1][c][lane]) + (red[2][c][lane] + red[3][c][lane]);
 }
 __global__ __launch_bounds__(256) void k_w8_mgemv_sum(const double* __restrict__ part, long np, int capr, double* __restrict__ out) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -529,37 +559,6 @@ __global__ __launch_bounds__(256) void k_w8_mgemv_sum(const double* __restrict__
     double s = 0.0;
     for (int js = 0; js < W8_JS; js++) s += part[((long)js * capr + c) * np + i];
     out[(long)c * np + i] = s;
-}
-// The transposed product: out[c][i] = sum_j At[i][j] x[c][j] (a wave takes four rows i, lanes strided over j, fixed order)
-__global__ __launch_bounds__(256) void k_w8_mgemv_row(const double* __restrict__ At, long n, long np, const double* __restrict__ X, double* __restrict__ out) {
-    const int c0 = blockIdx.y * W8_MG;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const long i0 = (long)blockIdx.x * 16 + w * 4;
-    double acc[4][W8_MG];
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int c = 0; c < W8_MG; c++) acc[q][c] = 0.0;
-    for (long j = lane; j < n; j += 64) {
-        double x[W8_MG], a[4];
-#pragma unroll
-        for (int c = 0; c < W8_MG; c++) x[c] = X[(long)(c0 + c) * np + j];
-#pragma unroll
-        for (int q = 0; q < 4; q++) a[q] = At[(i0 + q) * np + j];   // (rows beyond n are zero padding)
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-#pragma unroll
-            for (int c = 0; c < W8_MG; c++) acc[q][c] += a[q] * x[c];
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int c = 0; c < W8_MG; c++) {
-            double v = acc[q][c];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-            if (lane == 0) out[(long)(c0 + c) * np + i0 + q] = v;
-        }
 }
 // x[c][j] = (double) rows8[c][j] for c < count, zero rows up to the next multiple of 16
 __global__ __launch_bounds__(256) void k_w8_rows_f64(const int8_t* __restrict__ rows8, long ld, long np, int count, double* __restrict__ X) {
@@ -583,14 +582,14 @@ __global__ __launch_bounds__(256) void k_w8_rowdot(const double* __restrict__ T,
     if (threadIdx.x == 0) out[dst ? dst[c] : c] = red[0];
 }
 
-// out[dst[c]] = m_c^T S V S m_c = (S^T m_c)^T V (S m_c) for the `count` rows of rows8 (host count), 256 rows at a time through a
-// ctx-owned buffer (images: S m = Sa^T m is the column-type product, S^T m = Sa m the row-type one).
+// out[dst[c]] = m_c^T S V S m_c = m_c^T (S (V (S m_c))) for the `count` rows of rows8 (host count), 256 rows at a time through a ctx-owned
+// buffer: three products of the same kind (the image Sa is the row-major S^T: out_c = S x_c sums Sa[j][i] x[c][j] over j), then m . r.
 // S, V: the operands of the last eagle_dev_scan_operands_w8 (still alive: it is the caller's scan).
 extern "C" int eagle_w8_true_vara(eagle_ctx* ctx, const int8_t* rows8, long count, long n_pad, long ld, const long* dst_dev, double* out, void* stream) {
     if (!ctx->w8_Sa || !ctx->w8_Va || ctx->w8_n <= 0) return eagle_fail(ctx, EAGLE_ERR_ARG, "w8_true_vara: no operands on record");
     if (count <= 0) return EAGLE_OK;
     hipStream_t s = (hipStream_t)stream;
-    const size_t need = (size_t)(4 + W8_JS) * W8_TRUE_CHUNK * n_pad * sizeof(double);
+    const size_t need = (size_t)(3 + W8_JS) * W8_TRUE_CHUNK * n_pad * sizeof(double);
     if (need > ctx->w8_true_cap) {
         if (ctx->w8_true_ws) { (void)hipStreamSynchronize(s); (void)hipFree(ctx->w8_true_ws); ctx->w8_true_ws = nullptr; ctx->w8_true_cap = 0; }
         hipError_t e = hipMalloc(&ctx->w8_true_ws, need);
@@ -600,20 +599,26 @@ extern "C" int eagle_w8_true_vara(eagle_ctx* ctx, const int8_t* rows8, long coun
     double* X = (double*)ctx->w8_true_ws;
     double* T = X + (size_t)W8_TRUE_CHUNK * n_pad;
     double* U = T + (size_t)W8_TRUE_CHUNK * n_pad;
-    double* Tt = U + (size_t)W8_TRUE_CHUNK * n_pad;
-    double* part = Tt + (size_t)W8_TRUE_CHUNK * n_pad;
+    double* part = U + (size_t)W8_TRUE_CHUNK * n_pad;
     const long n = ctx->w8_n;
     for (long c0 = 0; c0 < count; c0 += W8_TRUE_CHUNK) {
         const int cnt = (int)std::min<long>(W8_TRUE_CHUNK, count - c0);
-        const int capr = (cnt + W8_MG - 1) / W8_MG * W8_MG;
+        // a handful of candidates: one row tile of 16 per pass over the matrices; many (a structured panel flags hundreds): 64 per pass --
+        // the same bits per marker
+        const bool many = cnt > W8_MG;
+        const int mg = many ? W8_MGL : W8_MG;
+        const int capr = (cnt + mg - 1) / mg * mg;
         hipLaunchKernelGGL(k_w8_rows_f64, dim3((unsigned)((n_pad + 255) / 256), (unsigned)capr), dim3(256), 0, s, rows8 + c0 * ld, ld, n_pad, cnt, X);
-        const dim3 gp((unsigned)(n_pad / 64), W8_JS, (unsigned)(capr / W8_MG)), gs((unsigned)((n_pad + 255) / 256), (unsigned)capr);
-        hipLaunchKernelGGL(k_w8_mgemv_part, gp, dim3(256), 0, s, ctx->w8_Sa, n, n_pad, (const double*)X, part, capr);
-        hipLaunchKernelGGL(k_w8_mgemv_sum, gs, dim3(256), 0, s, (const double*)part, n_pad, capr, T);
-        hipLaunchKernelGGL(k_w8_mgemv_part, gp, dim3(256), 0, s, ctx->w8_Va, n, n_pad, (const double*)T, part, capr);
-        hipLaunchKernelGGL(k_w8_mgemv_sum, gs, dim3(256), 0, s, (const double*)part, n_pad, capr, U);
-        hipLaunchKernelGGL(k_w8_mgemv_row, dim3((unsigned)(n_pad / 16), (unsigned)(capr / W8_MG)), dim3(256), 0, s, ctx->w8_Sa, n, n_pad, (const double*)X, Tt);
-        hipLaunchKernelGGL(k_w8_rowdot, dim3((unsigned)cnt), dim3(256), 0, s, (const double*)Tt, (const double*)U, n_pad, dst_dev ? dst_dev + c0 : nullptr,
+        const dim3 gp((unsigned)(capr / mg), W8_JS, (unsigned)(n_pad / 64)), gs((unsigned)((n_pad + 255) / 256), (unsigned)capr);
+        const double* mats[3] = {ctx->w8_Sa, ctx->w8_Va, ctx->w8_Sa};      // t = S m,  u = V t,  r = S u
+        const double* src[3] = {X, T, U};
+        double* dstv[3] = {T, U, T};
+        for (int k = 0; k < 3; k++) {
+            if (many) hipLaunchKernelGGL((k_w8_mgemv_part<W8_MGL / 16>), gp, dim3(256), 0, s, mats[k], n, n_pad, src[k], part, capr);
+            else hipLaunchKernelGGL((k_w8_mgemv_part<W8_MG / 16>), gp, dim3(256), 0, s, mats[k], n, n_pad, src[k], part, capr);
+            hipLaunchKernelGGL(k_w8_mgemv_sum, gs, dim3(256), 0, s, (const double*)part, n_pad, capr, dstv[k]);
+        }
+        hipLaunchKernelGGL(k_w8_rowdot, dim3((unsigned)cnt), dim3(256), 0, s, (const double*)X, (const double*)T, n_pad, dst_dev ? dst_dev + c0 : nullptr,
                            dst_dev ? out : out + c0);
     }
     hipError_t e = hipGetLastError();

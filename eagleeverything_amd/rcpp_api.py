@@ -130,6 +130,15 @@ def last_scan_budget(device=0):
     return b.value, lv.value, we.value
 
 
+def last_scan_enforced(device=0):
+    """(budget the certificate of the last digit-slice scan enforced per marker, markers over the tight threshold): the budget in force, or
+    the default behind a tight one when more than 512 markers of the whole scan missed the tight threshold (eagle_last_scan_enforced)."""
+    ctx = context(device)
+    b, nt = C.c_double(), C.c_long()
+    _check(ctx, _lib.load().eagle_last_scan_enforced(ctx, C.byref(b), C.byref(nt)))
+    return b.value, nt.value
+
+
 def prepare_scan(n, L, device=0):
     """Start the allocation of the scan's device arena on a background thread (eagle_prepare_scan; calculateMMt_rcpp does it by itself)."""
     ctx = context(device)

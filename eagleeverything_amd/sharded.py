@@ -180,6 +180,29 @@ class DeviceShard:
             self.Mt8[lo - self.first:hi - self.first, : self.n] = g[lo - c0:hi - c0]
         self.M8 = None
 
+    def fill_structured(self, K=2, fst=0.5, seed=5, pmin=0.05, chunk=16384):
+        """Synthetic genotypes WITH population structure (Balding-Nichols): K equal sub-populations whose allele frequencies drift from a
+        common ancestral frequency by Fst.  The operands of such a panel leave many markers whose quadratic form cancels against its
+        diagonal term -- the case the certificate's two-tier threshold is for (tools/diag_structure.py, tests/test_gpu_structure.py)."""
+        torch = self.torch
+        n, L, dev = self.n, self.Lloc, self.dev
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed)
+        pop = torch.arange(n, device=dev) * K // n
+        for r0 in range(0, L, chunk):
+            r1 = min(L, r0 + chunk)
+            p0 = pmin + (1 - 2 * pmin) * torch.rand(r1 - r0, 1, generator=gen, device=dev)
+            a, b = p0 * (1 - fst) / fst, (1 - p0) * (1 - fst) / fst
+            # Beta(a, b) per (marker, population) through two gammas (torch.distributions draws from the global generator: seeded here)
+            torch.manual_seed(seed + 1000003 * (r0 // chunk + 1))
+            ga = torch.distributions.Gamma(a.expand(-1, K), 1.0).sample()
+            gb = torch.distributions.Gamma(b.expand(-1, K), 1.0).sample()
+            p = (ga / (ga + gb)).clamp(0.001, 0.999)[:, pop]          # (markers, n)
+            g = (torch.rand(p.shape, generator=gen, device=dev) < p).to(torch.int8) + (torch.rand(p.shape, generator=gen, device=dev) < p).to(torch.int8) - 1
+            self.Mt8[r0:r1, :n] = g
+        self.M8 = self.M4 = None
+        self.Mt8s = None
+
     def load_Mt_ascii(self, path, max_mem_gb=8.0, threads=8):
         """Rows [first, first+Lloc) of Mt.ascii (the shard is a contiguous byte range of the file)."""
         self.Mt8.zero_()
@@ -392,15 +415,17 @@ class DeviceShard:
                                                   self._stream()))
 
     def certificate(self):
-        """{lower_bound, reevaluated, overflow, flagged} of the last certify() (synchronises)."""
+        """{lower_bound, reevaluated, overflow, flagged, over_tight} of the last certify() (synchronises).  over_tight: markers over 1.8 x the
+        budget in force; more than 512 of them under the tight budget and `flagged` is counted against 1.8 x the default one."""
         h = self.cert_ws[:24].cpu().numpy().tobytes()
         i = np.frombuffer(h[8:24], dtype=np.int32)
         return {"lower_bound": float(np.frombuffer(h[0:8], dtype=np.float64)[0]), "reevaluated": int(min(i[0], 2048)),
-                "overflow": int(i[1]), "flagged": int(i[2])}
+                "overflow": int(i[1]), "flagged": int(i[2]), "over_tight": int(i[3])}
 
     def vara_i8_info(self):
         """(slices used, absolute error bound, max |off-diagonal W|) of the last int8-slice vara launch (synchronises)."""
-        h = self.ws[:112].cpu().numpy().tobytes()
+        h = self.ws[:120].cpu().numpy().tobytes()
+        self.last_budget_loose = float(np.frombuffer(h[112:120], dtype=np.float64)[0])   # the default behind a tight budget in force
         self.last_budget = float(np.frombuffer(h[56:64], dtype=np.float64)[0])   # the budget in force (tight one first: eagle_last_scan_budget)
         self.last_wErr = float(np.frombuffer(h[96:104], dtype=np.float64)[0])    # || W - S V S ||_F bound of a W from the int8 engine (0: fp64 products)
         self.last_level = int(np.frombuffer(h[92:96], dtype=np.int32)[0])   # which level of the spectral bound took the digit off (0: none)

@@ -106,7 +106,7 @@ int eagle_set_scan_rounding(eagle_ctx* ctx, int stochastic);
  * padded individuals up, the two n^3 products run on the int8 MFMA from exact base-256 digit slices of the off-diagonal parts of S, V
  * and X = V S (diagonal parts exactly, in fp64), under a rigorous Frobenius-norm bound eta of the error of the W delivered; the scan's
  * per-marker certificate adds eta * sum_j m'_ij^2 to its bound, the correction vector of the re-centred markers comes from
- * r = S (V (S 1)) in fp64, and the markers the certificate re-evaluates are computed as (S m)^T V (S m) in fp64.  A call whose
+ * r = S (V (S 1)) in fp64, and the markers the certificate re-evaluates are computed as m^T (S (V (S m))) in fp64.  A call whose
  * operands the configurations on offer cannot certify to 2 % of the digit budget (wild scaling, cancelling V, non-finite or visibly
  * asymmetric matrices, no workspace) DECLINES and the fp64 GEMM runs as before.  0: always the fp64 GEMM.  2: the int8 engine at any
  * size (tests).  eagle_set_scan_mode(0) never uses it.  csrc/eagle_w8.hip. */
@@ -397,8 +397,11 @@ int eagle_dev_vara_i8(eagle_ctx* ctx, const int8_t* Mt8, long L_pad, long n_pad,
  * certified arrays is then the arg-max of the fp64 scan (find_qtl.R:71-83 selects the same marker in either mode).
  * L = real markers of the block (rows beyond it are padding), L_pad / nslices / vara_ws as passed to prepare + mfma.
  * cert_ws: eagle_scan_certify_workspace_bytes(n_pad) bytes; its head is an eagle_cert_info the host may copy back.  If more
- * than 2048 markers qualify (degenerate operands) the whole block is redone in fp64 (overflow = 1). */
-typedef struct { double lower_bound; int32_t reevaluated; int32_t overflow; int32_t flagged; int32_t pad; } eagle_cert_info;
+ * than 2048 markers qualify (degenerate operands) the whole block is redone in fp64 (overflow = 1).
+ * Round 4: over_tight = markers whose bound exceeds 1.8 x the budget in force; with the tight budget (1e-7) in force and more than 512
+ * of them (structured populations: quadratic forms that cancel against their diagonal term) the certificate enforces 1.8 x the default
+ * budget (5e-7) instead -- `flagged` counts against the threshold that was enforced. */
+typedef struct { double lower_bound; int32_t reevaluated; int32_t overflow; int32_t flagged; int32_t over_tight; } eagle_cert_info;
 int64_t eagle_scan_certify_workspace_bytes(long n_pad);
 int eagle_dev_scan_certify(eagle_ctx* ctx, const int8_t* Mt8, long L, long L_pad, long n_pad, long ld, const int8_t* cshift,
                            const int32_t* l1norm, int nslices, void* vara_ws, const double* Wu, const double* a, double* vara,
@@ -425,6 +428,10 @@ int eagle_last_scan_digits(eagle_ctx* ctx, int* digits_used, int* digits_cut, do
  * the digits that run anyway certify a marker with q2 = n_pad to it (worst-case bound, or the spectral bound at level 1 / 2);
  * eagle_set_scan_budget(b) makes b the only budget, eagle_set_scan_budget(0) restores the default policy. */
 int eagle_last_scan_budget(eagle_ctx* ctx, double* budget_used, int* bound_level, double* w_error_bound);
+/* What the certificate of the last digit-slice scan ENFORCED per marker (bound <= 1.8 x budget_enforced x |vara_i|, else fp64): the
+ * budget in force, or the default behind a tight one when more than 512 markers of the whole scan (all blocks, all devices) missed the
+ * tight threshold (n_over_tight; see eagle_cert_info). */
+int eagle_last_scan_enforced(eagle_ctx* ctx, double* budget_enforced, long* n_over_tight);
 /* Round 4.  The first eagle_calculate_a_and_vara of a context allocates its device arena (four n x n fp64 images + the digit-slice and
  * certification workspaces: 100 GB at 50,000 individuals, 3-6 s of hipMalloc).  This call starts that allocation on a background
  * thread and returns at once; the scan collects it.  eagle_calculateMMt calls it by itself (AM() calls calcMMt once and then works

@@ -1,0 +1,129 @@
+"""A panel WITH population structure under the tight-first digit budget (round 4).
+
+Two sub-populations far apart (Balding-Nichols, Fst 0.5) leave thousands of markers whose quadratic form m^T W m cancels against its
+diagonal term: their digit bound sits between 1.8 x 1e-7 and 1.8 x 5e-7 of |vara_i|.  Re-evaluating all of them would overflow the
+certificate (2,048 rows) and throw the scan back to fp64 (first measured that way: 934 ms instead of 108 ms at n = 10,000).  The
+certificate therefore counts the markers over the TIGHT threshold over the whole scan first and, above 512 of them, enforces the default
+budget -- the same decision however the markers were cut into blocks or shards (csrc/eagle_i8mfma.hip CERT_TIGHT_MAX;
+find_qtl.R:71-83 must still select the fp64 scan's marker, every vara inside 0.9e-6 of the fp64 value)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N, L = 4096, 131072
+
+
+@pytest.fixture(scope="module")
+def panel():
+    import torch
+    import bench
+    from eagleeverything_amd.sharded import DeviceShard
+    sh = DeviceShard(N, L)
+    sh.fill_structured(K=2, fst=0.5, seed=5)
+    c32 = sh.mmt_partial()
+    MMt, _ = sh.mmt_finish(c32, normalise=True)
+    gen = torch.Generator(device=sh.dev)
+    gen.manual_seed(7)
+    y = torch.randn(N, generator=gen, device=sh.dev, dtype=torch.float64)
+    X = torch.ones((N, 1), dtype=torch.float64, device=sh.dev)
+    S, V, ahat, _, _ = bench.host_operands_torch(torch, MMt, X, y, 1.0, 0.5)
+    del MMt, c32
+    yield torch, sh, S.contiguous(), V.contiguous(), ahat.contiguous()
+
+
+def test_many_markers_over_the_tight_threshold_are_held_to_the_default_budget(panel):
+    torch, sh, S, V, ahat = panel
+    sh.set_operands(S, V, ahat)
+    sh.mode = 0
+    sh.scan()
+    torch.cuda.synchronize()
+    v64, best64 = sh.vara[:L].clone(), sh.best()[:2]
+    sh.mode = 1
+    sh.w_mode = 1
+    sh.scan()
+    torch.cuda.synchronize()
+    sh.vara_i8_info()
+    c = sh.certificate()
+    assert sh.last_budget == 1e-7 and sh.last_budget_loose == 5e-7            # the tight budget is in force for the digits ...
+    assert c["over_tight"] > 512 and c["overflow"] == 0                       # ... too many markers miss its threshold: not an overflow,
+    assert c["flagged"] < c["over_tight"] and c["reevaluated"] >= c["flagged"]  # the default threshold decides who is re-evaluated
+    assert sh.w_info()["int8"] == 1 and sh.w_info()["declined"] == 0          # and W stays the int8 engine's
+    # (markers fixed inside each sub-population cancel down to the fp64 noise of the diagonal term: two fp64 evaluations of the same
+    # quadratic form differ there too -- those are held to an absolute 1e-12 of the largest value instead)
+    vmax = float(v64.abs().max())
+    ok = v64.abs() > 1e-9 * vmax
+    err = (sh.vara[:L] - v64).abs()
+    assert float((err / v64.abs())[ok].max()) <= 9e-7, (float((err / v64.abs())[ok].max()), int((~ok).sum()))
+    assert float(err[~ok].max() if int((~ok).sum()) else 0.0) <= 1e-12 * vmax
+    assert sh.best()[1] == best64[1]
+    # the markers over the default threshold BEFORE the extension gave them the dropped digit back bound the flagged ones from above
+    q2, l1 = sh.l1[:L, 1].double(), sh.l1[:L, 0].double()
+    S_used = sh.vara_i8_info()[0]
+    b = 0.5 * l1 * l1 * 2.0 ** (sh.last_e + 1 - 8 * S_used)
+    if sh.last_specH > 0:
+        b = torch.minimum(sh.last_specH * q2, b)
+    assert c["flagged"] <= int((b + sh.last_wErr * q2 > 9e-7 * sh.vara[:L].abs()).sum())
+
+
+def test_reevaluation_gives_a_marker_the_same_bits_in_a_batch_of_16_or_64(panel):
+    """Hundreds of flagged markers are re-evaluated 64 per pass over S and V instead of 16 (eagle_w8_true_vara, fp64 MFMA): per marker the same sums
+    in the same order."""
+    torch, sh, S, V, ahat = panel
+    sh.set_operands(S, V, ahat)
+    sh.mode = 1
+    sh.w_mode = 1
+    sh.scan()
+    torch.cuda.synchronize()
+    assert sh.w_info()["int8"] == 1
+    f = sh.L.eagle_w8_true_vara
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p]
+    ld = sh.Mt8.stride(0)
+    out = {}
+    for cnt in (10, 40, 300):
+        o = torch.zeros(cnt, dtype=torch.float64, device=sh.dev)
+        rc = f(sh.ctx, sh.Mt8.data_ptr(), cnt, sh.np_, ld, None, o.data_ptr(), sh._stream())
+        assert rc == 0
+        torch.cuda.synchronize()
+        out[cnt] = o
+    assert torch.equal(out[40][:10], out[10]) and torch.equal(out[300][:40], out[40])
+    M = sh.Mt8[:300, :N].double()
+    W = S @ (V @ S)
+    ref = ((M @ W) * M).sum(1)
+    assert float(((out[300] - ref).abs() / ref.abs()).max()) < 1e-9
+
+
+def test_the_decision_does_not_depend_on_blocks_or_shards(panel, tmp_path):
+    """Through the C ABI: one resident block, the file streamed in marker blocks, two contexts sharing the card -- the same count over the
+    tight threshold, the same enforced budget, the same bits."""
+    torch, sh, S, V, ahat = panel
+    from eagleeverything_amd import rcpp_api as api, synth
+    geno = synth.write_geno_pair_sidecars(str(tmp_path), sh)
+    Sh, Vh, ah = S.cpu().numpy(), V.cpu().numpy(), ahat.cpu().numpy()
+    sh.release_operands()
+    try:
+        api.set_scan_mode(1)
+        r = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], np.nan, Sh, Vh, 8.0, (L, N), ah)
+        enforced, over = api.last_scan_enforced()
+        assert api.last_scan_budget()[0] == 1e-7 and enforced == 5e-7 and over > 512
+        assert api.last_scan_certificate()[2] == 0 and api.last_w_info()["int8"] == 1
+        best = api.last_scan_argmax()[:2]
+        os.environ["EAGLE_HIP_MAX_RESIDENT_GB"] = "%.6f" % (1.6 * sh.np_ * 32768 / 1e9)   # marker blocks: the file is streamed
+        api.drop_cache()
+        r2 = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], np.nan, Sh, Vh, 8.0, (L, N), ah)
+        assert api.last_stream_stats()["chunks"] > 1
+        assert api.last_scan_enforced() == (enforced, over)
+        assert np.array_equal(r2["vara"], r["vara"]) and np.array_equal(r2["a"], r["a"])
+        os.environ.pop("EAGLE_HIP_MAX_RESIDENT_GB", None)
+        api.drop_cache()
+        r3 = api.calculate_a_and_vara_rcpp(geno["asciifileMt"], np.nan, Sh, Vh, 8.0, (L, N), ah, device=(0, 0))
+        assert api.last_scan_enforced(device=(0, 0)) == (enforced, over)
+        assert np.array_equal(r3["vara"], r["vara"]) and np.array_equal(r3["a"], r["a"])
+        assert api.last_scan_argmax(device=(0, 0))[:2] == best
+    finally:
+        os.environ.pop("EAGLE_HIP_MAX_RESIDENT_GB", None)
+        api.close_all()

@@ -106,7 +106,7 @@ def test_scan_on_the_int8_w_returns_the_fp64_scan():
         rel = ((res[wm][0] - v64).abs() / v64.abs()).max()
         assert float(rel) <= 1e-7, (wm, float(rel))                     # measured ~1e-9: the enforced ceiling is 9e-7
         assert res[wm][3]["overflow"] == 0
-    # the marker the certificate re-evaluated carries m^T S V S m in fp64 ((S^T m)^T V (S m), not a value read off the int8 W)
+    # the marker the certificate re-evaluated carries m^T S V S m in fp64 (m^T (S (V (S m))), not a value read off the int8 W)
     i = res[2][2][1]
     m = sh.Mt8[i, :sh.n].double()
     true = float((S.T @ m) @ (V @ (S @ m)))

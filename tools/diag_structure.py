@@ -17,21 +17,7 @@ args = bench.parse_args(["--n", str(n), "--markers", str(L)])
 run = bench.Run(args, torch, None, Collectives(None), n, L, 0, 1, 0, "none")
 sh = run.sh
 dev = sh.dev
-gen = torch.Generator(device=dev); gen.manual_seed(5)
-pop = torch.arange(n, device=dev) * K // n
-for r0 in range(0, L, 16384):
-    r1 = min(L, r0 + 16384)
-    p0 = PMIN + (1 - 2 * PMIN) * torch.rand(r1 - r0, 1, generator=gen, device=dev)
-    a, b = p0 * (1 - fst) / fst, (1 - p0) * (1 - fst) / fst
-    # Beta(a, b) per (marker, population) through two gammas
-    ga = torch.distributions.Gamma(a.expand(-1, K), 1.0).sample()
-    gb = torch.distributions.Gamma(b.expand(-1, K), 1.0).sample()
-    pk = (ga / (ga + gb)).clamp(0.001, 0.999)                      # (markers, K)
-    p = pk[:, pop]                                                  # (markers, n)
-    g = (torch.rand(p.shape, generator=gen, device=dev) < p).to(torch.int8) + (torch.rand(p.shape, generator=gen, device=dev) < p).to(torch.int8) - 1
-    sh.Mt8[r0:r1, :n] = g
-sh.M8 = sh.M4 = None
-sh.Mt8s = None
+sh.fill_structured(K=K, fst=fst, seed=5, pmin=PMIN)
 torch.cuda.synchronize()
 MMt, _, _ = run.mmt_build(1)
 ev = torch.linalg.eigvalsh(MMt)
@@ -45,6 +31,13 @@ for tune, name in ((29, "worst-case count"), (0, "with the spectral bound")):
     S_used = sh.vara_i8_info()[0]
     print("%-24s digits used %d cut %d specH %.3g  step %.2f ms (vara kernel + extension %.2f, certify %.2f)  certificate %s  selected %s"
           % (name, S_used, sh.last_sliced, sh.last_specH, el / 3 * 1e3, parts["kern"] * 1e3, parts["cert"] * 1e3, sh.certificate(), sel))
+    ct = sh.certificate()
+    print("    certificate enforced 1.8 x %.0e (over the tight threshold: %d markers, switch above 512)"
+          % (sh.last_budget_loose if ct["over_tight"] > 512 else sh.last_budget, ct["over_tight"]))
+    wi = sh.w_info()
+    print("    budget in force %.0e level %d;  W engine: int8=%d declined=%d (k,T)=(%d,%d)+(%d,%d) eta/mean|W_kk| %.2e  W %.2f ms"
+          % (sh.last_budget, sh.last_level, wi["int8"], wi["declined"], wi["k1"], wi["T1"], wi["k2"], wi["T2"],
+             wi["eta"] / wi["mean_diag"] if wi["mean_diag"] else 0.0, parts["w"] * 1e3))
 sh.L.eagle_dev_set_tune(sh.ctx, 0)
 if sh.last_specH > 0:
     q2 = sh.l1[:L, 1].double(); l1 = sh.l1[:L, 0].double()
