@@ -1006,16 +1006,23 @@ static int upload_square_staged(eagle_ctx* ctx, const double* host, long n, long
     std::vector<hipEvent_t> block_events;
     int rcb = EAGLE_OK;
     long k = 0, block0 = 0;
+    double t_wait = 0, t_copy = 0, t_issue = 0, t_cb = 0;   // (EAGLE_HIP_TIMING: where the host side of the upload spends its time)
+    const bool timed = timing_on();
+    const double t_begin = timed ? now_s() : 0.0;
     for (long r0 = 0; r0 < n && e == hipSuccess && !rcb; k++) {
         long nr = std::min(rows_per, n - r0);
         if (on_block && block_rows > 0) nr = std::min(nr, block0 + block_rows - r0);   // pieces end at block boundaries
+        double tq = timed ? now_s() : 0.0;
         if (k >= 2) e = hipEventSynchronize(ev[k & 1]);   // the DMA that last read this buffer
         if (e != hipSuccess) break;
+        if (timed) { const double t = now_s(); t_wait += t - tq; tq = t; }
         char* dst = (char*)ctx->stage_pin[k & 1];
         const char* src = (const char*)(host + r0 * n);
         parallel_for((long)(rowb * (size_t)nr), threads, [&](long a, long b, int) { memcpy(dst + a, src + a, (size_t)(b - a)); });
+        if (timed) { const double t = now_s(); t_copy += t - tq; tq = t; }
         e = hipMemcpy2DAsync(dev + r0 * np, sizeof(double) * np, dst, rowb, rowb, (size_t)nr, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipEventRecord(ev[k & 1], st);
+        if (timed) { const double t = now_s(); t_issue += t - tq; tq = t; }
         r0 += nr;
         if (on_block && e == hipSuccess && (r0 == block0 + block_rows || r0 == n)) {
             // the block [block0, r0) is on its way; the last one takes the zero padding rows n .. n_pad along (block_rows is a multiple
@@ -1026,7 +1033,15 @@ static int upload_square_staged(eagle_ctx* ctx, const double* host, long n, long
             if (e == hipSuccess) { block_events.push_back(be); e = hipEventRecord(be, st); }
             if (e == hipSuccess) rcb = on_block(block0, end, be);
             block0 = end;
+            if (timed) t_cb += now_s() - tq;
         }
+    }
+    if (timed) {
+        const double t_loop = now_s() - t_begin;
+        (void)hipStreamSynchronize(st);
+        fprintf(stderr, "[eaglehip] staged upload %ld x %ld (%d threads, %ld pieces): host loop %.1f ms = waiting for a buffer %.1f + memcpy %.1f (%.1f GB/s) + "
+                "issue %.1f + block callbacks %.1f; all landed after %.1f ms (%.1f GB/s)\n", n, n, threads, k, t_loop * 1e3, t_wait * 1e3, t_copy * 1e3,
+                rowb * (double)n / 1e9 / std::max(t_copy, 1e-9), t_issue * 1e3, t_cb * 1e3, (now_s() - t_begin) * 1e3, rowb * (double)n / 1e9 / (now_s() - t_begin));
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);   // (the staging buffers serve other loaders after this call)
     for (int b = 0; b < 2; b++) (void)hipEventDestroy(ev[b]);
@@ -1369,6 +1384,13 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
     double *Sa = nullptr, *Va = nullptr, *tmp = nullptr, *Wu = nullptr, *ah = nullptr, *v = nullptr;
     bool s_from_cache = false;  // the product runs on the device copy of the last call's S; the caller's S is verified under it
     bool s_check_pending = false;  // ... and the outcome of that verification has not been collected yet
+    struct Helper {   // the thread that issues a deferred verification (joined on every way out)
+        std::thread t;
+        int rc = EAGLE_OK;
+        void start(const std::function<int()>& f) { t = std::thread([this, f] { rc = f(); }); }
+        int join() { if (t.joinable()) t.join(); return rc; }
+        ~Helper() { if (t.joinable()) t.join(); }
+    } s_verify;
     void *ws = nullptr, *cert = nullptr;
     long* cert_totals = (long*)((char*)ctx->d_scratch + EAGLE_SCR_CERT_TOTALS);  // {re-evaluated, flagged, fell back, over the tight threshold}, summed over marker blocks
     ChunkRing ring;
@@ -1522,24 +1544,34 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
         }
     }
     if (!rc && s_from_cache) {
-        // under the product: the caller's S to the scratch copy (loader stream), compared with the cached one.  One resident block
+        // under the scan: the caller's S to the scratch copy (loader stream), compared with the cached one.  One resident block
         // on one device: nothing below needs the host before the results go back, so the answer is collected only then (S's 800 MB
-        // at n = 10,000 then hide under the whole scan, not under W alone: on a host whose pageable copies run at 25 GB/s the
-        // two uploads of a call took 64 ms against W's 47); otherwise (marker blocks, several devices: the host is in the loop
-        // anyway) right here.
+        // at n = 10,000 then hide under the whole scan, not under W alone); otherwise (marker blocks, several devices: the host is
+        // in the loop anyway) right here.
+        // Round 4: a copy out of PAGEABLE memory blocks the calling thread until the runtime has staged it (14 ms for 800 MB), and since
+        // the int8 W ends with a host read of its statistics nothing was queued behind it any more: the card sat idle for those 14 ms
+        // (rocprofv3 timeline of the call, tools/upload_probe.py).  The deferred verification is therefore issued from a helper thread
+        // while this one goes on queueing the genotype pass and the vara kernel.
         int* flag = (int*)((char*)ctx->d_scratch + EAGLE_SCR_SCACHE_FLAG);
         if (!ctx->h_flag && (e = hipHostMalloc((void**)&ctx->h_flag, 64, hipHostMallocDefault)) != hipSuccess) rc = eagle_fail_hip(ctx, e, "pinned flag");
-        if (!rc) {
+        auto verify = [ctx, flag, inv_MMt_sqrt, n, np]() -> int {
+            hipError_t ev = hipSetDevice(ctx->device);
+            if (ev != hipSuccess) return eagle_fail_hip(ctx, ev, "hipSetDevice");
             *ctx->h_flag = 0;
-            e = hipMemsetAsync(flag, 0, sizeof(int), ctx->load_stream);
-            if (e == hipSuccess) rc = upload_square_on(ctx, inv_MMt_sqrt, n, np, ctx->d_Sscr, ctx->load_stream);
-            if (e == hipSuccess && !rc) {
-                hipLaunchKernelGGL(k_bits_differ, dim3(1024), dim3(256), 0, ctx->load_stream, (const unsigned long long*)ctx->d_Sscr,
-                                   (const unsigned long long*)ctx->d_Scache, np * np, flag);
-                e = hipMemcpyAsync(ctx->h_flag, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->load_stream);
-            }
-            if (e != hipSuccess && !rc) rc = eagle_fail_hip(ctx, e, "verification of the cached S");
+            ev = hipMemsetAsync(flag, 0, sizeof(int), ctx->load_stream);
+            if (ev != hipSuccess) return eagle_fail_hip(ctx, ev, "verification of the cached S");
+            int r = upload_square_on(ctx, inv_MMt_sqrt, n, np, ctx->d_Sscr, ctx->load_stream);
+            if (r) return r;
+            hipLaunchKernelGGL(k_bits_differ, dim3(1024), dim3(256), 0, ctx->load_stream, (const unsigned long long*)ctx->d_Sscr,
+                               (const unsigned long long*)ctx->d_Scache, np * np, flag);
+            ev = hipMemcpyAsync(ctx->h_flag, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->load_stream);
+            if (ev != hipSuccess) return eagle_fail_hip(ctx, ev, "verification of the cached S");
+            return EAGLE_OK;
+        };
+        if (!rc) {
             s_check_pending = true;
+            if (streamed || bounds_flow || rv) rc = verify();
+            else s_verify.start(verify);
         }
         // (rv: a device of a multi-device call must not defer -- a peer that streams or holds no cached S settles a changed S inline,
         // and a deferred restart of this one would pass every rendezvous of the call a second time)
@@ -1701,6 +1733,8 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
 #undef EAGLE_ARRIVE
 #undef EAGLE_ARRIVE2
     if (s_check_pending) {   // the deferred outcome of the verification of the cached S (nothing of the caller's S may be in flight past here)
+        const int rs = s_verify.join();
+        if (rs && !rc) rc = rs;
         e = hipStreamSynchronize(ctx->load_stream);
         if (e != hipSuccess && !rc) rc = eagle_fail_hip(ctx, e, "verification of the cached S");
         if (!rc && *ctx->h_flag) {
