@@ -116,8 +116,9 @@ def set_scan_rounding(stochastic, device=0):
 
 
 def set_scan_budget(relative_budget, device=0):
-    """Relative digit budget of the int8 scan (default 5e-7 = half of the path's 1e-6 tolerance; 1e-7 = rounds 1-2).  The certificate
-    sends every marker whose own bound exceeds 1.8 x budget to the fp64 kernel."""
+    """Relative digit budget of the int8 scan.  A context whose budget was never set tries 1e-7 first and falls back to 5e-7 (half of the
+    path's 1e-6 tolerance); a value given here becomes THE budget, 0 restores that default policy.  The certificate sends every marker
+    whose own bound exceeds 1.8 x the budget it enforces (last_scan_enforced) to the fp64 kernel."""
     ctx = context(device)
     _check(ctx, _lib.load().eagle_set_scan_budget(ctx, float(relative_budget)))
 

@@ -215,7 +215,7 @@ def test_context_stops_saving_after_a_fallback(tmp_path):
         api.calculate_a_and_vara_rcpp(geno["asciifileMt"], np.nan, S, V, 8.0, (L, n), ahat)
         assert api.last_scan_digits()[2] > 0.0         # re-armed
     finally:
-        api.set_scan_budget(5e-7)
+        api.set_scan_budget(0)                         # the default policy again (1e-7 first, then 5e-7) for whoever shares the context
         api.drop_cache()
 
 
@@ -351,6 +351,7 @@ def test_extension_is_a_per_marker_decision_resident_and_streamed(tmp_path, monk
         assert api.last_scan_digits() == d1 and api.last_scan_certificate() == c1
     finally:
         monkeypatch.delenv("EAGLE_HIP_MAX_RESIDENT_GB", raising=False)
+        api.set_scan_budget(0)
         api.drop_cache()
 
 
@@ -376,5 +377,7 @@ def test_extension_over_two_contexts_sharing_one_card(tmp_path):
         assert api.last_scan_argmax(device=(0, 0))[:2] == b1
         assert not api.last_scan_certificate(device=(0, 0))[2]
     finally:
+        api.set_scan_budget(0)
+        api.set_scan_budget(0, device=(0, 0))
         api.drop_cache()
         api.drop_cache(device=(0, 0))

@@ -23,6 +23,7 @@ def panel():
     import bench
     from eagleeverything_amd.sharded import DeviceShard
     sh = DeviceShard(N, L)
+    sh._check(sh.L.eagle_set_scan_budget(sh.ctx, 0.0))   # the default policy, whatever an earlier test left on the shared context
     sh.fill_structured(K=2, fst=0.5, seed=5)
     c32 = sh.mmt_partial()
     MMt, _ = sh.mmt_finish(c32, normalise=True)
