@@ -389,6 +389,7 @@ extern "C" void eagle_close(eagle_ctx* ctx) {
     if (ctx->d_pack2) (void)hipFree(ctx->d_pack2);
     for (int b = 0; b < 2; b++) { if (ctx->stage_pin[b]) (void)hipHostFree(ctx->stage_pin[b]); if (ctx->stage_raw[b]) (void)hipFree(ctx->stage_raw[b]); }
     if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
+    free(ctx->h_Scache);
     (void)hipStreamDestroy(ctx->stream);
     if (ctx->load_stream) (void)hipStreamDestroy(ctx->load_stream);
     delete ctx;
@@ -1375,6 +1376,9 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
     // certified against ONE lower bound of the maximum over every block of every device, so that the candidates, and with them every
     // returned bit, are those of the one-block scan of the whole file (the per-marker bounds of all blocks stay: 8 bytes per marker).
     const bool bounds_flow = use_i8 && (streamed || rv);
+    // one resident block on one device: the caller's S is compared with a HOST copy of the cached one (memcmp on the cores that idle while
+    // the card works) -- measured: the 800 MB upload + device comparison under the vara kernel cost the call 3.4 ms of 141.5 at the headline size
+    const bool host_verify = !streamed && !rv && !getenv("EAGLE_HIP_NO_HOST_SVERIFY");
     long over_tight_all = 0;   // markers of the whole scan over the tight threshold (CERT_TIGHT_MAX)
     const long Lc = streamed ? stream_chunk_rows(np, Lp) : Lp;  // marker rows per pass
     DevBuf dsel;
@@ -1391,6 +1395,9 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
         int join() { if (t.joinable()) t.join(); return rc; }
         ~Helper() { if (t.joinable()) t.join(); }
     } s_verify;
+    int host_flag_store = 0;
+    int* const host_flag = &host_flag_store;   // outcome of a HOST-side verification (1: the caller's S differs from the cached one)
+    int s_check_kind = 0;   // what s_check_pending waits for: 1 = the device comparison, 2 = the host comparison, 3 = only the refresh of the host copy
     void *ws = nullptr, *cert = nullptr;
     long* cert_totals = (long*)((char*)ctx->d_scratch + EAGLE_SCR_CERT_TOTALS);  // {re-evaluated, flagged, fell back, over the tight threshold}, summed over marker blocks
     ChunkRing ring;
@@ -1443,8 +1450,34 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
                 else { if (ctx->d_Scache) (void)hipFree(ctx->d_Scache); ctx->d_Scache = nullptr; (void)hipGetLastError(); }
             }
             if (cacheable && ctx->scache_np == np) {
-                s_from_cache = ctx->scache_n == n && !s_trusted;
-                if (!s_from_cache && !s_trusted && (r = upload_square(ctx, inv_MMt_sqrt, n, np, ctx->d_Scache))) return r;
+                // (EAGLE_HIP_EXPERIMENT_TRUST_S: measurement only -- what the verification traffic costs the kernels it runs under; never set it
+                // for real work: a changed S would go unnoticed)
+                const bool trust = s_trusted || (ctx->scache_n == n && getenv("EAGLE_HIP_EXPERIMENT_TRUST_S"));
+                s_from_cache = ctx->scache_n == n && !trust;
+                if (!s_from_cache && !trust) {
+                    if ((r = upload_square(ctx, inv_MMt_sqrt, n, np, ctx->d_Scache))) return r;
+                    ctx->h_Scache_n = 0;
+                }
+                if (!s_from_cache && host_verify && ctx->h_Scache_n != n) {
+                    // the device copy is (about to be) this caller's S: its host copy is made off the critical path, joined before the call returns
+                    const size_t bytes = sizeof(double) * (size_t)n * (size_t)n;
+                    if (bytes > ctx->h_Scache_cap) {
+                        free(ctx->h_Scache);
+                        ctx->h_Scache = (double*)malloc(bytes);
+                        ctx->h_Scache_cap = ctx->h_Scache ? bytes : 0;
+                    }
+                    if (ctx->h_Scache) {
+                        s_check_pending = true;   // (nothing to check: only the join)
+                        s_check_kind = 3;
+                        s_verify.start([ctx, inv_MMt_sqrt, n, bytes]() -> int {
+                            parallel_for((long)bytes, std::max(1, std::min(host_threads(), 16)), [&](long a, long b, int) {
+                                memcpy((char*)ctx->h_Scache + a, (const char*)inv_MMt_sqrt + a, (size_t)(b - a));
+                            });
+                            ctx->h_Scache_n = n;
+                            return EAGLE_OK;
+                        });
+                    }
+                }
                 ctx->scache_n = n;
                 Sa = ctx->d_Scache;
             } else if ((r = upload_square(ctx, inv_MMt_sqrt, n, np, Sa))) return r;
@@ -1570,19 +1603,36 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
         };
         if (!rc) {
             s_check_pending = true;
-            if (streamed || bounds_flow || rv) rc = verify();
-            else s_verify.start(verify);
+            if (host_verify && ctx->h_Scache && ctx->h_Scache_n == n) {
+                s_check_kind = 2;
+                *host_flag = 0;
+                s_verify.start([ctx, inv_MMt_sqrt, n, host_flag]() -> int {
+                    const size_t bytes = sizeof(double) * (size_t)n * (size_t)n;
+                    std::atomic<int> differs{0};
+                    parallel_for((long)bytes, std::max(1, std::min(host_threads(), 16)), [&](long a, long b, int) {
+                        if (memcmp((const char*)ctx->h_Scache + a, (const char*)inv_MMt_sqrt + a, (size_t)(b - a)) != 0) differs.store(1);
+                    });
+                    *host_flag = differs.load();
+                    return EAGLE_OK;
+                });
+            } else {
+                s_check_kind = 1;
+                if (streamed || bounds_flow || rv) rc = verify();
+                else s_verify.start(verify);
+            }
         }
         // (rv: a device of a multi-device call must not defer -- a peer that streams or holds no cached S settles a changed S inline,
         // and a deferred restart of this one would pass every rendezvous of the call a second time)
         if (s_check_pending && (streamed || bounds_flow || rv || rc)) {
             s_check_pending = false;
+            (void)s_verify.join();
             e = hipStreamSynchronize(ctx->load_stream);
             if (e != hipSuccess && !rc) rc = eagle_fail_hip(ctx, e, "verification of the cached S");
-            if (!rc && *ctx->h_flag) {  // another S: it is already on the device -- start the product over with it
+            if (!rc && s_check_kind == 1 && *ctx->h_flag) {  // another S: it is already on the device -- start the product over with it
                 if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) rc = eagle_fail_hip(ctx, e, "scan operands");
                 std::swap(ctx->d_Scache, ctx->d_Sscr);
                 Sa = ctx->d_Scache;
+                ctx->h_Scache_n = 0;
                 if (!rc) rc = eagle_dev_scan_operands(ctx, Sa, Va, ah, n, np, v, Wu, tmp, ctx->stream);
                 ctx->scache_misses++;
             } else if (!rc) ctx->scache_hits++;
@@ -1737,15 +1787,24 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
         if (rs && !rc) rc = rs;
         e = hipStreamSynchronize(ctx->load_stream);
         if (e != hipSuccess && !rc) rc = eagle_fail_hip(ctx, e, "verification of the cached S");
-        if (!rc && *ctx->h_flag) {
+        if (!rc && s_check_kind == 1 && *ctx->h_flag) {
             // another S than the cached one: this scan ran on the wrong operand.  The caller's S is on the device already (the scratch
             // copy): it becomes the cached one and the scan starts over, once, without another verification.
             if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return eagle_fail_hip(ctx, e, "scan on a stale S");
             std::swap(ctx->d_Scache, ctx->d_Sscr);
+            ctx->h_Scache_n = 0;
             ctx->scache_misses++;
             return scan_range(ctx, f_name_ascii, L, n, m0, m1, sel, inv_MMt_sqrt, dim_reduced_vara, a, max_memory_in_Gbytes, quiet, a_out, vara_out, k, nd,
                               rv, rccl, w_direct, true);
-        } else if (!rc) ctx->scache_hits++;
+        } else if (!rc && s_check_kind == 2 && *host_flag) {
+            // (host comparison) the caller's S is not on the device: the cache is dropped and the scan starts over with an upload
+            if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return eagle_fail_hip(ctx, e, "scan on a stale S");
+            ctx->scache_n = 0;
+            ctx->h_Scache_n = 0;
+            ctx->scache_misses++;
+            return scan_range(ctx, f_name_ascii, L, n, m0, m1, sel, inv_MMt_sqrt, dim_reduced_vara, a, max_memory_in_Gbytes, quiet, a_out, vara_out, k, nd,
+                              rv, rccl, w_direct, false);
+        } else if (!rc && s_check_kind != 3) ctx->scache_hits++;
     }
     if (timing_on() && !rc) {
         (void)hipStreamSynchronize(ctx->stream);

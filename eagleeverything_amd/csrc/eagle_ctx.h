@@ -71,6 +71,9 @@ struct eagle_ctx {
     // S = inv_MMt_sqrt of the last scan, kept on the device: MMt^-1/2 is the same matrix in every find_qtl call of an AM() run
     // (scan_range: the next call computes on this copy while the caller's matrix is uploaded and compared under the product)
     double* d_Scache = nullptr; double* d_Sscr = nullptr; long scache_n = 0, scache_np = 0; long scache_hits = 0, scache_misses = 0;
+    // host copy of the cached S (n x n as the caller passed it): one resident block on one device verifies the caller's S against it with the
+    // host's idle cores (memcmp) instead of sending 8 n^2 bytes over PCIe and through HBM under the vara kernel; h_Scache_n = 0: none
+    double* h_Scache = nullptr; long h_Scache_n = 0; size_t h_Scache_cap = 0;
     // out-of-core bookkeeping of the last streamed call on this device (eagle_last_stream_stats)
     long st_chunks = 0, st_file_bytes = 0;
     double st_pread_s = 0, st_load_wall_s = 0, st_wait_s = 0, st_compute_s = 0, st_total_s = 0, st_starved_s = 0, st_load_first_s = 0;
