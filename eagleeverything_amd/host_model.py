@@ -111,7 +111,37 @@ def calculateP(H, X):
     return np.subtract(Hinv, T, out=T)
 
 
+_mmt_sqrt_memo = {"key": None, "value": None}
+
+
+def _content_key(A):
+    """Identity of a matrix by content (a 128-bit hash of its bytes: 60 ms for 800 MB, against seconds of eigen-decomposition)."""
+    import xxhash
+    order = "C"
+    if not A.flags.c_contiguous:
+        if A.flags.f_contiguous:
+            A, order = A.T, "F"       # the same bytes, read in place
+        else:
+            A = np.ascontiguousarray(A)
+    return (A.shape, order, A.dtype.str, xxhash.xxh3_128_hexdigest(memoryview(A).cast("B")))
+
+
 def calculateMMt_sqrt_and_sqrtinv(MMt, checkres=True):
+    """eigen(MMt, symmetric=TRUE); sqrt = U diag(sqrt(l)) U^T ; invsqrt = chol2inv(chol(sqrt)).
+
+    MMt is the same matrix in every iteration of an AM() run, yet find_qtl.R:19 calls this every time (1.6 s per iteration on the
+    device, 12 s on host LAPACK at n = 10,000): the last result is kept and returned for a matrix with the same CONTENT.  The kept
+    matrices are column-major, the layout the C ABI takes them in, so the wrapper does not copy 800 MB per call either."""
+    key = (_la.name, _content_key(MMt))
+    if _mmt_sqrt_memo["key"] == key:
+        return _mmt_sqrt_memo["value"]
+    r = _calculateMMt_sqrt_and_sqrtinv(MMt, checkres)
+    r = {k: np.asfortranarray(v) for k, v in r.items()}
+    _mmt_sqrt_memo["key"], _mmt_sqrt_memo["value"] = key, r
+    return r
+
+
+def _calculateMMt_sqrt_and_sqrtinv(MMt, checkres=True):
     """eigen(MMt, symmetric=TRUE); sqrt = U diag(sqrt(l)) U^T ; invsqrt = chol2inv(chol(sqrt))."""
     if _la.name == "device":  # the whole function in one C-ABI call, the matrices staying in HBM between its steps
         r = _la.api.mmt_sqrt_and_sqrtinv(MMt, device=_la.device)
