@@ -74,6 +74,9 @@ struct eagle_ctx {
     // host copy of the cached S (n x n as the caller passed it): one resident block on one device verifies the caller's S against it with the
     // host's idle cores (memcmp) instead of sending 8 n^2 bytes over PCIe and through HBM under the vara kernel; h_Scache_n = 0: none
     double* h_Scache = nullptr; long h_Scache_n = 0; size_t h_Scache_cap = 0;
+    // above 16,384 padded individuals no second device copy of S is kept (20 GB at n = 50,000): the last scan's S is still in its ARENA slot
+    // when nothing has re-laid the arena since, and the next scan computes on it if the host comparison agrees (arena_S_ptr: that slot, else null)
+    const void* arena_S_ptr = nullptr; const void* arena_S_base = nullptr; long arena_S_n = 0, arena_S_np = 0;
     // out-of-core bookkeeping of the last streamed call on this device (eagle_last_stream_stats)
     long st_chunks = 0, st_file_bytes = 0;
     double st_pread_s = 0, st_load_wall_s = 0, st_wait_s = 0, st_compute_s = 0, st_total_s = 0, st_starved_s = 0, st_load_first_s = 0;

@@ -973,6 +973,58 @@ def test_cached_S_is_verified_and_never_changes_a_result(api, tmp_path, monkeypa
     api.drop_cache()
 
 
+@pytest.mark.parametrize("streamed", [False, True])
+def test_S_kept_in_its_arena_slot_above_the_cache_limit(api, tmp_path, monkeypatch, streamed):
+    """Above 16,384 padded individuals no second device copy of S is kept (20 GB at n = 50,000): the last scan's S is still in its arena
+    slot when nothing has re-laid the arena since, the next scan computes on it, and the caller's matrix is compared with a host copy
+    while the card works (a streamed file too).  EAGLE_HIP_SCACHE_MAX_NP=0 forces that form here.  Same S -> a hit and no upload;
+    a changed S, an MM^T call in between (its background allocation may replace the arena) or a dropped cache -> an upload; always the
+    bits of a call with the mechanism switched off."""
+    n, L = 900, 5000
+    rng = np.random.default_rng(8)
+    Mt8 = synth.genotypes_marker_major(n, L, seed=31)
+    geno = synth.write_geno_pair(str(tmp_path), Mt8)
+    A = rng.standard_normal((n, 30)) / 6.0
+    S = np.asfortranarray(np.eye(n) + A @ A.T)
+    V1 = np.asfortranarray(0.6 * np.eye(n) - 0.02 * (A[:, :5] @ A[:, :5].T))
+    V2 = np.asfortranarray(0.9 * np.eye(n) - 0.01 * (A[:, 5:9] @ A[:, 5:9].T))
+    ahat = rng.standard_normal(n)
+    S2 = S.copy(order="F")
+    S2[n // 2, n // 3] += 1e-3
+    call = lambda Sx, Vx: api.calculate_a_and_vara_rcpp(geno["asciifileMt"], NA, Sx, Vx, 8.0, (L, n), ahat)
+    api.drop_cache()
+    if streamed:
+        monkeypatch.setenv("EAGLE_HIP_MAX_RESIDENT_GB", "%.6f" % (1.6 * 1024 * 1024 / 1e9))   # marker blocks of 1,024
+    monkeypatch.setenv("EAGLE_HIP_NO_SCACHE", "1")
+    ref = {k: call(*k_args) for k, k_args in (("S,V1", (S, V1)), ("S,V2", (S, V2)), ("S2,V2", (S2, V2)))}
+    monkeypatch.delenv("EAGLE_HIP_NO_SCACHE")
+    monkeypatch.setenv("EAGLE_HIP_SCACHE_MAX_NP", "0")
+    try:
+        api.drop_cache()
+        stats = [api.scan_operand_cache_stats()]
+        got = []
+        for Sx, Vx, key in ((S, V1, "S,V1"), (S, V2, "S,V2"), (S2, V2, "S2,V2"), (S2, V2, "S2,V2")):
+            got.append((call(Sx, Vx), key))
+            stats.append(api.scan_operand_cache_stats())
+            if streamed:
+                assert api.last_stream_stats()["chunks"] > 1
+        d = [(b[0] - a[0], b[1] - a[1]) for a, b in zip(stats, stats[1:])]
+        assert d == [(0, 0), (1, 0), (0, 1), (1, 0)], d            # filled; hit; another S detected; hit on that one
+        api.calculateMMt_rcpp(geno["asciifileM"], 8.0, 4, NA, (n, L))     # (may start a background allocation that replaces the arena)
+        got.append((call(S2, V1), None))
+        got.append((call(S2, V2), "S2,V2"))
+        api.drop_cache()
+        got.append((call(S2, V2), "S2,V2"))                       # arena gone: uploaded again
+        h, m = api.scan_operand_cache_stats()
+        assert m == stats[-1][1]                                   # none of these was a wrong guess
+        for r, key in got:
+            if key:
+                np.testing.assert_array_equal(r["a"], ref[key]["a"])
+                np.testing.assert_array_equal(r["vara"], ref[key]["vara"])
+    finally:
+        api.drop_cache()
+
+
 def test_mmt_of_many_individuals_comes_back_through_the_staged_download(api, tmp_path):
     """n = 6,000: the 288 MB result returns through the two pinned staging buffers in 64 MiB pieces (csrc/eagle_api.cpp, download_big),
     a path the smaller shapes above never take; the normalised form too.  Exact against the integer product."""
