@@ -30,8 +30,10 @@ static std::vector<std::vector<int>> run_rounds(int n, int rounds, int bad, int 
                 // has already failed and arrived for the next round
                 if (bad_is_fast && k != bad) std::this_thread::sleep_for(std::chrono::milliseconds(2));
                 const bool ok = !(k == bad && r >= bad_round);
-                seen[(size_t)k][(size_t)r] = rv.arrive(ok, (double)(r * 100 + k)) ? 1 : 0;
+                seen[(size_t)k][(size_t)r] = rv.arrive(ok, (double)(r * 100 + k), (long)(r + k)) ? 1 : 0;
                 if (seen[(size_t)k][(size_t)r] == 1 && rv.vmax != (double)(r * 100 + n - 1)) g_fail++;  // the round's maximum, stable until the next arrival
+                // ... and the round's SUM (round 4: the markers over the tight threshold, added up over the devices of a scan)
+                if (seen[(size_t)k][(size_t)r] == 1 && rv.vsum != (long)n * r + (long)n * (n - 1) / 2) g_fail++;
             }
         });
     for (auto& t : th) t.join();
@@ -76,7 +78,9 @@ static void test_rendezvous() {
         rv.n = 1;
         CHECK(rv.arrive(true, NAN) && rv.vmax == -HUGE_VAL);
         CHECK(rv.arrive(true, 3.0) && rv.vmax == 3.0);
-        CHECK(rv.arrive(true) && rv.vmax == -HUGE_VAL);
+        CHECK(rv.arrive(true) && rv.vmax == -HUGE_VAL && rv.vsum == 0);
+        CHECK(rv.arrive(true, 1.0, 7) && rv.vsum == 7);
+        CHECK(rv.arrive(true) && rv.vsum == 0);   // a round's sum does not leak into the next
     }
 }
 
