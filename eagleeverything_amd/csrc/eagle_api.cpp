@@ -1412,6 +1412,10 @@ static int scan_range(eagle_ctx* ctx, const char* f_name_ascii, long L, long n, 
     // the device copy is (about to be) this caller's S: its host copy is made off the critical path, joined before the call returns
     auto refresh_host_copy = [&]() {
         const size_t bytes = sizeof(double) * (size_t)n * (size_t)n;
+        // (20 GB at n = 50,000: only when the host has that to spare four times over -- an overcommitted malloc would succeed and the
+        // copy then meet the OOM killer; without a host copy the small sizes verify on the device and the large ones upload S every call)
+        const long pages = sysconf(_SC_AVPHYS_PAGES), psz = sysconf(_SC_PAGESIZE);
+        if (bytes > ctx->h_Scache_cap && pages > 0 && psz > 0 && (double)bytes > 0.25 * (double)pages * (double)psz) return;
         if (bytes > ctx->h_Scache_cap) {
             free(ctx->h_Scache);
             ctx->h_Scache = (double*)malloc(bytes);
